@@ -1,0 +1,305 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE (build container only).
+
+Run from the repo root:   PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference (ThibHlln/smartpy v0.2.2, read-only at /root/reference) is pure Python; it is imported
+here, never copied, and never travels to the GPU box.  What is committed are numbers only: inputs and
+the outputs the reference produced for them, plus the values the reference's own tests/examples hold
+(G1..G4).  spotpy / netCDF4 are not installed, so a stub `spotpy` module (parameter.List /
+parameter.generate only) is injected to let the reference's montecarlo.LHS construct and sample; none
+of spotpy's arithmetic is involved in any vector stored here.
+"""
+import importlib
+import os
+import shutil
+import sys
+import tempfile
+import types
+from datetime import datetime, timedelta
+
+import numpy as np
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+# ---- stub spotpy so that smartpy.montecarlo imports (lhs.py:23-26, montecarlo.py:27-30) ---------------------
+spotpy = types.ModuleType('spotpy')
+spotpy.parameter = types.ModuleType('spotpy.parameter')
+
+
+class _List(object):
+    def __init__(self, name, values):
+        self.name, self.values = name, values
+
+
+spotpy.parameter.List = _List
+spotpy.parameter.generate = lambda params: None
+spotpy.algorithms = types.ModuleType('spotpy.algorithms')
+spotpy.objectivefunctions = types.ModuleType('spotpy.objectivefunctions')
+sys.modules['spotpy'] = spotpy
+sys.modules['spotpy.parameter'] = spotpy.parameter
+
+import smartpy  # noqa: E402  (the reference)
+from smartpy import structure  # noqa: E402
+
+assert not structure.smart_in_cpp, "the oracle must be the pure-Python path"
+
+EXTRA = {'aar': 1200, 'r-o_ratio': 0.45, 'r-o_split': (0.10, 0.15, 0.15, 0.30, 0.30)}
+AREA = 175.46 * 1e6
+NAMES = ['T', 'C', 'H', 'D', 'S', 'Z', 'SK', 'FK', 'GK', 'RK']
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print('%-28s %8.1f kB' % (name, os.path.getsize(path) / 1e3))
+
+
+def make_model(root, delta_simu, start='01/01/2007 09:00:00', end='31/12/2016 09:00:00', warm_up=365,
+               gauged=175.97 * 1e6):
+    return smartpy.SMART(
+        catchment='Catchment', catchment_area_m2=AREA,
+        start=datetime.strptime(start, '%d/%m/%Y %H:%M:%S'), end=datetime.strptime(end, '%d/%m/%Y %H:%M:%S'),
+        time_delta_simu=delta_simu, time_delta_save=timedelta(days=1), warm_up_days=warm_up,
+        in_format='csv', out_format='csv', root=root, gauged_area_m2=gauged)
+
+
+class Capture(object):
+    """Record what structure.run_all_steps returns (run() drops the final state, structure.py:143-146)."""
+
+    def __init__(self):
+        self.calls = []
+        self.orig = structure.run_all_steps
+
+    def __enter__(self):
+        def wrapped(*a):
+            r = self.orig(*a)
+            self.calls.append((a, r))
+            return r
+        structure.run_all_steps = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        structure.run_all_steps = self.orig
+
+
+def storage_table(area, dt, L, rain, peva, p, initial):
+    """The (L+1) x 19 table of structure.py:177-187, rebuilt by calling the reference's run_one_step."""
+    tab = np.zeros((L + 1, 19))
+    tab[0] = initial
+    for i in range(1, L + 1):
+        tab[i] = structure.run_one_step(area, dt, rain[i - 1], peva[i - 1], *p, *tab[i - 1, 7:])
+    return tab
+
+
+def main():
+    scratch = tempfile.mkdtemp(prefix='smart_golden_')
+    shutil.copytree(os.path.join(REF, 'tests', 'data'), os.path.join(scratch, 'data'))
+    root = os.path.join(scratch, 'data') + os.sep
+    for dirpath, _, files in os.walk(scratch):
+        os.chmod(dirpath, 0o755)
+        for f in files:
+            os.chmod(os.path.join(dirpath, f), 0o644)
+
+    # ---------------------------------------------------------------------------------------------------
+    # forcing + observations of the shipped example, as the reference's input pipeline delivers them
+    # ---------------------------------------------------------------------------------------------------
+    sm_h = make_model(root, timedelta(hours=1))
+    sm_d = make_model(root, timedelta(days=1))
+    sm_h.extra = EXTRA
+    sm_d.extra = EXTRA
+    sm_h.parameters.set_parameters_with_file(sm_h.in_f + 'Catchment.parameters')
+    p_ex = np.array([sm_h.parameters.values[n] for n in NAMES])
+    rain_d, peva_d = sm_d.nd_rain.copy(), sm_d.nd_peva.copy()
+    # the hourly series is the daily one split equally over 24 steps (timeframe.py:167-233)
+    assert np.array_equal(sm_h.nd_rain, np.repeat(rain_d / 24, 24))
+    assert np.array_equal(sm_h.nd_peva, np.repeat(peva_d / 24, 24))
+    assert np.array_equal(sm_h.nd_flow, sm_d.nd_flow, equal_nan=True)
+    save('forcing_example.npz', rain_daily=rain_d, peva_daily=peva_d, flow_obs=sm_h.nd_flow, area=AREA,
+         params=p_ex, extra=np.array([EXTRA['aar'], EXTRA['r-o_ratio']] + list(EXTRA['r-o_split'])))
+
+    # ---------------------------------------------------------------------------------------------------
+    # KAT-1 hourly, W=365 d, extra, shipped parameters, summary and raw (structure.py:189-195)
+    # ---------------------------------------------------------------------------------------------------
+    with Capture() as cap:
+        dis_s, gw_s = sm_h.simulate(sm_h.parameters.values, report='summary')
+    (a_wu, r_wu), (a_run, r_run) = cap.calls
+    init_wu, init_run, final_s = a_wu[6].copy(), a_run[6].copy(), r_run[2].copy()
+    with Capture() as cap:
+        dis_r, gw_r = sm_h.simulate(sm_h.parameters.values, report='raw')
+    final_r = cap.calls[1][1][2].copy()
+    first = storage_table(AREA, 3600.0, 48, sm_h.nd_rain, sm_h.nd_peva, p_ex, init_run)
+    save('kat1_hourly.npz', discharge_summary=dis_s, gw_summary=gw_s, final_summary=final_s,
+         discharge_raw=dis_r, gw_raw=gw_r, final_raw=final_r, initial_warmup=init_wu, initial_run=init_run,
+         first48=first, n_steps=len(sm_h.nd_rain), n_warm=365 * 24, gap=24)
+
+    # G2: the committed example output must be what the reference regenerates (examples/out/.../*.mod.flow)
+    g2 = np.loadtxt(os.path.join(REF, 'examples/out/ExampleDaily/ExampleDaily.mod.flow'), delimiter=',',
+                    skiprows=1, usecols=1)
+    assert [('%e' % v) for v in dis_s] == [('%e' % v) for v in g2]
+    g3 = np.genfromtxt(os.path.join(REF, 'examples/out/ExampleDaily/ExampleDaily.obs.flow'), delimiter=',',
+                       skip_header=1, usecols=1)
+    save('g2_g3_example_flows.npz', mod_flow=g2, obs_flow=g3)
+
+    # G1: the 91 dated values hard-coded in the reference's own test (tests/test_run_daily_to_hourly.py:30-122)
+    sys.path.insert(0, os.path.join(REF, 'tests'))
+    cwd = os.getcwd()
+    os.chdir(scratch)  # the test's setUp builds SMART(root="data/")
+    try:
+        tmod = importlib.import_module('test_run_daily_to_hourly')
+        tc = tmod.TestRunDaily2Hourly('test_compare_discharge_series')
+        tc.setUp()
+        idx = np.array([tc.sm.timeseries_report[1:].index(dt) for dt in tc.expected_outcome])
+        val = np.array([tc.expected_outcome[dt] for dt in tc.expected_outcome])
+    finally:
+        os.chdir(cwd)
+    assert all(('%.6e' % dis_s[i]) == ('%.6e' % v) for i, v in zip(idx, val))
+    save('g1_reference_test.npz', report_index=idx, expected=val)
+
+    # ---------------------------------------------------------------------------------------------------
+    # KAT-2 daily (gap = 1), KAT-3 no warm-up with / without extra
+    # ---------------------------------------------------------------------------------------------------
+    with Capture() as cap:
+        dis_d, gw_d = sm_d.simulate(sm_h.parameters.values)
+    save('kat2_daily.npz', discharge=dis_d, gw=gw_d, final=cap.calls[1][1][2], n_steps=len(rain_d), n_warm=365,
+         gap=1)
+
+    out3 = {}
+    for tag, extra in (('extra', EXTRA), ('noextra', None)):
+        for res, delta in (('daily', timedelta(days=1)), ('hourly', timedelta(hours=1))):
+            sm = make_model(root, delta, end='31/12/2008 09:00:00', warm_up=0)
+            sm.extra = extra
+            with Capture() as cap:
+                d, g = sm.simulate(sm_h.parameters.values)
+            out3['discharge_%s_%s' % (res, tag)] = d
+            out3['gw_%s_%s' % (res, tag)] = g
+            out3['final_%s_%s' % (res, tag)] = cap.calls[0][1][2]
+            out3['initial_%s_%s' % (res, tag)] = cap.calls[0][0][6]
+    save('kat3_nowarm.npz', n_days=731, **out3)
+
+    # ---------------------------------------------------------------------------------------------------
+    # KAT-7 LHS sampler (lhs.py:133-167) through the reference's own class, and KAT-4 batch on 32 rows
+    # ---------------------------------------------------------------------------------------------------
+    from smartpy.montecarlo.lhs import LHS
+    lhs = LHS.__new__(LHS)            # only _get_params_from_lh is exercised: needs model.parameters + names
+    lhs.model = sm_h
+    lhs.param_names = sm_h.parameters.names
+    out7 = {}
+    for seed in (0, 42, 2718):
+        for n in (5, 64, 1000):
+            np.random.seed(seed)
+            out7['seed%d_n%d' % (seed, n)] = lhs._get_params_from_lh(n)
+    save('kat7_lhs.npz', **out7)
+
+    np.random.seed(2718)
+    p32 = lhs._get_params_from_lh(32)
+    sm2 = make_model(root, timedelta(hours=1), end='31/12/2008 09:00:00', warm_up=365)
+    sm2.extra = EXTRA
+    dis_h2, gw_h2, dis_d10, gw_d10 = [], [], [], []
+    for row in p32:
+        par = dict(zip(NAMES, row))
+        d, g = sm2.simulate(par)
+        dis_h2.append(d.copy()); gw_h2.append(g)
+        d, g = sm_d.simulate(par)
+        dis_d10.append(d.copy()); gw_d10.append(g)
+    save('kat4_batch.npz', params=p32, discharge_hourly_2yr=np.array(dis_h2), gw_hourly_2yr=np.array(gw_h2),
+         discharge_daily_10yr=np.array(dis_d10), gw_daily_10yr=np.array(gw_d10), n_days_hourly=731)
+
+    # ---------------------------------------------------------------------------------------------------
+    # KAT-5 river "95 % rule" and zero clamps: daily steps with RK*3600 < dt (structure.py:429-450,492-496)
+    # ---------------------------------------------------------------------------------------------------
+    rows, tabs = [], []
+    for rk in (1.0, 2.0, 6.0, 12.0, 23.9):
+        for skv in (1.0, 5.0):
+            p = p_ex.copy()
+            p[9], p[6] = rk, skv
+            init = np.zeros(19)
+            init[7:12] = [3e4, 2e4, 5e5, 4e6, 6e6]
+            init[12:18] = (p[5] / 12) / 1000 * AREA
+            init[18] = 1e5
+            tabs.append(storage_table(AREA, 86400.0, 400, rain_d, peva_d, p, init))
+            rows.append(p)
+    save('kat5_river.npz', params=np.array(rows), tables=np.array(tabs), n_steps=400)
+
+    # raw report with a length that is not a multiple of the gap (structure.py:192-195)
+    init = first[0]
+    d_raw, g_raw, f_raw = structure.run_all_steps(AREA, 3600.0, 1000, sm_h.nd_rain, sm_h.nd_peva, p_ex, init, 2, 24)
+    d_big, g_big, f_big = structure.run_all_steps(AREA, 86400.0, 3653, rain_d, peva_d, p_ex, init, 2, 1)
+    save('kat9_raw_ragged.npz', initial=init, discharge=d_raw, gw=g_raw, final=f_raw, n_steps=1000, gap=24,
+         discharge_gap1=d_big, gw_gap1=g_big)
+
+    # ---------------------------------------------------------------------------------------------------
+    # KAT-6 single steps: every branch of structure.py:267-503, hand-made + random
+    # ---------------------------------------------------------------------------------------------------
+    rng = np.random.default_rng(20261002)
+    lo = np.array([0.9, 0.0, 0.0, 0.0, 0.0, 15.0, 1.0, 48.0, 1200.0, 1.0])
+    hi = np.array([1.1, 1.0, 0.3, 1.0, 0.013, 150.0, 240.0, 1440.0, 4800.0, 96.0])
+    cases = []
+
+    def add(area, dt, rain, peva, p, st):
+        cases.append((area, dt, rain, peva, np.array(p, float), np.array(st, float)))
+
+    def soil(p, frac):
+        return list(np.asarray(frac, float) * (p[5] / 6) / 1000 * AREA)
+
+    res5 = [3e4, 2e4, 5e5, 4e6, 6e6]
+    for dt in (3600.0, 86400.0):
+        p = p_ex.copy()
+        add(AREA, dt, 0.0, 0.0, p, res5 + soil(p, [0.5] * 6) + [1e5])              # ex == 0 exactly, wet path
+        add(AREA, dt, 1.5, 1.5, p, res5 + soil(p, [0.5] * 6) + [1e5])              # rain*T == peva (T = 1)
+        add(AREA, dt, 30.0, 0.1, p, res5 + soil(p, [1.0] * 6) + [1e5])             # saturated soil
+        add(AREA, dt, 30.0, 0.1, p, res5 + soil(p, [0.99, 1, 1, 0.5, 0, 0]) + [1e5])
+        add(AREA, dt, 200.0, 0.0, p, res5 + soil(p, [0.0] * 6) + [1e5])            # fills every layer, excess left
+        for c in (0.0, 0.5, 1.0):                                                  # empty soil, big deficit
+            q = p.copy(); q[1] = c
+            add(AREA, dt, 0.0, 5.0, q, res5 + soil(q, [0.0] * 6) + [1e5])
+            add(AREA, dt, 0.1, 9.0, q, res5 + soil(q, [0.01, 0.02, 0.0, 0.5, 0.0, 1.0]) + [1e5])
+        for k, v in ((4, 0.0), (2, 0.0), (3, 0.0), (3, 1.0)):                      # S = 0, H = 0, D in {0, 1}
+            q = p.copy(); q[k] = v
+            add(AREA, dt, 12.0, 0.3, q, res5 + soil(q, [0.9, 0.8, 1.0, 0.2, 0.0, 0.6]) + [1e5])
+        add(AREA, dt, 0.0, 0.0, p, [0.0] * 5 + soil(p, [0.0] * 6) + [0.0])         # everything empty (gw = 0/0)
+        q = p.copy(); q[9] = 1.0; q[6] = 1.0                                       # river rule + reservoir clamps
+        add(AREA, dt, 0.0, 2.0, q, res5 + soil(q, [0.5] * 6) + [1e5])
+        add(AREA, dt, 0.0, 2.0, q, res5 + soil(q, [0.5] * 6) + [0.0])
+    for _ in range(600):
+        p = lo + rng.random(10) * (hi - lo)
+        dt = float(rng.choice([3600.0, 86400.0, 900.0]))
+        area = float(np.exp(rng.uniform(np.log(20e6), np.log(2000e6))))
+        frac = rng.random(6) * rng.choice([0.0, 1.0, 1.0], 6)
+        frac[rng.random(6) < 0.2] = 1.0
+        st = list(rng.random(5) * [1e5, 1e5, 1e6, 1e7, 1e7] * rng.choice([0.0, 1.0, 1.0], 5)) + \
+            list(frac * (p[5] / 6) / 1000 * area) + [float(rng.random() * 1e6 * rng.choice([0.0, 1.0]))]
+        scale = dt / 86400.0
+        rain = float(rng.choice([0.0, 1.0, 1.0]) * rng.gamma(0.7, 4.57) * scale * rng.choice([1.0, 1.0, 20.0]))
+        peva = float(rng.choice([0.0, 1.0, 1.0]) * rng.random() * 3.0 * scale)
+        add(area, dt, rain, peva, p, st)
+    outs = np.array([structure.run_one_step(a, dt, r, e, *p, *st) for (a, dt, r, e, p, st) in cases])
+    save('kat6_steps.npz', area=np.array([c[0] for c in cases]), dt=np.array([c[1] for c in cases]),
+         rain=np.array([c[2] for c in cases]), peva=np.array([c[3] for c in cases]),
+         params=np.array([c[4] for c in cases]), states=np.array([c[5] for c in cases]), out=outs)
+
+    # ---------------------------------------------------------------------------------------------------
+    # G4: the committed sampling database of the example (float32 text), examples/out/.../*.SMART.lhs
+    # ---------------------------------------------------------------------------------------------------
+    with open(os.path.join(REF, 'examples/out/ExampleDaily/ExampleDaily.SMART.lhs')) as f:
+        header = f.readline().strip().split(',')
+    g4 = np.loadtxt(os.path.join(REF, 'examples/out/ExampleDaily/ExampleDaily.SMART.lhs'), delimiter=',', skiprows=1)
+    cols = {h: g4[:, i] for i, h in enumerate(header)}
+    # the run that produced it: ExampleDaily.sttngs (hourly simu, daily report, W = 365) + the notebook's extra
+    dis4, gw4 = [], []
+    for r in range(g4.shape[0]):
+        par = {n: float(cols[n][r]) for n in NAMES}
+        d, g = sm_h.simulate(par)
+        dis4.append(d.copy()); gw4.append(g)
+    save('g4_example_lhs.npz', params=np.array([cols[n] for n in NAMES]).T,
+         objfns=np.array([cols[n] for n in ['NSE', 'KGE', 'KGEc', 'KGEa', 'KGEb', 'PBias', 'RMSE', 'GW']]).T,
+         discharge=np.array(dis4), gw=np.array(gw4), gw_constraint=0.12667)
+
+    shutil.rmtree(scratch)
+
+
+if __name__ == '__main__':
+    main()
