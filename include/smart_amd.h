@@ -1,0 +1,157 @@
+/*
+ * smart_amd.h -- C ABI of the MI355X-native SMART ensemble engine (libsmart_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of ThibHlln/smartpy v0.2.2: the time loop
+ * structure.run -> run_all_steps -> run_one_step (smartpy/structure.py:30-503).  The reference already
+ * has a plug-in hook for exactly this path -- an optional extension module named `smartcpp`, looked up
+ * at import time (structure.py:22-27) and used as smartcpp.allsteps (structure.py:56-62) or
+ * smartcpp.onestep (structure.py:171-174).  Every entry point below states which reference interface
+ * it stands in for.  INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; no torch / numpy types cross this boundary;
+ *   - "device pointer" = memory the GPU can address (hipMalloc, or a torch.Tensor's data_ptr());
+ *   - every function returns 0 on success or a negative SMART_E_* code, never throws; the text of the
+ *     last error of the calling thread is available from smart_last_error();
+ *   - buffers are owned by the caller, are not retained after the call returns and inputs are never
+ *     written; launches are asynchronous on the given stream unless stated otherwise;
+ *   - no global mutable state besides the per-thread error text: calls on different streams may run
+ *     concurrently.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ *     SMART_E_NO_DEVICE.
+ *
+ * Vector layouts (all IEEE fp64)
+ *   parameters  p[10]  = T, C, H, D, S, Z, SK, FK, GK, RK                       (parameters.py:25)
+ *   variables   v[19]  = Q_aeva, Q_ove, Q_dra, Q_int, Q_sgw, Q_dgw, Q_out,
+ *                        V_ove, V_dra, V_int, V_sgw, V_dgw, V_ly1..V_ly6, V_river (structure.py:78-82)
+ *   extra       x[7]   = aar, r-o_ratio, r-o_split[5]                          (structure.py:100-112)
+ *   objectives  o[8]   = NSE, KGE, KGEc, KGEa, KGEb, PBias, RMSE, GW           (montecarlo.py:71-74)
+ */
+#ifndef SMART_AMD_H
+#define SMART_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMART_AMD_ABI_VERSION 1
+
+/* report_type, as structure.py:65-70 maps report='summary' / 'raw' */
+#define SMART_REPORT_SUMMARY 1
+#define SMART_REPORT_RAW 2
+
+/* math_mode */
+#define SMART_MATH_LITERAL 0 /* the reference's operation order, IEEE division, no FMA contraction:     */
+                             /* bit-identical to the CPU oracle configured with the product chain for   */
+                             /* s'**i (the only place where CPython calls libm)                         */
+#define SMART_MATH_FAST 1    /* reciprocals hoisted out of the time loop, soil layers kept in mm,       */
+                             /* reservoirs kept as outflows, FMA: <= 1e-11 relative on discharge         */
+
+/* error codes; the reference raises Exception at the cited places */
+#define SMART_OK 0
+#define SMART_E_NULL (-1)        /* a required pointer is NULL                                          */
+#define SMART_E_SIZE (-2)        /* a size is <= 0 or inconsistent                                      */
+#define SMART_E_REPORT_TYPE (-3) /* unknown report type                          (structure.py:69-70)   */
+#define SMART_E_WARMUP (-4)      /* warm-up longer than the simulation           (structure.py:90-95)   */
+#define SMART_E_GAP (-5)         /* summary report: length (or warm-up) is not a multiple of the gap    */
+                                 /* -- np.reshape raises                         (structure.py:190)     */
+#define SMART_E_NO_DEVICE (-6)   /* no HIP device / HIP runtime error (text in smart_last_error)        */
+#define SMART_E_MODE (-7)        /* unknown math mode                                                   */
+
+/*
+ * One ensemble launch = the whole per-sample loop that spotpy's sampler drives
+ * (montecarlo.py:153-154 -> :179-186 -> smart.py:204-207 -> structure.py:30-146), for n_samples
+ * parameter sets on each of n_catchments catchments.  One wavefront lane advances one sample; the time
+ * loop (warm-up then simulation) runs inside the kernel with parameters and the 12 states in registers.
+ *
+ * All pointers are device pointers.
+ */
+typedef struct SmartEnsemble {
+    /* ---- sizes -------------------------------------------------------------------------------- */
+    int64_t n_catchments; /* C >= 1                                                                 */
+    int64_t n_samples;    /* N >= 1 parameter sets per catchment                                    */
+    int64_t n_steps;      /* T = len(timeseries) - 1                          (structure.py:73)      */
+    int64_t n_warm;       /* W = int(warm_up_days * 86400 / delta_sec), 0 = none (structure.py:87-88); */
+                          /* the warm-up replays forcing[0 .. W)              (structure.py:118-121) */
+    int64_t report_gap;   /* g = T // R                                       (structure.py:75)      */
+    int32_t report_type;  /* SMART_REPORT_*                                                          */
+    int32_t math_mode;    /* SMART_MATH_*                                                            */
+    double delta_sec;     /* simulation time step in seconds                  (structure.py:74)      */
+
+    /* ---- inputs ------------------------------------------------------------------------------- */
+    const double *area_m2; /* [C]                                                                    */
+    const double *forcing; /* [C][T][2]: rain, peva in mm per step, interleaved (smart.py:141-142)   */
+    const double *params;  /* [N][10] row-major, exactly the matrix lhs.py:114 produces; or [C][N][10] */
+    int64_t params_catchment_stride; /* 0: every catchment runs the same N rows; else N*10          */
+    const double *extra;   /* [C][7] educated guess of the initial reservoirs, or NULL: start empty   */
+                           /*                                                 (structure.py:97-140)  */
+    const double *initial; /* [C][N][12] states to start from instead (chained runs), or NULL;        */
+                           /* used as the warm-up's start when n_warm != 0                           */
+    const double *obs;     /* [C][R] observed discharge, NaN = missing (smart.py:143), or NULL        */
+    const double *gw_obs;  /* [C] groundwater constraint (inout.py:134-139), NaN = none, or NULL      */
+
+    /* ---- outputs (each nullable except gw) ----------------------------------------------------- */
+    double *discharge;     /* [C][R][discharge_ld] sample-minor, so that a wavefront stores 512       */
+                           /* contiguous bytes per report step; element (c, r, n) = what              */
+                           /* SMART.simulate(row n)[0][r] returns                   (smart.py:208)   */
+    int64_t discharge_ld;  /* >= N                                                                   */
+    double *gw;            /* [C][N] groundwater contribution to runoff (structure.py:191,194-195)   */
+    double *objfn;         /* [C][N][8] objective functions (montecarlo.py:193-209); needs obs;       */
+                           /* column 7 (GW) is NaN where gw_obs is absent                            */
+    double *final_vars;    /* [C][N][19] last row of the storage table        (structure.py:197)     */
+    double *workspace;     /* [C][8 + R] scratch, required when objfn != NULL                        */
+
+    void *stream;          /* hipStream_t; NULL = the default stream                                 */
+} SmartEnsemble;
+
+/* Number of report steps R for a run (structure.py:190 / :193): T // g (summary), ceil(T / g) (raw). */
+int64_t smart_n_reports(int64_t n_steps, int64_t report_gap, int32_t report_type);
+
+/* Validate and launch.  Asynchronous on e->stream.  Stands in for the spotpy repetition loop over
+ * MonteCarlo.simulation + MonteCarlo.objectivefunction (montecarlo.py:179-209). */
+int smart_run_ensemble_hip(const SmartEnsemble *e);
+
+/* Validation only (no device needed): the checks smart_run_ensemble_hip performs before launching. */
+int smart_check_ensemble(const SmartEnsemble *e);
+
+/*
+ * smartcpp.allsteps -- same arguments and results as run_all_steps (structure.py:149-152,197).
+ * HOST pointers; synchronous (copies in, runs one sample on the GPU in SMART_MATH_LITERAL, copies out).
+ *   nd_rain / nd_peva hold at least length_simu values (the warm-up call passes the full series with a
+ *   shorter length, structure.py:118-121); nd_parameters[10]; nd_initial[19];
+ *   discharge[smart_n_reports(length_simu, report_gap, report_type)]; *groundwater_component;
+ *   final_vars[19].
+ */
+int smart_allsteps_hip(double area_m2, double delta_sec, int64_t length_simu, const double *nd_rain,
+                       const double *nd_peva, const double *nd_parameters, const double *nd_initial,
+                       int32_t report_type, int64_t report_gap, double *discharge,
+                       double *groundwater_component, double *final_vars);
+
+/*
+ * smartcpp.onestep -- run_one_step (structure.py:200-264): 2 constants, 2 forcings, 10 parameters and
+ * 12 states in, the 19-vector out.  HOST pointers; synchronous; n independent steps per call
+ * (n = 1 reproduces the reference's call at structure.py:182-187).
+ *   in[n][26]  = area, dt, rain, peva, T..RK, V_ove..V_river ;  out[n][19]
+ */
+int smart_onestep_hip(int64_t n, const double *in, double *out);
+
+/*
+ * Objective functions of an existing discharge matrix (montecarlo.py:193-209 applied to every sample),
+ * two-pass like the spotpy formulas.  Device pointers; asynchronous on stream.
+ *   sim[R][ld] sample-minor (the layout smart_run_ensemble_hip writes), obs[R] (NaN = missing),
+ *   gw_sim[N] and gw_obs: pass NULL / NaN to skip the GW column; objfn[N][8].
+ */
+int smart_objfn_hip(int64_t n_samples, int64_t n_reports, const double *sim, int64_t ld, const double *obs,
+                    const double *gw_sim, double gw_obs, double *objfn, void *stream);
+
+/* Device bookkeeping */
+int smart_device_count(void);           /* number of visible HIP devices (0 if none / no driver)      */
+int smart_abi_version(void);            /* SMART_AMD_ABI_VERSION the library was built with           */
+const char *smart_last_error(void);     /* text of the calling thread's last error ("" if none)       */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMART_AMD_H */

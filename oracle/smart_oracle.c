@@ -31,6 +31,8 @@
 
 #define SMART_SUM_NUMPY 0 /* report means / gw sums in numpy's pairwise order (bit-parity with ref)  */
 #define SMART_SUM_SEQ 1   /* plain left-to-right sums (what a streaming GPU kernel can do)           */
+#define SMART_SUM_GPU 2   /* what the HIP literal kernel does: numpy-ordered report means for gaps   */
+                          /* up to 128 (it stages a report interval in LDS), sequential gw sums      */
 
 #define SMART_REPORT_SUMMARY 1 /* structure.py:65-66 */
 #define SMART_REPORT_RAW 2     /* structure.py:67-68 */
@@ -260,7 +262,7 @@ int smart_oracle_all_steps(double area, double dt, long L, const double *rain, c
         for (long r = 0; r < R; ++r) {
             const double *q = tab + (1 + r * gap) * NVAR + 6;
             double s;
-            if (sum_mode == SMART_SUM_NUMPY) {
+            if (sum_mode == SMART_SUM_NUMPY || (sum_mode == SMART_SUM_GPU && gap <= 128)) {
                 s = np_pairwise(q, gap, NVAR);
             } else {
                 s = 0.0;
@@ -350,9 +352,10 @@ void smart_oracle_initial(double area, const double *p, const double *extra, dou
  * n_warm = int(warm_up_days * 86400 / dt) is computed by the caller.  final is nullable.
  * Returns 0; -1 for the reshape error; -4 when the warm-up is longer than the run (:90-95).
  */
-int smart_oracle_run(double area, double dt, long n_steps, long n_warm, const double *rain,
-                     const double *peva, const double *p, const double *extra, int report_type,
-                     long gap, int pow_mode, int sum_mode, double *discharge, double *gw, double *final)
+static int run_with_scratch(double area, double dt, long n_steps, long n_warm, const double *rain,
+                            const double *peva, const double *p, const double *extra, int report_type,
+                            long gap, int pow_mode, int sum_mode, double *discharge, double *gw,
+                            double *final, double *scratch)
 {
     double init[NVAR];
     if (n_warm != 0) {
@@ -365,7 +368,7 @@ int smart_oracle_run(double area, double dt, long n_steps, long n_warm, const do
         if (!dis_wu)
             return -3;
         int rc = smart_oracle_all_steps(area, dt, n_warm, rain, peva, p, init_wu, report_type, gap,
-                                        pow_mode, sum_mode, dis_wu, &gw_wu, init, NULL);
+                                        pow_mode, sum_mode, dis_wu, &gw_wu, init, scratch);
         free(dis_wu);
         if (rc)
             return rc;
@@ -373,7 +376,15 @@ int smart_oracle_run(double area, double dt, long n_steps, long n_warm, const do
         smart_oracle_initial(area, p, extra, init);
     }
     return smart_oracle_all_steps(area, dt, n_steps, rain, peva, p, init, report_type, gap, pow_mode,
-                                  sum_mode, discharge, gw, final, NULL);
+                                  sum_mode, discharge, gw, final, scratch);
+}
+
+int smart_oracle_run(double area, double dt, long n_steps, long n_warm, const double *rain,
+                     const double *peva, const double *p, const double *extra, int report_type,
+                     long gap, int pow_mode, int sum_mode, double *discharge, double *gw, double *final)
+{
+    return run_with_scratch(area, dt, n_steps, n_warm, rain, peva, p, extra, report_type, gap, pow_mode,
+                            sum_mode, discharge, gw, final, NULL);
 }
 
 /*
@@ -393,20 +404,27 @@ int smart_oracle_run_batch(long n_samples, double area, double dt, long n_steps,
     if (n_threads > 0)
         omp_set_num_threads(n_threads);
 #endif
-#pragma omp parallel for schedule(dynamic, 1)
-    for (long n = 0; n < n_samples; ++n) {
-        double *dis = discharge ? discharge + n * R : (double *)malloc(sizeof(double) * (size_t)(R > 0 ? R : 1));
-        double g = 0.0;
-        int rc = smart_oracle_run(area, dt, n_steps, n_warm, rain, peva, params + n * 10, extra,
-                                  report_type, gap, pow_mode, sum_mode, dis, &g,
-                                  final ? final + n * NVAR : NULL);
-        gw[n] = g;
-        if (!discharge)
-            free(dis);
-        if (rc) {
+#pragma omp parallel
+    {
+        /* one (L+1) x 19 table (structure.py:177) and one discharge row per thread, reused by its samples */
+        double *table = (double *)malloc(sizeof(double) * (size_t)(n_steps + 1) * NVAR);
+        double *row = (double *)malloc(sizeof(double) * (size_t)(R > 0 ? R : 1));
+#pragma omp for schedule(dynamic, 1)
+        for (long n = 0; n < n_samples; ++n) {
+            double g = 0.0;
+            int rc = (table && row) ? run_with_scratch(area, dt, n_steps, n_warm, rain, peva, params + n * 10,
+                                                       extra, report_type, gap, pow_mode, sum_mode,
+                                                       discharge ? discharge + n * R : row, &g,
+                                                       final ? final + n * NVAR : NULL, table)
+                                    : -3;
+            gw[n] = g;
+            if (rc) {
 #pragma omp critical
-            status = rc;
+                status = rc;
+            }
         }
+        free(table);
+        free(row);
     }
     return status;
 }

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libsmart_oracle.so")
 
 POW_LIBM, POW_MUL = 0, 1
-SUM_NUMPY, SUM_SEQ = 0, 1
+SUM_NUMPY, SUM_SEQ, SUM_GPU = 0, 1, 2
 REPORT_SUMMARY, REPORT_RAW = 1, 2
 NVAR = 19
 

@@ -1,0 +1,79 @@
+"""ctypes binding of libsmart_amd.so (the C ABI of include/smart_amd.h).
+
+The library is the product: there is no CPU fallback.  If the shared object is missing (not built) or
+cannot be loaded, importing the engine fails loudly with instructions, and every compute entry point
+returns SMART_E_NO_DEVICE when no HIP device is visible.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libsmart_amd.so')
+
+REPORT_SUMMARY, REPORT_RAW = 1, 2
+MATH_LITERAL, MATH_FAST = 0, 1
+
+_dp = ctypes.c_void_p   # device or host address, passed as an integer
+
+
+class SmartEnsemble(ctypes.Structure):
+    """struct SmartEnsemble of include/smart_amd.h (field for field)."""
+    _fields_ = [
+        ('n_catchments', ctypes.c_int64), ('n_samples', ctypes.c_int64), ('n_steps', ctypes.c_int64),
+        ('n_warm', ctypes.c_int64), ('report_gap', ctypes.c_int64),
+        ('report_type', ctypes.c_int32), ('math_mode', ctypes.c_int32), ('delta_sec', ctypes.c_double),
+        ('area_m2', _dp), ('forcing', _dp), ('params', _dp), ('params_catchment_stride', ctypes.c_int64),
+        ('extra', _dp), ('initial', _dp), ('obs', _dp), ('gw_obs', _dp),
+        ('discharge', _dp), ('discharge_ld', ctypes.c_int64), ('gw', _dp), ('objfn', _dp),
+        ('final_vars', _dp), ('workspace', _dp), ('stream', _dp),
+    ]
+
+
+# every symbol include/smart_amd.h declares: (restype, argtypes)
+SYMBOLS = {
+    'smart_n_reports': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32]),
+    'smart_run_ensemble_hip': (ctypes.c_int, [ctypes.POINTER(SmartEnsemble)]),
+    'smart_check_ensemble': (ctypes.c_int, [ctypes.POINTER(SmartEnsemble)]),
+    'smart_allsteps_hip': (ctypes.c_int, [ctypes.c_double, ctypes.c_double, ctypes.c_int64, _dp, _dp, _dp, _dp,
+                                          ctypes.c_int32, ctypes.c_int64, _dp, _dp, _dp]),
+    'smart_onestep_hip': (ctypes.c_int, [ctypes.c_int64, _dp, _dp]),
+    'smart_objfn_hip': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, _dp, ctypes.c_int64, _dp, _dp,
+                                       ctypes.c_double, _dp, _dp]),
+    'smart_device_count': (ctypes.c_int, []),
+    'smart_abi_version': (ctypes.c_int, []),
+    'smart_last_error': (ctypes.c_char_p, []),
+}
+
+_lib = None
+
+
+class SmartEngineError(Exception):
+    """Raised when the C ABI reports an error (the reference raises plain Exception at the same places)."""
+
+    def __init__(self, code, message):
+        Exception.__init__(self, message)
+        self.code = code
+
+
+def lib():
+    """Load libsmart_amd.so once.  No fallback of any kind."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "smartpy_amd: the HIP extension %s has not been built.  Run `python -m smartpy_amd.build` "
+                "(needs hipcc; cross-compiles for gfx950 without a GPU).  There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)       # AttributeError here = the header and the library disagree
+            fn.restype = res
+            fn.argtypes = args
+        if L.smart_abi_version() != 1:
+            raise ImportError("smartpy_amd: ABI version mismatch between smartpy_amd/_lib.py and %s" % LIB_PATH)
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SmartEngineError(rc, lib().smart_last_error().decode('utf8', 'replace') or 'error %d' % rc)

@@ -1,0 +1,381 @@
+// smart_capi.hip -- the C ABI of include/smart_amd.h: validation, launch plumbing, and the two small
+// kernels around the ensemble launch (observation statistics, objective functions of a stored matrix).
+#include "../../include/smart_amd.h"
+#include "smart_device.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace smart {
+void launch_literal(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s);
+void launch_onestep(long n, const double *in, double *out, hipStream_t s);
+void launch_fast(const KArgs &a, dim3 grid, hipStream_t s);
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char *what)
+{
+    return fail(SMART_E_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t _e = (expr);                                                                                        \
+        if (_e != hipSuccess)                                                                                          \
+            return hip_fail(_e, #expr);                                                                                \
+    } while (0)
+
+// ---- block reduction helper (256 threads), deterministic order -----------------------------------------
+__device__ inline double block_sum(double v, double *sh)
+{
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (tid < s)
+            sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// statistics of one observation series (NaN = missing, montecarlo.py:195-196): st[0..4] = n, mean, sum,
+// sum((e-mean)^2), sum(e-mean); dev[r] = e[r] - mean (0 where missing) when dev != null
+__device__ inline void obs_stats(const double *obs, long R, double *st, double *dev, double *sh)
+{
+    double cnt = 0.0, s = 0.0;
+    for (long r = threadIdx.x; r < R; r += blockDim.x) {
+        const double e = obs[r];
+        if (e == e) {
+            cnt += 1.0;
+            s += e;
+        }
+    }
+    cnt = block_sum(cnt, sh);
+    s = block_sum(s, sh);
+    const double mean = s / cnt;
+    double s2 = 0.0, s1 = 0.0;
+    for (long r = threadIdx.x; r < R; r += blockDim.x) {
+        const double e = obs[r];
+        const double d = (e == e) ? e - mean : 0.0;
+        s2 += d * d;
+        s1 += d;
+        if (dev)
+            dev[r] = d;
+    }
+    s2 = block_sum(s2, sh);
+    s1 = block_sum(s1, sh);
+    st[0] = cnt;
+    st[1] = mean;
+    st[2] = s;
+    st[3] = s2;
+    st[4] = s1;
+}
+
+__global__ __launch_bounds__(256) void smart_obs_prepare(const double *obs, long R, double *ws)
+{
+    __shared__ double sh[256];
+    __shared__ double st[5];
+    const long c = blockIdx.x;
+    double *w = ws + c * (kWsHead + R);
+    obs_stats(obs + c * R, R, st, w + kWsHead, sh);
+    if (threadIdx.x < 5)
+        w[threadIdx.x] = st[threadIdx.x];
+}
+
+// Objective functions of a stored discharge matrix sim[R][ld] (sample-minor): one lane per sample, two
+// passes over the column like the spotpy formulas (mean first, then deviations).  HBM-bound: 2 * 8 * R
+// bytes per sample, every wavefront load a contiguous 512-byte row segment.
+__global__ __launch_bounds__(256) void smart_objfn_matrix(long N, long R, const double *sim, long ld, const double *obs,
+                                                          const double *gw_sim, double gw_obs, double *objfn)
+{
+    __shared__ double sh[256];
+    __shared__ double st[5];
+    obs_stats(obs, R, st, nullptr, sh);
+    __syncthreads();
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N)
+        return;
+    const double cnt = st[0], ebar = st[1], se = st[2], see = st[3];
+    double ss = 0.0;
+    for (long r = 0; r < R; ++r) {
+        const double e = obs[r];
+        if (e == e)
+            ss += sim[r * ld + n];
+    }
+    const double sbar = ss / cnt;
+    double B = 0.0, A = 0.0, vs = 0.0, cv = 0.0;
+    for (long r = 0; r < R; ++r) {
+        const double e = obs[r];
+        if (e == e) {
+            const double s = sim[r * ld + n];
+            const double d = e - s;
+            B += d * d;
+            A += s - e;
+            const double u = s - sbar;
+            vs += u * u;
+            cv += (e - ebar) * u;
+        }
+    }
+    double cc = cv / sqrt(vs * see);
+    cc = fmin(fmax(cc, -1.0), 1.0);
+    const double alpha = sqrt(vs / cnt) / sqrt(see / cnt);
+    const double beta = ss / se;
+    double *o = objfn + n * 8;
+    o[0] = 1.0 - B / see;
+    o[1] = 1.0 - sqrt((cc - 1.0) * (cc - 1.0) + (alpha - 1.0) * (alpha - 1.0) + (beta - 1.0) * (beta - 1.0));
+    o[2] = cc;
+    o[3] = alpha;
+    o[4] = beta;
+    o[5] = 100.0 * (A / se);
+    o[6] = sqrt(B / cnt);
+    if (gw_sim && gw_obs == gw_obs) {
+        const double g = gw_sim[n];
+        o[7] = (gw_obs - 0.1 <= g && g <= gw_obs + 0.1) ? 1.0 : 0.0;
+    } else {
+        o[7] = __builtin_nan("");
+    }
+}
+
+static int check(const SmartEnsemble *e)
+{
+    if (!e)
+        return fail(SMART_E_NULL, "SmartEnsemble pointer is NULL");
+    if (e->n_catchments < 1 || e->n_samples < 1 || e->n_steps < 1 || e->n_warm < 0 || e->report_gap < 1)
+        return fail(SMART_E_SIZE, "sizes must satisfy n_catchments, n_samples, n_steps, report_gap >= 1 and n_warm >= 0 "
+                                  "(got %lld, %lld, %lld, %lld, %lld)",
+                    (long long)e->n_catchments, (long long)e->n_samples, (long long)e->n_steps,
+                    (long long)e->report_gap, (long long)e->n_warm);
+    if (e->report_type != SMART_REPORT_SUMMARY && e->report_type != SMART_REPORT_RAW)
+        return fail(SMART_E_REPORT_TYPE, "Reporting type '%d' unknown.", (int)e->report_type);
+    if (e->math_mode != SMART_MATH_LITERAL && e->math_mode != SMART_MATH_FAST)
+        return fail(SMART_E_MODE, "math mode '%d' unknown.", (int)e->math_mode);
+    if (e->n_warm > e->n_steps)
+        return fail(SMART_E_WARMUP, "The warm-up duration (%lld steps) cannot exceed the length of the simulation period "
+                                    "(%lld steps) because the beginning of the simulation period is used as made-up "
+                                    "warm-up data.",
+                    (long long)e->n_warm, (long long)e->n_steps);
+    if (e->report_type == SMART_REPORT_SUMMARY && (e->n_steps % e->report_gap || e->n_warm % e->report_gap))
+        return fail(SMART_E_GAP, "summary report: simulation length %lld and warm-up length %lld must be multiples of the "
+                                 "report gap %lld",
+                    (long long)e->n_steps, (long long)e->n_warm, (long long)e->report_gap);
+    if (!(e->delta_sec > 0.0))
+        return fail(SMART_E_SIZE, "delta_sec must be > 0");
+    if (!e->area_m2 || !e->forcing || !e->params || !e->gw)
+        return fail(SMART_E_NULL, "area_m2, forcing, params and gw are required");
+    if (e->params_catchment_stride != 0 && e->params_catchment_stride < e->n_samples * 10)
+        return fail(SMART_E_SIZE, "params_catchment_stride must be 0 or >= n_samples * 10");
+    if (e->discharge && e->discharge_ld < e->n_samples)
+        return fail(SMART_E_SIZE, "discharge_ld must be >= n_samples");
+    if (e->objfn && (!e->obs || !e->workspace))
+        return fail(SMART_E_NULL, "objfn needs obs and workspace");
+    g_err[0] = 0;
+    return SMART_OK;
+}
+
+static int device_ready()
+{
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess)
+        return hip_fail(err, "hipGetDeviceCount");
+    if (n < 1)
+        return fail(SMART_E_NO_DEVICE, "no HIP device is visible; this engine has no CPU fallback");
+    return SMART_OK;
+}
+
+static int run(const SmartEnsemble *e)
+{
+    int rc = check(e);
+    if (rc)
+        return rc;
+    if ((rc = device_ready()))
+        return rc;
+    hipStream_t s = (hipStream_t)e->stream;
+    KArgs a;
+    a.N = e->n_samples;
+    a.T = e->n_steps;
+    a.W = e->n_warm;
+    a.gap = e->report_gap;
+    a.R = smart_n_reports(e->n_steps, e->report_gap, e->report_type);
+    a.first_len = e->report_type == SMART_REPORT_RAW && e->n_steps % e->report_gap ? e->n_steps % e->report_gap
+                                                                                 : e->report_gap;
+    a.report_type = e->report_type;
+    a.dt = e->delta_sec;
+    a.area = e->area_m2;
+    a.forcing = e->forcing;
+    a.params = e->params;
+    a.pstride_c = e->params_catchment_stride;
+    a.extra = e->extra;
+    a.initial = e->initial;
+    a.obs = e->obs;
+    a.gw_obs = e->gw_obs;
+    a.ws = e->objfn ? e->workspace : nullptr;
+    a.discharge = e->discharge;
+    a.ld = e->discharge_ld;
+    a.gw = e->gw;
+    a.objfn = e->objfn;
+    a.final_vars = e->final_vars;
+    a.np_mean = e->math_mode == SMART_MATH_LITERAL && e->report_type == SMART_REPORT_SUMMARY && a.gap >= 8 && a.gap <= 128;
+
+    if (e->objfn)
+        hipLaunchKernelGGL(smart_obs_prepare, dim3((unsigned)e->n_catchments), dim3(256), 0, s, e->obs, a.R, e->workspace);
+
+    const dim3 grid((unsigned)((a.N + kWave - 1) / kWave), (unsigned)e->n_catchments);
+    if (e->math_mode == SMART_MATH_LITERAL)
+        launch_literal(a, grid, a.np_mean ? (size_t)a.gap * kWave * sizeof(double) : 0, s);
+    else
+        launch_fast(a, grid, s);
+    HIP_TRY(hipGetLastError());
+    return SMART_OK;
+}
+
+} // namespace smart
+
+using namespace smart;
+
+extern "C" {
+
+int64_t smart_n_reports(int64_t n_steps, int64_t report_gap, int32_t report_type)
+{
+    if (report_gap < 1 || n_steps < 0)
+        return 0;
+    return report_type == SMART_REPORT_RAW ? (n_steps + report_gap - 1) / report_gap : n_steps / report_gap;
+}
+
+int smart_check_ensemble(const SmartEnsemble *e) { return check(e); }
+
+int smart_run_ensemble_hip(const SmartEnsemble *e) { return run(e); }
+
+int smart_allsteps_hip(double area_m2, double delta_sec, int64_t length_simu, const double *nd_rain,
+                       const double *nd_peva, const double *nd_parameters, const double *nd_initial,
+                       int32_t report_type, int64_t report_gap, double *discharge, double *groundwater_component,
+                       double *final_vars)
+{
+    if (!nd_rain || !nd_peva || !nd_parameters || !nd_initial || !discharge || !groundwater_component || !final_vars)
+        return fail(SMART_E_NULL, "smart_allsteps_hip: NULL argument");
+    if (length_simu < 1 || report_gap < 1)
+        return fail(SMART_E_SIZE, "smart_allsteps_hip: length_simu and report_gap must be >= 1");
+    int rc = device_ready();
+    if (rc)
+        return rc;
+    const int64_t R = smart_n_reports(length_simu, report_gap, report_type);
+    std::vector<double> host((size_t)length_simu * 2 + 10 + 12 + 1);
+    for (int64_t t = 0; t < length_simu; ++t) {
+        host[2 * t] = nd_rain[t];
+        host[2 * t + 1] = nd_peva[t];
+    }
+    double *hp = host.data() + 2 * length_simu;
+    std::memcpy(hp, nd_parameters, 10 * sizeof(double));
+    std::memcpy(hp + 10, nd_initial + 7, 12 * sizeof(double)); // only the states are read (structure.py:182-187)
+    hp[22] = area_m2;
+    const size_t n_in = host.size(), n_out = (size_t)(R > 0 ? R : 1) + 1 + 19;
+    double *dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, (n_in + n_out) * sizeof(double)));
+    hipError_t err = hipMemcpy(dev, host.data(), n_in * sizeof(double), hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        SmartEnsemble e;
+        std::memset(&e, 0, sizeof(e));
+        e.n_catchments = 1;
+        e.n_samples = 1;
+        e.n_steps = length_simu;
+        e.n_warm = 0;
+        e.report_gap = report_gap;
+        e.report_type = report_type;
+        e.math_mode = SMART_MATH_LITERAL;
+        e.delta_sec = delta_sec;
+        e.forcing = dev;
+        e.params = dev + 2 * length_simu;
+        e.initial = dev + 2 * length_simu + 10;
+        e.area_m2 = dev + 2 * length_simu + 22;
+        double *o = dev + n_in;
+        e.discharge = o;
+        e.discharge_ld = 1;
+        e.gw = o + (R > 0 ? R : 1);
+        e.final_vars = e.gw + 1;
+        rc = run(&e);
+        if (rc == SMART_OK) {
+            std::vector<double> back(n_out);
+            err = hipMemcpy(back.data(), o, n_out * sizeof(double), hipMemcpyDeviceToHost);
+            if (err == hipSuccess) {
+                std::memcpy(discharge, back.data(), (size_t)R * sizeof(double));
+                *groundwater_component = back[(size_t)(R > 0 ? R : 1)];
+                std::memcpy(final_vars, back.data() + (R > 0 ? R : 1) + 1, 19 * sizeof(double));
+            }
+        }
+    }
+    (void)hipFree(dev);
+    if (err != hipSuccess)
+        return hip_fail(err, "smart_allsteps_hip copy");
+    return rc;
+}
+
+int smart_onestep_hip(int64_t n, const double *in, double *out)
+{
+    if (!in || !out)
+        return fail(SMART_E_NULL, "smart_onestep_hip: NULL argument");
+    if (n < 1)
+        return fail(SMART_E_SIZE, "smart_onestep_hip: n must be >= 1");
+    int rc = device_ready();
+    if (rc)
+        return rc;
+    double *dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, (size_t)n * (26 + 19) * sizeof(double)));
+    hipError_t err = hipMemcpy(dev, in, (size_t)n * 26 * sizeof(double), hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        launch_onestep(n, dev, dev + n * 26, nullptr);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess)
+        err = hipMemcpy(out, dev + n * 26, (size_t)n * 19 * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (err != hipSuccess)
+        return hip_fail(err, "smart_onestep_hip");
+    g_err[0] = 0;
+    return SMART_OK;
+}
+
+int smart_objfn_hip(int64_t n_samples, int64_t n_reports, const double *sim, int64_t ld, const double *obs,
+                    const double *gw_sim, double gw_obs, double *objfn, void *stream)
+{
+    if (!sim || !obs || !objfn)
+        return fail(SMART_E_NULL, "smart_objfn_hip: sim, obs and objfn are required");
+    if (n_samples < 1 || n_reports < 1 || ld < n_samples)
+        return fail(SMART_E_SIZE, "smart_objfn_hip: need n_samples, n_reports >= 1 and ld >= n_samples");
+    int rc = device_ready();
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(smart_objfn_matrix, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (long)n_samples, (long)n_reports, sim, (long)ld, obs, gw_sim, gw_obs, objfn);
+    HIP_TRY(hipGetLastError());
+    g_err[0] = 0;
+    return SMART_OK;
+}
+
+int smart_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int smart_abi_version(void) { return SMART_AMD_ABI_VERSION; }
+
+const char *smart_last_error(void) { return g_err; }
+
+} // extern "C"

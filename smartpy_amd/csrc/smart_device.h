@@ -1,0 +1,241 @@
+// smart_device.h -- kernel argument block and the time-loop skeleton shared by the two math modes.
+//
+// Mapping (gfx950): one wavefront lane = one Monte-Carlo sample, one 64-thread workgroup = one wavefront,
+// grid = (ceil(N / 64), n_catchments).  The whole warm-up + simulation time loop of
+// structure.py:87-146 runs inside one launch; the 10 parameters and the 12 states of a sample stay in
+// VGPRs, the forcing of a step is the same for every lane of a wavefront and is fetched with scalar
+// loads (s_load, address uniform in blockIdx.y and the time index), report means / groundwater sums /
+// objective-function moments are accumulated in registers, and the only per-step-scale HBM traffic is
+// one coalesced 512-byte discharge store per wavefront per report step.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace smart {
+
+struct KArgs {
+    long N, T, W, gap, R, first_len; // first_len: steps in report interval 0 (raw mode with T % gap != 0)
+    int report_type;                 // 1 summary, 2 raw
+    int np_mean;                     // literal mode: reproduce numpy's pairwise mean through LDS (8 <= gap <= 128)
+    double dt;
+    const double *area;    // [C]
+    const double *forcing; // [C][T][2]
+    const double *params;  // [C?][N][10]
+    long pstride_c;
+    const double *extra;   // [C][7] | null
+    const double *initial; // [C][N][12] | null
+    const double *obs;     // [C][R] | null
+    const double *gw_obs;  // [C] | null
+    const double *ws;      // [C][8 + R]: n, mean(e), sum(e), sum((e-mean)^2), sum(e-mean), then e - mean per report step
+    double *discharge;     // [C][R][ld] | null
+    long ld;
+    double *gw;         // [C][N]
+    double *objfn;      // [C][N][8] | null
+    double *final_vars; // [C][N][19] | null
+};
+
+constexpr int kWave = 64;
+constexpr int kWsHead = 8;
+
+// objective functions from the one-pass moments (montecarlo.py:193-209; formulas of spotpy's nashsutcliffe,
+// kge(return_all=True), pbias, rmse).  Moments are taken about the observation mean, known before the run:
+//   A = sum(s - e)   B = sum((s - e)^2)   C1 = sum(s - ebar)   C2 = sum((s - ebar)^2)   C3 = sum((e - ebar)(s - ebar))
+__device__ inline void finish_objectives(const double *st, double A, double B, double C1, double C2, double C3,
+                                         double gw_sim, double gw_obs, double *o)
+{
+    const double n = st[0], se = st[2], see = st[3], sd = st[4];
+    const double inv_n = 1.0 / n;
+    const double m1 = C1 * inv_n;
+    const double var_s = C2 * inv_n - m1 * m1;
+    const double var_e = see * inv_n;
+    const double cov = (C3 - sd * m1) * inv_n;
+    double cc = cov / sqrt(var_s * var_e);
+    cc = fmin(fmax(cc, -1.0), 1.0); // np.corrcoef clips
+    const double alpha = sqrt(var_s / var_e);
+    const double beta = 1.0 + A / se;
+    o[0] = 1.0 - B / see;
+    o[1] = 1.0 - sqrt((cc - 1.0) * (cc - 1.0) + (alpha - 1.0) * (alpha - 1.0) + (beta - 1.0) * (beta - 1.0));
+    o[2] = cc;
+    o[3] = alpha;
+    o[4] = beta;
+    o[5] = 100.0 * (A / se);
+    o[6] = sqrt(B * inv_n);
+    if (gw_obs == gw_obs) // objfunctions.py:20-24
+        o[7] = (gw_obs - 0.1 <= gw_sim && gw_sim <= gw_obs + 0.1) ? 1.0 : 0.0;
+    else
+        o[7] = __builtin_nan("");
+}
+
+// numpy's pairwise sum of n (< 8, or 8..128) values held in LDS column `lane` (stride 64 doubles):
+// the order np.mean(np.reshape(Q_out, (-1, gap)), axis=-1) adds them in (structure.py:190).
+__device__ inline double np_pairwise_lds(const double *col, long n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (long i = 0; i < n; ++i)
+            r += col[i * kWave];
+        return r;
+    }
+    double r0 = col[0], r1 = col[kWave], r2 = col[2 * kWave], r3 = col[3 * kWave];
+    double r4 = col[4 * kWave], r5 = col[5 * kWave], r6 = col[6 * kWave], r7 = col[7 * kWave];
+    long i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        const double *b = col + i * kWave;
+        r0 += b[0];
+        r1 += b[kWave];
+        r2 += b[2 * kWave];
+        r3 += b[3 * kWave];
+        r4 += b[4 * kWave];
+        r5 += b[5 * kWave];
+        r6 += b[6 * kWave];
+        r7 += b[7 * kWave];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i)
+        res += col[i * kWave];
+    return res;
+}
+
+// The launch body.  Model supplies: setup(area, dt, p), set_states(st12), step(rain, peva, capture),
+// members q_out, q_in (sum of the five catchment outflows), q_gw (shallow + deep), get_vars(v19).
+//
+// forcing / obs / ws arrive as separate __restrict__ kernel parameters: only then can the compiler prove that
+// the discharge stores do not clobber them and fetch the wave-uniform forcing with scalar loads (s_load)
+// instead of one 64-lane vector load per step.
+template <class Model, bool NP_MEAN>
+__device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__restrict__ forcing,
+                                             const double *__restrict__ obs_all, const double *__restrict__ ws_all,
+                                             double *lds)
+{
+    const int lane = threadIdx.x;
+    const long c = blockIdx.y;
+    long n = (long)blockIdx.x * kWave + lane;
+    const bool live = n < a.N;
+    if (!live)
+        n = a.N - 1;
+
+    double p[10];
+    {
+        const double *pp = a.params + c * a.pstride_c + n * 10;
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+            p[i] = pp[i];
+    }
+    const double area = a.area[c];
+
+    Model m;
+    m.setup(area, a.dt, p);
+
+    double st[12];
+    if (a.initial) {
+        const double *ip = a.initial + (c * a.N + n) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            st[i] = ip[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            st[i] = 0.0;
+        if (a.extra) { // structure.py:100-112 / :125-137, same operation order
+            const double *x = a.extra + c * 7;
+            const double ro = x[0] * x[1];
+            st[0] = ro * x[2] / 1000 * area / 8766 * p[6];
+            st[1] = ro * x[3] / 1000 * area / 8766 * p[6];
+            st[2] = ro * x[4] / 1000 * area / 8766 * p[7];
+            st[3] = ro * x[5] / 1000 * area / 8766 * p[8];
+            st[4] = ro * x[6] / 1000 * area / 8766 * p[8];
+            st[11] = ro / 1000 * area / 8766 * p[9];
+        }
+        const double half = (p[5] / 12) / 1000 * area; // structure.py:115-116 / :139-140
+#pragma unroll
+        for (int i = 5; i < 11; ++i)
+            st[i] = half;
+    }
+    m.set_states(st);
+
+    const double2 *__restrict__ f = forcing + c * a.T;
+
+    // The forcing of step t+1 is requested (scalar load) before step t is computed, so its latency hides
+    // behind ~100 fp64 instructions; the wait sits at the top of the next iteration.
+    double2 nxt = f[0];
+
+    // warm-up over the first W steps of the same forcing; only the states survive (structure.py:118-121)
+    for (long t = 0; t < a.W; ++t) {
+        const double2 v = nxt;
+        nxt = f[t + 1 < a.W ? t + 1 : 0];
+        m.step(v.x, v.y, false);
+    }
+
+    const bool summary = a.report_type == 1;
+    const bool want_obj = a.objfn != nullptr;
+    const double *__restrict__ ws = ws_all ? ws_all + c * (kWsHead + a.R) : nullptr;
+    const double ebar = want_obj ? ws[1] : 0.0;
+    const double inv_gap = 1.0 / (double)a.gap;
+
+    double num = 0.0, den = 0.0;         // groundwater sums over every step (summary, structure.py:191)
+    double num_raw = 0.0, den_raw = 0.0; // ... over the reported rows only (raw, structure.py:194-195)
+    double A = 0.0, B = 0.0, C1 = 0.0, C2 = 0.0, C3 = 0.0; // objective-function moments
+    long t = 0;
+    for (long r = 0; r < a.R; ++r) {
+        const long len = r == 0 ? a.first_len : a.gap;
+        double acc = 0.0;
+        for (long k = 0; k < len; ++k, ++t) {
+            const double2 v = nxt;
+            nxt = f[t + 1 < a.T ? t + 1 : t];
+            m.step(v.x, v.y, false);
+            if (NP_MEAN)
+                lds[k * kWave + lane] = m.q_out;
+            else
+                acc += m.q_out;
+            num += m.q_gw;
+            den += m.q_in;
+        }
+        double val;
+        if (summary) {
+            if (NP_MEAN)
+                val = np_pairwise_lds(lds + lane, len) / (double)a.gap;
+            else
+                val = Model::kExactDivide ? acc / (double)a.gap : acc * inv_gap;
+        } else {
+            val = m.q_out;
+            num_raw += m.q_gw;
+            den_raw += m.q_in;
+        }
+        if (a.discharge && live)
+            a.discharge[(c * a.R + r) * a.ld + n] = val;
+        if (want_obj) {
+            const double e = obs_all[c * a.R + r];
+            if (e == e) { // not NaN: montecarlo.py:195-196
+                const double d = val - e;
+                const double u = val - ebar;
+                A += d;
+                B += d * d;
+                C1 += u;
+                C2 += u * u;
+                C3 += ws[kWsHead + r] * u;
+            }
+        }
+    }
+
+    const double gw = summary ? num / den : num_raw / den_raw;
+    if (live)
+        a.gw[c * a.N + n] = gw;
+    if (want_obj && live) {
+        double o[8];
+        finish_objectives(ws, A, B, C1, C2, C3, gw, a.gw_obs ? a.gw_obs[c] : __builtin_nan(""), o);
+        double *op = a.objfn + (c * a.N + n) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            op[i] = o[i];
+    }
+    if (a.final_vars && live) {
+        double v[19];
+        m.get_vars(v);
+        double *fp = a.final_vars + (c * a.N + n) * 19;
+#pragma unroll
+        for (int i = 0; i < 19; ++i)
+            fp[i] = v[i];
+    }
+}
+
+} // namespace smart

@@ -1,0 +1,233 @@
+"""Host side of the ensemble engine: torch tensors in, one HIP launch through the C ABI, torch tensors out.
+
+PyTorch is plumbing here (device memory, streams, torch.distributed); all arithmetic of the hot path is in
+smartpy_amd/csrc/*.hip behind include/smart_amd.h.  Nothing in this module computes model steps on the CPU
+and nothing imports the test oracle.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SmartEngineError, REPORT_SUMMARY, REPORT_RAW, MATH_LITERAL, MATH_FAST  # noqa: F401
+
+OBJ_FN_NAMES = ['NSE', 'KGE', 'KGEc', 'KGEa', 'KGEb', 'PBias', 'RMSE', 'GW']   # montecarlo.py:71-74
+VARIABLES = ['Q_aeva', 'Q_ove', 'Q_dra', 'Q_int', 'Q_sgw', 'Q_dgw', 'Q_out',
+             'V_ove', 'V_dra', 'V_int', 'V_sgw', 'V_dgw',
+             'V_ly1', 'V_ly2', 'V_ly3', 'V_ly4', 'V_ly5', 'V_ly6', 'V_river']  # structure.py:78-82
+
+_REPORT = {'summary': REPORT_SUMMARY, 'raw': REPORT_RAW}
+_MATH = {'literal': MATH_LITERAL, 'fast': MATH_FAST}
+
+
+def report_code(report):
+    """structure.py:65-70."""
+    try:
+        return _REPORT[report]
+    except KeyError:
+        raise Exception("Reporting type '{}' unknown.".format(report))
+
+
+def default_device():
+    if not torch.cuda.is_available():
+        raise SmartEngineError(-6, "smartpy_amd needs a HIP device (torch.cuda.is_available() is False); "
+                                   "there is no CPU fallback")
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def as_device(x, device, shape=None):
+    """numpy / list / tensor -> contiguous fp64 tensor on device."""
+    if x is None:
+        return None
+    if not isinstance(x, torch.Tensor):
+        x = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64)))
+    x = x.to(device=device, dtype=torch.float64).contiguous()
+    if shape is not None:
+        x = x.reshape(shape)
+    return x
+
+
+def extra_vector(extra):
+    """{'aar', 'r-o_ratio', 'r-o_split'} -> the 7 doubles of include/smart_amd.h (structure.py:100-112)."""
+    if not extra:
+        return None
+    return [float(extra['aar']), float(extra['r-o_ratio'])] + [float(v) for v in extra['r-o_split']]
+
+
+class EnsembleResult(object):
+    """Outputs of one launch.  discharge is a [C, N, R] *view* of the sample-minor buffer the kernel writes."""
+
+    def __init__(self, discharge_rn, gw, objfn, final_vars, n_samples, squeeze):
+        self._dis = discharge_rn        # [C, R, ld] or None
+        self._n = n_samples
+        self._squeeze = squeeze
+        self.gw = gw[0] if squeeze else gw
+        self.objfn = None if objfn is None else (objfn[0] if squeeze else objfn)
+        self.final_vars = None if final_vars is None else (final_vars[0] if squeeze else final_vars)
+
+    @property
+    def discharge_report_major(self):
+        """[C, R, N] (or [R, N]) exactly as stored: row r holds every sample's discharge of report step r."""
+        if self._dis is None:
+            return None
+        d = self._dis[:, :, :self._n]
+        return d[0] if self._squeeze else d
+
+    @property
+    def discharge(self):
+        """[C, N, R] (or [N, R]): discharge[n] is what SMART.simulate(row n)[0] returns (smart.py:208)."""
+        d = self.discharge_report_major
+        return None if d is None else d.transpose(-1, -2)
+
+
+def n_reports(n_steps, gap, report_type):
+    return int(_lib.lib().smart_n_reports(n_steps, gap, report_type))
+
+
+def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report='summary', extra=None,
+                 initial=None, obs=None, gw_obs=None, math_mode='fast', want_discharge=True, want_objfn=None,
+                 want_final=False, device=None, discharge_out=None):
+    """One launch of the whole ensemble: the batched form of the spotpy loop over MonteCarlo.simulation /
+    objectivefunction (montecarlo.py:153-154,179-209).
+
+    params   [N, 10] or [C, N, 10]    forcing [T, 2] or [C, T, 2] (rain, peva per step)
+    area_m2  scalar or [C]            extra   dict / 7-vector / [C, 7] / None
+    initial  [N, 12] / [C, N, 12]     obs     [R] or [C, R], NaN = missing    gw_obs scalar / [C] / None
+    """
+    L = _lib.lib()
+    device = torch.device(device) if device is not None else (
+        params.device if isinstance(params, torch.Tensor) and params.is_cuda else default_device())
+    params = as_device(params, device)
+    forcing = as_device(forcing, device)
+    squeeze = forcing.dim() == 2
+    if squeeze:
+        forcing = forcing.unsqueeze(0)
+    C, T = forcing.shape[0], forcing.shape[1]
+    if forcing.shape[2] != 2:
+        raise Exception("forcing must be [T, 2] or [C, T, 2] (rain, peva)")
+    if params.dim() == 2:
+        pstride = 0
+        N = params.shape[0]
+    else:
+        if params.shape[0] != C:
+            raise Exception("params [C, N, 10] must have one block per catchment")
+        N = params.shape[1]
+        pstride = N * 10
+    if params.shape[-1] != 10:
+        raise Exception("params must have 10 columns (T, C, H, D, S, Z, SK, FK, GK, RK)")
+    rtype = report_code(report)
+    try:
+        mmode = _MATH[math_mode]
+    except KeyError:
+        raise Exception("math mode '{}' unknown.".format(math_mode))
+    R = n_reports(T, report_gap, rtype)
+
+    area = as_device(np.full(C, area_m2, dtype=np.float64) if np.ndim(area_m2) == 0 else area_m2, device, (C,))
+    if isinstance(extra, dict):
+        extra = extra_vector(extra)
+    if extra is not None:
+        extra = as_device(extra, device)
+        extra = extra.reshape(1, 7).expand(C, 7).contiguous() if extra.numel() == 7 else extra.reshape(C, 7)
+    if initial is not None:
+        initial = as_device(initial, device)
+        initial = initial.reshape(1, N, 12).expand(C, N, 12).contiguous() if initial.numel() == N * 12 \
+            else initial.reshape(C, N, 12)
+    if want_objfn is None:
+        want_objfn = obs is not None
+    if obs is not None:
+        obs = as_device(obs, device)
+        obs = obs.reshape(1, R).expand(C, R).contiguous() if obs.numel() == R else obs.reshape(C, R)
+    elif want_objfn:
+        raise Exception("objective functions need observations")
+    if gw_obs is not None:
+        gw_obs = as_device(np.full(C, gw_obs, dtype=np.float64) if np.ndim(gw_obs) == 0 else gw_obs, device, (C,))
+
+    ld = N
+    dis = None
+    if discharge_out is not None:
+        dis = discharge_out
+        assert dis.is_contiguous() and dis.dtype == torch.float64 and dis.shape[:2] == (C, R) and dis.shape[2] >= N
+        ld = dis.shape[2]
+    elif want_discharge:
+        dis = torch.empty((C, R, ld), dtype=torch.float64, device=device)
+    gw = torch.empty((C, N), dtype=torch.float64, device=device)
+    objfn = torch.empty((C, N, 8), dtype=torch.float64, device=device) if want_objfn else None
+    fin = torch.empty((C, N, 19), dtype=torch.float64, device=device) if want_final else None
+    ws = torch.empty((C, 8 + R), dtype=torch.float64, device=device) if want_objfn else None
+
+    def ptr(t):
+        return None if t is None else t.data_ptr()
+
+    e = _lib.SmartEnsemble()
+    e.n_catchments, e.n_samples, e.n_steps, e.n_warm, e.report_gap = C, N, T, int(n_warm), int(report_gap)
+    e.report_type, e.math_mode, e.delta_sec = rtype, mmode, float(delta_sec)
+    e.area_m2, e.forcing, e.params, e.params_catchment_stride = ptr(area), ptr(forcing), ptr(params), pstride
+    e.extra, e.initial, e.obs, e.gw_obs = ptr(extra), ptr(initial), ptr(obs), ptr(gw_obs)
+    e.discharge, e.discharge_ld, e.gw, e.objfn = ptr(dis), ld, ptr(gw), ptr(objfn)
+    e.final_vars, e.workspace = ptr(fin), ptr(ws)
+    with torch.cuda.device(device):
+        e.stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(L.smart_run_ensemble_hip(ctypes.byref(e)))
+    # keep the inputs alive until the launch has been enqueued on the torch stream (it has: the call returned)
+    return EnsembleResult(dis, gw, objfn, fin, N, squeeze)
+
+
+def objective_functions(discharge_report_major, obs, gw_sim=None, gw_obs=None):
+    """montecarlo.py:193-209 for every column of a stored [R, N] discharge matrix (two-pass, HBM-bound)."""
+    L = _lib.lib()
+    sim = discharge_report_major
+    if not (isinstance(sim, torch.Tensor) and sim.is_cuda):
+        sim = as_device(sim, default_device())
+    if sim.stride(-1) != 1:
+        sim = sim.contiguous()
+    R, N = sim.shape
+    ld = sim.stride(0)
+    obs = as_device(obs, sim.device, (R,))
+    gw_sim = as_device(gw_sim, sim.device, (N,)) if gw_sim is not None else None
+    out = torch.empty((N, 8), dtype=torch.float64, device=sim.device)
+    with torch.cuda.device(sim.device):
+        _lib.check(L.smart_objfn_hip(N, R, sim.data_ptr(), ld, obs.data_ptr(),
+                                     None if gw_sim is None else gw_sim.data_ptr(),
+                                     float('nan') if gw_obs is None else float(gw_obs), out.data_ptr(),
+                                     torch.cuda.current_stream(sim.device).cuda_stream))
+    return out
+
+
+def allsteps(area_m2, delta_sec, length_simu, nd_rain, nd_peva, nd_parameters, nd_initial, report_type, report_gap):
+    """smartcpp.allsteps: same arguments and results as run_all_steps (structure.py:149-152,197); host arrays."""
+    L = _lib.lib()
+    rain = np.ascontiguousarray(nd_rain, dtype=np.float64)
+    peva = np.ascontiguousarray(nd_peva, dtype=np.float64)
+    par = np.ascontiguousarray(nd_parameters, dtype=np.float64)
+    ini = np.ascontiguousarray(nd_initial, dtype=np.float64)
+    length_simu, report_gap = int(length_simu), int(report_gap)
+    if len(rain) < length_simu or len(peva) < length_simu or len(par) != 10 or len(ini) != 19:
+        raise Exception("allsteps: inconsistent argument sizes")
+    if report_type == REPORT_SUMMARY and report_gap > 0 and length_simu % report_gap:
+        raise ValueError("cannot reshape array of size {} into shape ({})".format(length_simu, report_gap))
+    R = n_reports(length_simu, report_gap, report_type)
+    dis = np.empty(max(R, 0), dtype=np.float64)
+    gw = ctypes.c_double(math.nan)
+    fin = np.empty(19, dtype=np.float64)
+    _lib.check(L.smart_allsteps_hip(float(area_m2), float(delta_sec), length_simu, rain.ctypes.data, peva.ctypes.data,
+                                    par.ctypes.data, ini.ctypes.data, int(report_type), report_gap, dis.ctypes.data,
+                                    ctypes.addressof(gw), fin.ctypes.data))
+    return dis, gw.value, fin
+
+
+def onestep(*args):
+    """smartcpp.onestep: the 26 positional floats of run_one_step (structure.py:200-206) -> 19 floats."""
+    if len(args) != 26:
+        raise TypeError("onestep() takes exactly 26 positional arguments ({} given)".format(len(args)))
+    return onestep_batch(np.asarray(args, dtype=np.float64).reshape(1, 26))[0]
+
+
+def onestep_batch(inputs):
+    """[n, 26] -> [n, 19]: n independent single steps in one launch."""
+    L = _lib.lib()
+    x = np.ascontiguousarray(inputs, dtype=np.float64)
+    out = np.empty((x.shape[0], 19), dtype=np.float64)
+    _lib.check(L.smart_onestep_hip(x.shape[0], x.ctypes.data, out.ctypes.data))
+    return out

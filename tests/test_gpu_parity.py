@@ -1,0 +1,313 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the golden vectors.  Needs an MI355X.
+
+Gates
+  literal mode : bit-identical to the oracle configured with the product chain for s'**i and the kernel's
+                 summation orders (oracle pow_mode=POW_MUL, sum_mode=SUM_GPU) -- integer-exact comparison of
+                 fp64 bit patterns; and within 1e-11 of the reference-exact oracle / the reference's own values.
+  fast mode    : relative difference <= 1e-9 on discharge (contract of BASELINE.json: 1e-6), 1e-10 on gw.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import smart_oracle as so
+from oracle import objfn_oracle, lhs_oracle
+
+pytestmark = pytest.mark.gpu
+
+REL_FAST = 1e-9
+REL_CONTRACT = 1e-6
+
+
+def rel(a, b, floor=0.0):
+    """max |a - b| / max(|a|, |b|); magnitudes below `floor` count as equal (subnormal reservoir volumes that
+    have been draining for ten years carry no relative precision)."""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    m = np.maximum(np.abs(a), np.abs(b))
+    with np.errstate(invalid='ignore', divide='ignore'):
+        r = np.where(m > floor, np.abs(a - b) / m, 0.0)
+    return float(np.max(r)) if r.size else 0.0
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return a.shape == b.shape and np.array_equal(a.view(np.int64), b.view(np.int64))
+
+
+@pytest.fixture(scope='module')
+def eng():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from smartpy_amd import engine
+    return engine
+
+
+def forcing_of(rain, peva):
+    return np.stack([rain, peva], axis=1)
+
+
+# ------------------------------------------------------------------------------------------------------
+# single steps (smartcpp.onestep stand-in)
+# ------------------------------------------------------------------------------------------------------
+def test_onestep_literal_bit_exact_on_kat6(eng):
+    g = load_golden('kat6_steps.npz')
+    n = len(g['area'])
+    x = np.concatenate([g['area'][:, None], g['dt'][:, None], g['rain'][:, None], g['peva'][:, None],
+                        g['params'], g['states']], axis=1)
+    got = eng.onestep_batch(x)
+    want = np.array([so.one_step(g['area'][k], g['dt'][k], g['rain'][k], g['peva'][k], g['params'][k],
+                                 g['states'][k], pow_mode=so.POW_MUL) for k in range(n)])
+    assert bits_equal(got, want)
+    assert rel(got, g['out']) < 1e-12                     # vs the reference itself (libm pow)
+    one = eng.onestep(*x[7])                              # the 26-positional-float call of structure.py:182-187
+    assert bits_equal(one, want[7])
+
+
+# ------------------------------------------------------------------------------------------------------
+# ensembles against the oracle
+# ------------------------------------------------------------------------------------------------------
+def _run_both(eng, example, params, res, n_days, n_warm_days, report='summary', extra='example', math_mode='fast',
+              want_final=False):
+    if res == 'hourly':
+        rain, peva, dt, gap, per = example['rain_hourly'], example['peva_hourly'], 3600.0, 24, 24
+    else:
+        rain, peva, dt, gap, per = example['rain_daily'], example['peva_daily'], 86400.0, 1, 1
+    T, W = n_days * per, n_warm_days * per
+    ex = example['extra'] if extra == 'example' else None
+    out = eng.run_ensemble(params, forcing_of(rain[:T], peva[:T]), example['area'], dt, W, gap, report=report,
+                           extra=ex, math_mode=math_mode, want_final=want_final)
+    return out, (example['area'], dt, T, W, rain, peva, params, ex, so.REPORT_SUMMARY if report == 'summary'
+                 else so.REPORT_RAW, gap)
+
+
+@pytest.mark.parametrize('res,n_days,warm', [('hourly', 731, 365), ('daily', 3653, 365), ('hourly', 400, 0)])
+def test_literal_ensemble_bit_exact(eng, example, res, n_days, warm):
+    """32 LHS rows (incl. RK, SK < 24 h on daily steps: river rule and clamps)."""
+    params = load_golden('kat4_batch.npz')['params']
+    out, args = _run_both(eng, example, params, res, n_days, warm, math_mode='literal', want_final=True)
+    dis, gw, fin = so.run_batch(*args, pow_mode=so.POW_MUL, sum_mode=so.SUM_GPU, want_final=True)
+    assert bits_equal(out.discharge.cpu().numpy(), dis)
+    assert bits_equal(out.gw.cpu().numpy(), gw)
+    assert bits_equal(out.final_vars.cpu().numpy(), fin)
+
+
+@pytest.mark.parametrize('report', ['summary', 'raw'])
+@pytest.mark.parametrize('res,n_days,warm,extra', [('hourly', 731, 365, 'example'), ('daily', 3653, 365, 'example'),
+                                                   ('daily', 731, 0, None), ('hourly', 731, 0, 'example')])
+def test_fast_ensemble_vs_reference_exact_oracle(eng, example, report, res, n_days, warm, extra):
+    params = load_golden('kat4_batch.npz')['params']
+    out, args = _run_both(eng, example, params, res, n_days, warm, report=report, extra=extra, want_final=True)
+    dis, gw, fin = so.run_batch(*args, want_final=True)                   # reference-exact configuration
+    d = rel(out.discharge.cpu().numpy(), dis)
+    assert d <= REL_FAST, d
+    assert rel(out.gw.cpu().numpy(), gw) <= 1e-10
+    assert rel(out.final_vars.cpu().numpy()[:, 7:], fin[:, 7:], floor=1e-290) <= 1e-8  # states (m3)
+    assert np.all(np.isnan(out.final_vars.cpu().numpy()[:, :7]))
+
+
+def test_golden_kat4_and_reference_values(eng, example):
+    """Straight against numbers the reference produced: KAT-4 batch, KAT-1, G1 ('%.6e') and G2 ('%e')."""
+    g = load_golden('kat4_batch.npz')
+    for mode in ('literal', 'fast'):
+        out, _ = _run_both(eng, example, g['params'], 'hourly', 731, 365, math_mode=mode)
+        assert rel(out.discharge.cpu().numpy(), g['discharge_hourly_2yr']) <= REL_FAST
+        assert rel(out.gw.cpu().numpy(), g['gw_hourly_2yr']) <= 1e-10
+        out, _ = _run_both(eng, example, g['params'], 'daily', 3653, 365, math_mode=mode)
+        assert rel(out.discharge.cpu().numpy(), g['discharge_daily_10yr']) <= REL_FAST
+        assert rel(out.gw.cpu().numpy(), g['gw_daily_10yr']) <= 1e-10
+    k1 = load_golden('kat1_hourly.npz')
+    g1 = load_golden('g1_reference_test.npz')
+    g2 = load_golden('g2_g3_example_flows.npz')
+    p1 = example['params'][None, :]
+    for mode in ('literal', 'fast'):
+        for report in ('summary', 'raw'):
+            out, _ = _run_both(eng, example, p1, 'hourly', 3653, 365, report=report, math_mode=mode)
+            dis = out.discharge.cpu().numpy()[0]
+            assert rel(dis, k1['discharge_' + report]) <= REL_FAST
+            assert rel(out.gw.cpu().numpy()[0], float(k1['gw_' + report])) <= 1e-10
+            if report == 'summary':
+                for i, v in zip(g1['report_index'], g1['expected']):        # the reference's own unit test
+                    assert '%.6e' % dis[i] == '%.6e' % v
+                assert ['%e' % v for v in dis] == ['%e' % v for v in g2['mod_flow']]
+
+
+def test_raw_report_ragged_length(eng, example):
+    g = load_golden('kat9_raw_ragged.npz')
+    L, gap = int(g['n_steps']), int(g['gap'])
+    f = forcing_of(example['rain_hourly'][:L], example['peva_hourly'][:L])
+    for mode, tol in (('literal', 1e-12), ('fast', REL_FAST)):
+        out = eng.run_ensemble(example['params'][None, :], f, example['area'], 3600.0, 0, gap, report='raw',
+                               initial=g['initial'][None, 7:], math_mode=mode, want_final=True)
+        assert out.discharge.shape == (1, 42)
+        assert rel(out.discharge.cpu().numpy()[0], g['discharge']) <= tol
+        assert rel(out.gw.cpu().numpy()[0], float(g['gw'])) <= 1e-10
+        assert rel(out.final_vars.cpu().numpy()[0, 7:], g['final'][7:], floor=1e-290) <= 1e-9
+    with pytest.raises(Exception):          # summary with length % gap != 0: np.reshape raises (structure.py:190)
+        eng.run_ensemble(example['params'][None, :], f, example['area'], 3600.0, 0, gap, report='summary')
+
+
+def test_allsteps_is_interchangeable_with_run_all_steps(eng, example):
+    """smartcpp.allsteps contract (structure.py:56-62,118-121,143-146): same arguments, same 3-tuple."""
+    k1 = load_golden('kat1_hourly.npz')
+    L = 24 * 60
+    dis, gw, fin = eng.allsteps(example['area'], 3600.0, L, example['rain_hourly'], example['peva_hourly'],
+                                example['params'], k1['initial_run'], 1, 24)
+    d0, g0, f0 = so.all_steps(example['area'], 3600.0, L, example['rain_hourly'], example['peva_hourly'],
+                              example['params'], k1['initial_run'], 1, 24, pow_mode=so.POW_MUL, sum_mode=so.SUM_GPU)
+    assert bits_equal(dis, d0) and bits_equal(fin, f0) and gw == g0
+    assert rel(dis, k1['discharge_summary'][:60]) < 1e-12
+    # the warm-up call passes the full series with a shorter length and keeps [2] (structure.py:118-121)
+    _, _, fin_wu = eng.allsteps(example['area'], 3600.0, 8760, example['rain_hourly'], example['peva_hourly'],
+                                example['params'], k1['initial_warmup'], 1, 24)
+    assert rel(fin_wu[7:], k1['initial_run'][7:]) < 1e-12
+
+
+def test_chained_runs_equal_one_run(eng, example):
+    """final states of a run are a valid `initial` for the next (checkpoint / resume property)."""
+    params = load_golden('kat4_batch.npz')['params']
+    T1, T2 = 24 * 200, 24 * 165
+    f = forcing_of(example['rain_hourly'][:T1 + T2], example['peva_hourly'][:T1 + T2])
+    for mode in ('literal', 'fast'):
+        whole = eng.run_ensemble(params, f, example['area'], 3600.0, 0, 24, extra=example['extra'], math_mode=mode,
+                                 want_final=True)
+        a = eng.run_ensemble(params, f[:T1], example['area'], 3600.0, 0, 24, extra=example['extra'], math_mode=mode,
+                             want_final=True)
+        b = eng.run_ensemble(params, f[T1:], example['area'], 3600.0, 0, 24, initial=a.final_vars[:, 7:],
+                             math_mode=mode, want_final=True)
+        joined = np.concatenate([a.discharge.cpu().numpy(), b.discharge.cpu().numpy()], axis=1)
+        if mode == 'literal':
+            assert bits_equal(joined, whole.discharge.cpu().numpy())
+        else:   # the fast path converts states to m3 and back at the hand-over
+            assert rel(joined, whole.discharge.cpu().numpy()) < 1e-12
+
+
+def test_catchment_axis_equals_separate_launches(eng, example):
+    """2-D batch (BASELINE config 5 shape): grid.y = catchment, own forcing / area / extra / obs each."""
+    rng = np.random.default_rng(5)
+    params = lhs_oracle.lhs_params(100, seed=11)
+    T = 24 * 120
+    fs, areas = [], [60e6, 175.46e6, 900e6]
+    for c in range(3):
+        scale = 0.5 + c
+        fs.append(forcing_of(example['rain_hourly'][c * 1000:c * 1000 + T] * scale,
+                             example['peva_hourly'][c * 1000:c * 1000 + T]))
+    obs = rng.random((3, T // 24)) * 5
+    obs[rng.random((3, T // 24)) < 0.12] = np.nan
+    both = eng.run_ensemble(params, np.stack(fs), areas, 3600.0, 24 * 30, 24, extra=example['extra'], obs=obs,
+                            gw_obs=[0.1, 0.2, np.nan], want_final=True)
+    assert both.discharge.shape == (3, 100, T // 24) and both.objfn.shape == (3, 100, 8)
+    for c in range(3):
+        one = eng.run_ensemble(params, fs[c], areas[c], 3600.0, 24 * 30, 24, extra=example['extra'], obs=obs[c],
+                               gw_obs=[0.1, 0.2, np.nan][c], want_final=True)
+        assert bits_equal(both.discharge[c].cpu().numpy(), one.discharge.cpu().numpy())
+        assert bits_equal(both.gw[c].cpu().numpy(), one.gw.cpu().numpy())
+        assert np.array_equal(both.objfn[c].cpu().numpy(), one.objfn.cpu().numpy(), equal_nan=True)
+    # per-catchment parameter blocks
+    p3 = np.stack([lhs_oracle.lhs_params(100, seed=s) for s in (1, 2, 3)])
+    blk = eng.run_ensemble(p3, np.stack(fs), areas, 3600.0, 0, 24, extra=example['extra'])
+    for c in range(3):
+        one = eng.run_ensemble(p3[c], fs[c], areas[c], 3600.0, 0, 24, extra=example['extra'])
+        assert bits_equal(blk.discharge[c].cpu().numpy(), one.discharge.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------------------
+# objective functions
+# ------------------------------------------------------------------------------------------------------
+def test_fused_objective_functions_and_g4(eng, example):
+    """One-pass moments in the time-loop kernel vs the two-pass numpy restatement; pinned by G4."""
+    g = load_golden('g4_example_lhs.npz')
+    f = forcing_of(example['rain_hourly'], example['peva_hourly'])
+    for mode in ('fast', 'literal'):
+        out = eng.run_ensemble(g['params'], f, example['area'], 3600.0, 8760, 24, extra=example['extra'],
+                               obs=example['flow_obs'], gw_obs=float(g['gw_constraint']), math_mode=mode)
+        want = objfn_oracle.objective_matrix(g['discharge'], example['flow_obs'], g['gw'], float(g['gw_constraint']))
+        got = out.objfn.cpu().numpy()
+        assert rel(got[:, :7], want[:, :7]) < 1e-9
+        assert np.array_equal(got[:, 7], want[:, 7])
+        assert rel(got[:, :7], g['objfns'][:, :7]) < 5e-6        # the reference's committed float32 database
+        assert np.array_equal(got[:, 7], g['objfns'][:, 7])
+        # the stored-matrix kernel (two-pass) agrees as well
+        got2 = eng.objective_functions(out.discharge_report_major, example['flow_obs'], out.gw,
+                                       float(g['gw_constraint'])).cpu().numpy()
+        assert rel(got2[:, :7], want[:, :7]) < 1e-11
+        assert np.array_equal(got2[:, 7], want[:, 7])
+    no_gw = eng.run_ensemble(g['params'][:3], f, example['area'], 3600.0, 8760, 24, extra=example['extra'],
+                             obs=example['flow_obs'], want_discharge=False)
+    assert no_gw.discharge is None and np.all(np.isnan(no_gw.objfn.cpu().numpy()[:, 7]))
+    assert rel(no_gw.objfn.cpu().numpy()[:, :7], want[:3, :7]) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------------
+# edge cases and error behaviour (structure.py:69-70, 90-95, 190)
+# ------------------------------------------------------------------------------------------------------
+def test_ragged_sample_counts_and_padding(eng, example):
+    """N not a multiple of the wavefront, N = 1, and a padded leading dimension."""
+    import torch
+    full = lhs_oracle.lhs_params(130, seed=3)
+    T = 24 * 40
+    f = forcing_of(example['rain_hourly'][:T], example['peva_hourly'][:T])
+    ref = eng.run_ensemble(full, f, example['area'], 3600.0, 0, 24, extra=example['extra']).discharge.cpu().numpy()
+    for n in (1, 63, 64, 65, 129):
+        out = eng.run_ensemble(full[:n], f, example['area'], 3600.0, 0, 24, extra=example['extra'])
+        assert bits_equal(out.discharge.cpu().numpy(), ref[:n])
+    buf = torch.full((1, T // 24, 192), -1.0, dtype=torch.float64, device='cuda')
+    out = eng.run_ensemble(full, f, example['area'], 3600.0, 0, 24, extra=example['extra'], discharge_out=buf)
+    assert bits_equal(out.discharge.cpu().numpy(), ref) and bool((buf[0, :, 130:] == -1.0).all())
+
+
+def test_guard_variant_for_out_of_range_parameters(eng, example):
+    """S >= 1 (s' ** i no longer < 1) and C < 0 take the guarded instantiation; still matches the oracle."""
+    p = lhs_oracle.lhs_params(64, seed=9)
+    p[5, 4] = 1.7        # S: leaks guarded by "leak < level" (structure.py:383,390,397)
+    p[9, 4] = 0.9
+    T = 24 * 90
+    f = forcing_of(example['rain_hourly'][:T], example['peva_hourly'][:T])
+    out = eng.run_ensemble(p, f, example['area'], 3600.0, 0, 24, extra=example['extra'])
+    dis, gw, _ = so.run_batch(example['area'], 3600.0, T, 0, example['rain_hourly'], example['peva_hourly'], p,
+                              example['extra'], so.REPORT_SUMMARY, 24)
+    assert rel(out.discharge.cpu().numpy(), dis) <= REL_FAST and rel(out.gw.cpu().numpy(), gw) <= 1e-10
+
+
+def test_error_behaviour(eng, example):
+    f = forcing_of(example['rain_hourly'][:240], example['peva_hourly'][:240])
+    p = example['params'][None, :]
+    with pytest.raises(Exception, match="Reporting type 'daily' unknown"):
+        eng.run_ensemble(p, f, example['area'], 3600.0, 0, 24, report='daily')
+    with pytest.raises(Exception, match='warm-up duration'):
+        eng.run_ensemble(p, f, example['area'], 3600.0, 480, 24)
+    with pytest.raises(Exception, match='multiples of the report gap'):
+        eng.run_ensemble(p, f, example['area'], 3600.0, 12, 24)
+    with pytest.raises(Exception):
+        eng.run_ensemble(p, f, example['area'], 3600.0, 0, 24, want_objfn=True)
+
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE sizes: size-independent properties
+# ------------------------------------------------------------------------------------------------------
+def test_headline_size_properties(eng, example):
+    """1e5 LHS samples x hourly 10 years (BASELINE config 3), objective functions fused, no discharge stored.
+    Properties: (i) a sample's result does not depend on its position in the batch or on its wavefront
+    neighbours (bit-identical under a permutation of the rows); (ii) 8 rows drawn at random agree with the
+    oracle; (iii) physical ranges."""
+    import torch
+    N = 100000
+    params = lhs_oracle.lhs_params(N, seed=2718)
+    f = forcing_of(example['rain_hourly'], example['peva_hourly'])
+    dev_p = torch.from_numpy(params).cuda()
+    out = eng.run_ensemble(dev_p, f, example['area'], 3600.0, 8760, 24, extra=example['extra'],
+                           obs=example['flow_obs'], gw_obs=0.12667, want_discharge=False)
+    perm = torch.randperm(N, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
+    out_p = eng.run_ensemble(dev_p[perm], f, example['area'], 3600.0, 8760, 24, extra=example['extra'],
+                             obs=example['flow_obs'], gw_obs=0.12667, want_discharge=False)
+    assert torch.equal(out.objfn[perm], out_p.objfn) and torch.equal(out.gw[perm], out_p.gw)
+    gw = out.gw.cpu().numpy()
+    obj = out.objfn.cpu().numpy()
+    assert np.all(np.isfinite(obj)) and np.all((gw >= 0) & (gw <= 1)) and np.all(obj[:, 0] <= 1) and \
+        np.all(obj[:, 6] >= 0) and set(np.unique(obj[:, 7])) <= {0.0, 1.0}
+    rows = np.random.default_rng(7).choice(N, 8, replace=False)
+    dis, gwo, _ = so.run_batch(example['area'], 3600.0, 87672, 8760, example['rain_hourly'], example['peva_hourly'],
+                               params[rows], example['extra'], so.REPORT_SUMMARY, 24)
+    want = objfn_oracle.objective_matrix(dis, example['flow_obs'], gwo, 0.12667)
+    assert rel(obj[rows, :7], want[:, :7]) < 1e-9 and np.array_equal(obj[rows, 7], want[:, 7])
+    assert rel(gw[rows], gwo) < 1e-10
