@@ -96,6 +96,37 @@ __device__ inline double np_pairwise_lds(const double *col, long n)
     return res;
 }
 
+// Walk n time steps of one catchment's forcing.  The forcing of a step is the same for all 64 lanes, so it is
+// fetched with scalar loads into SGPRs: kChunk steps (one 64-byte line) per s_load_dwordx16, and the next chunk is
+// requested before the current one is consumed, so the load latency hides behind kChunk model steps.
+constexpr int kChunk = 4;
+
+template <class Body>
+__device__ __forceinline__ void time_loop(const double2 *__restrict__ f, long n, Body &&body)
+{
+    const long n_chunks = n / kChunk;
+    double2 cur[kChunk], nxt[kChunk];
+    if (n_chunks > 0) {
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            cur[j] = f[j];
+    }
+    for (long ch = 0; ch < n_chunks; ++ch) {
+        const long pre = (ch + 1 < n_chunks ? ch + 1 : ch) * kChunk; // last chunk: harmless re-load of itself
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            nxt[j] = f[pre + j];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            body(cur[j]);
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            cur[j] = nxt[j];
+    }
+    for (long t = n_chunks * kChunk; t < n; ++t)
+        body(f[t]);
+}
+
 // The launch body.  Model supplies: setup(area, dt, p), set_states(st12), step(rain, peva, capture),
 // members q_out, q_in (sum of the five catchment outflows), q_gw (shallow + deep), get_vars(v19).
 //
@@ -155,67 +186,62 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
 
     const double2 *__restrict__ f = forcing + c * a.T;
 
-    // The forcing of step t+1 is requested (scalar load) before step t is computed, so its latency hides
-    // behind ~100 fp64 instructions; the wait sits at the top of the next iteration.
-    double2 nxt = f[0];
+    // ---- warm-up over the first W steps of the same forcing; only the states survive (structure.py:118-121)
+    time_loop(f, a.W, [&](const double2 v) { m.step(v.x, v.y, false); });
 
-    // warm-up over the first W steps of the same forcing; only the states survive (structure.py:118-121)
-    for (long t = 0; t < a.W; ++t) {
-        const double2 v = nxt;
-        nxt = f[t + 1 < a.W ? t + 1 : 0];
-        m.step(v.x, v.y, false);
-    }
-
+    // ---- the run proper (structure.py:143-146, 181-195)
     const bool summary = a.report_type == 1;
     const bool want_obj = a.objfn != nullptr;
     const double *__restrict__ ws = ws_all ? ws_all + c * (kWsHead + a.R) : nullptr;
+    const double *__restrict__ obs = obs_all ? obs_all + c * a.R : nullptr;
     const double ebar = want_obj ? ws[1] : 0.0;
     const double inv_gap = 1.0 / (double)a.gap;
 
     double num = 0.0, den = 0.0;         // groundwater sums over every step (summary, structure.py:191)
     double num_raw = 0.0, den_raw = 0.0; // ... over the reported rows only (raw, structure.py:194-195)
     double A = 0.0, B = 0.0, C1 = 0.0, C2 = 0.0, C3 = 0.0; // objective-function moments
-    long t = 0;
-    for (long r = 0; r < a.R; ++r) {
-        const long len = r == 0 ? a.first_len : a.gap;
-        double acc = 0.0;
-        for (long k = 0; k < len; ++k, ++t) {
-            const double2 v = nxt;
-            nxt = f[t + 1 < a.T ? t + 1 : t];
-            m.step(v.x, v.y, false);
-            if (NP_MEAN)
-                lds[k * kWave + lane] = m.q_out;
-            else
-                acc += m.q_out;
-            num += m.q_gw;
-            den += m.q_in;
-        }
-        double val;
-        if (summary) {
-            if (NP_MEAN)
-                val = np_pairwise_lds(lds + lane, len) / (double)a.gap;
-            else
-                val = Model::kExactDivide ? acc / (double)a.gap : acc * inv_gap;
-        } else {
-            val = m.q_out;
-            num_raw += m.q_gw;
-            den_raw += m.q_in;
-        }
-        if (a.discharge && live)
-            a.discharge[(c * a.R + r) * a.ld + n] = val;
-        if (want_obj) {
-            const double e = obs_all[c * a.R + r];
-            if (e == e) { // not NaN: montecarlo.py:195-196
-                const double d = val - e;
-                const double u = val - ebar;
-                A += d;
-                B += d * d;
-                C1 += u;
-                C2 += u * u;
-                C3 += ws[kWsHead + r] * u;
+    double acc = 0.0;                    // running sum of the current report interval
+    long k = 0, r = 0, len = a.first_len;
+    time_loop(f, a.T, [&](const double2 v) {
+        m.step(v.x, v.y, false);
+        if (NP_MEAN)
+            lds[k * kWave + lane] = m.q_out;
+        else
+            acc += m.q_out;
+        num += m.q_gw;
+        den += m.q_in;
+        if (++k == len) { // end of report interval r (wave-uniform)
+            double val;
+            if (summary) {
+                if (NP_MEAN)
+                    val = np_pairwise_lds(lds + lane, len) / (double)a.gap;
+                else
+                    val = Model::kExactDivide ? acc / (double)a.gap : acc * inv_gap;
+            } else {
+                val = m.q_out;
+                num_raw += m.q_gw;
+                den_raw += m.q_in;
             }
+            if (a.discharge && live)
+                a.discharge[(c * a.R + r) * a.ld + n] = val;
+            if (want_obj) {
+                const double e = obs[r];
+                if (e == e) { // not NaN: montecarlo.py:195-196
+                    const double d = val - e;
+                    const double u = val - ebar;
+                    A += d;
+                    B += d * d;
+                    C1 += u;
+                    C2 += u * u;
+                    C3 += ws[kWsHead + r] * u;
+                }
+            }
+            ++r;
+            k = 0;
+            len = a.gap;
+            acc = 0.0;
         }
-    }
+    });
 
     const double gw = summary ? num / den : num_raw / den_raw;
     if (live)
