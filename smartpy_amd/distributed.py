@@ -56,6 +56,13 @@ def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def rank_world():
+    """(rank, world_size) of the initialised process group, (0, 1) otherwise."""
+    if is_distributed():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def barrier():
     if is_distributed():
         dist.barrier()

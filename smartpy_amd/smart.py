@@ -1,0 +1,146 @@
+"""The model facade (counterpart of smartpy/smart.py): same constructor, attributes and methods, GPU underneath.
+
+`SMART.simulate(param)` runs one parameter set like the reference (smart.py:154-210).  The MI355X-native entry is
+`SMART.simulate_ensemble(matrix)`: every row of an [N, 10] parameter matrix in one launch, optionally with the
+objective functions fused, which is what the Monte-Carlo classes call.
+"""
+from os import path, makedirs, sep
+
+import numpy as np
+
+from .timeframe import TimeFrame
+from .parameters import Parameters
+from .inout import get_rain_series_simu, get_peva_series_simu, get_discharge_series, write_flow_file_from_nds
+from . import structure
+from . import engine
+
+
+class SMART(object):
+    """SMART is the core object to set up and use to run an experiment (smart.py:29)."""
+
+    def __init__(self, catchment, catchment_area_m2, start, end,
+                 time_delta_simu, time_delta_save, warm_up_days,
+                 in_format, out_format, root,
+                 gauged_area_m2=None):
+        self._init_common(catchment, catchment_area_m2, start, end, time_delta_simu, time_delta_save, warm_up_days,
+                          in_format, out_format, root)
+        if not path.exists(self.out_f):
+            makedirs(self.out_f)
+        ext = '.nc' if self.in_fmt == 'netcdf' else ''
+        base = ''.join([self.in_f, self.catchment])
+        # forcing on the simulation axis, observations on the report axis (smart.py:130-143)
+        self.nd_rain = get_rain_series_simu(base + '.rain' + ext, self.in_fmt, self.timeseries[1],
+                                            self.timeseries[-1], self.delta_simu)
+        self.nd_peva = get_peva_series_simu(base + '.peva' + ext, self.in_fmt, self.timeseries[1],
+                                            self.timeseries[-1], self.delta_simu)
+        self.nd_flow = get_discharge_series(base + '.flow' + ext, self.in_fmt, self.timeseries_report[1],
+                                            self.timeseries_report[-1], catchment_area_m2, gauged_area_m2) \
+            if gauged_area_m2 else None
+
+    @classmethod
+    def from_arrays(cls, catchment_area_m2, start, end, time_delta_simu, time_delta_save, warm_up_days,
+                    nd_rain, nd_peva, nd_flow=None, catchment='catchment', out_format='csv', root=None):
+        """Build a model from in-memory series instead of files: nd_rain / nd_peva per simulation step (length T),
+        nd_flow per report step (length R, NaN = missing) or None."""
+        self = cls.__new__(cls)
+        self._init_common(catchment, catchment_area_m2, start, end, time_delta_simu, time_delta_save, warm_up_days,
+                          'csv', out_format, root if root is not None else '.')
+        self.nd_rain = np.ascontiguousarray(nd_rain, dtype=np.float64)
+        self.nd_peva = np.ascontiguousarray(nd_peva, dtype=np.float64)
+        self.nd_flow = None if nd_flow is None else np.ascontiguousarray(nd_flow, dtype=np.float64)
+        T, R = len(self.timeseries) - 1, len(self.timeseries_report) - 1
+        if len(self.nd_rain) != T or len(self.nd_peva) != T or (self.nd_flow is not None and len(self.nd_flow) != R):
+            raise Exception("from_arrays: expected {} forcing values and {} observations.".format(T, R))
+        return self
+
+    def _init_common(self, catchment, catchment_area_m2, start, end, time_delta_simu, time_delta_save,
+                     warm_up_days, in_format, out_format, root):
+        self.catchment = catchment
+        self.area = catchment_area_m2
+        self.in_fmt = in_format
+        self.out_fmt = out_format
+        self.root_f = root
+        self.in_f = sep.join([self.root_f, 'in', self.catchment, sep])
+        self.out_f = sep.join([self.root_f, 'out', self.catchment, sep])
+        self.start = start
+        self.end = end
+        self.delta_simu = time_delta_simu
+        self.delta_save = time_delta_save
+        self.timeframe = TimeFrame(self.start, self.end, self.delta_simu, self.delta_save)
+        self.timeseries = self.timeframe.get_series_simu()
+        self.timeseries_report = self.timeframe.get_series_save()
+        self.warm_up = warm_up_days
+        self.extra = None                    # smart.py:145
+        self.parameters = Parameters()
+        self.outputs = None
+        self.nd_discharge = None
+        self.gw_contribution = None
+        self._device_cache = None
+
+    # ------------------------------------------------------------------------------------------------------
+    def simulate(self, param, report='summary'):
+        """One parameter set (dict with the ten names) -> (discharge ndarray [R], gw float) (smart.py:154-210)."""
+        nd_parameters = np.array([param[name] for name in self.parameters.names])
+        self.outputs = structure.run(self.area, self.delta_simu, self.nd_rain, self.nd_peva,
+                                     nd_parameters, self.extra, self.timeseries, self.timeseries_report,
+                                     report=report, warm_up=self.warm_up)
+        self.nd_discharge = self.outputs[0]
+        self.gw_contribution = self.outputs[1]
+        return self.outputs
+
+    def simulate_ensemble(self, parameters, report='summary', objective_functions=False, gw_constraint=None,
+                          save_discharge=True, math_mode='fast', device=None):
+        """Every row of `parameters` ([N, 10] ndarray or device tensor, columns in self.parameters.names order)
+        in one launch.  Returns an engine.EnsembleResult with device tensors: .discharge [N, R] (a view of the
+        sample-minor buffer), .gw [N], .objfn [N, 8] when objective_functions (needs observations)."""
+        import torch
+        device = torch.device(device) if device is not None else engine.default_device()
+        delta_sec = self.delta_simu.total_seconds()
+        T = len(self.timeseries) - 1
+        n_warm = structure.warm_up_length(self.warm_up, delta_sec, T) if self.warm_up != 0 else 0
+        gap = T // (len(self.timeseries_report) - 1)
+        if self._device_cache is None or self._device_cache[0] != device:
+            forcing = engine.as_device(np.stack([self.nd_rain, self.nd_peva], axis=1), device)
+            obs = engine.as_device(self.nd_flow, device) if self.nd_flow is not None else None
+            self._device_cache = (device, forcing, obs)
+        _, forcing, obs = self._device_cache
+        if objective_functions and obs is None:
+            raise Exception("The observation array does not exist. Please make sure that a value is assigned "
+                            "to the gauged_area_m2 attribute of your SMART class instance.")
+        return engine.run_ensemble(parameters, forcing, float(self.area), delta_sec, n_warm, gap, report=report,
+                                   extra=self.extra if self.extra else None, obs=obs if objective_functions else None,
+                                   gw_obs=gw_constraint if objective_functions else None, math_mode=math_mode,
+                                   want_discharge=save_discharge, want_objfn=bool(objective_functions),
+                                   device=device)
+
+    # ------------------------------------------------------------------------------------------------------
+    def write_output_files(self, which='both', parallel=False):
+        """smart.py:212-255."""
+        if (which == 'both') or (which == 'modelled'):
+            if self.nd_discharge is not None:
+                write_flow_file_from_nds(self.timeseries_report[1:], self.nd_discharge,
+                                         ''.join([self.out_f, self.catchment, '.mod.flow']),
+                                         out_file_format=self.out_fmt, parallel=parallel)
+            else:
+                raise Exception("The modelled flow output file cannot be written. Please make sure to call the "
+                                "simulate method of your SMART instance before writing this output file.")
+        if (which == 'both') or (which == 'observed'):
+            if self.nd_flow is not None:
+                write_flow_file_from_nds(self.timeseries_report[1:], self.nd_flow,
+                                         ''.join([self.out_f, self.catchment, '.obs.flow']),
+                                         out_file_format=self.out_fmt, parallel=parallel)
+            else:
+                raise Exception("The observed flow output file cannot be written. Please make sure that a value is "
+                                "assigned to the gauged_area_m2 attribute of the SMART class instance.")
+
+    def get_simulation_array(self):
+        if self.nd_discharge is not None:
+            return self.nd_discharge
+        raise Exception("The simulation array cannot be retrieved. Please make sure to call the simulate "
+                        "method of your SMART instance before requesting this output array.")
+
+    def get_evaluation_array(self):
+        if self.nd_flow is not None:
+            return self.nd_flow
+        raise Exception("The observation array does not exist. Please make sure that a value is assigned "
+                        "to the gauged_area_m2 attribute of your SMART class instance.")

@@ -95,6 +95,17 @@ def storage_table(area, dt, L, rain, peva, p, initial):
     return tab
 
 
+def resampling_vectors(root):
+    """KAT-10: the input pipeline on axes that need re-aggregation (timeframe.py:158-233): 6-hourly steps on the
+    daily 09:00 data (resolution 6 h) and the same shifted to 12:00 (resolution 3 h, two portions per step)."""
+    out = {}
+    for tag, hh in (('aligned', 9), ('shifted', 12)):
+        sm = smartpy.SMART('Catchment', AREA, datetime(2007, 1, 1, hh), datetime(2007, 12, 31, hh),
+                           timedelta(hours=6), timedelta(days=1), 0, 'csv', 'csv', root, gauged_area_m2=175.97 * 1e6)
+        out['rain_' + tag], out['peva_' + tag], out['flow_' + tag] = sm.nd_rain, sm.nd_peva, sm.nd_flow
+    save('kat10_resampling.npz', **out)
+
+
 def main():
     scratch = tempfile.mkdtemp(prefix='smart_golden_')
     shutil.copytree(os.path.join(REF, 'tests', 'data'), os.path.join(scratch, 'data'))
@@ -103,6 +114,11 @@ def main():
         os.chmod(dirpath, 0o755)
         for f in files:
             os.chmod(os.path.join(dirpath, f), 0o644)
+
+    resampling_vectors(root)
+    if '--only-resampling' in sys.argv:
+        shutil.rmtree(scratch)
+        return
 
     # ---------------------------------------------------------------------------------------------------
     # forcing + observations of the shipped example, as the reference's input pipeline delivers them

