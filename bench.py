@@ -94,6 +94,7 @@ def main():
     ap.add_argument('--math', default='fast', choices=['fast', 'literal'])
     ap.add_argument('--no-discharge', action='store_true', help='do not write the [R, N] discharge matrix')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sort-col', type=int, default=-1, help='experiment: sort the sample rows by this parameter column')
     args = ap.parse_args()
 
     rank, world, device = sdist.init()
@@ -108,6 +109,8 @@ def main():
     n_local = args.samples
     ranges = Parameters().ranges
     params = latin_hypercube(n_local, ranges, seed=2718 + rank)       # this rank's shard of the ensemble
+    if args.sort_col >= 0:
+        params = params[np.argsort(params[:, args.sort_col], kind='stable')]
     d_forcing = torch.from_numpy(forcing).to(device)
     d_params = torch.from_numpy(params).to(device)
 

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libsmart_amd.so')
+# SMART_AMD_LIB selects another build of the same ABI (kernel tuning experiments: tools/ab_variants.sh)
+LIB_PATH = os.environ.get('SMART_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libsmart_amd.so')
 
 REPORT_SUMMARY, REPORT_RAW = 1, 2
 MATH_LITERAL, MATH_FAST = 0, 1

@@ -210,7 +210,7 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
             acc += m.q_out;
         num += m.q_gw;
         den += m.q_in;
-        if (++k == len) { // end of report interval r (wave-uniform)
+        if (__builtin_expect(++k == len, 0)) { // end of report interval r (wave-uniform, 1 step in `gap`)
             double val;
             if (summary) {
                 if (NP_MEAN)

@@ -27,8 +27,13 @@
 
 namespace smart {
 
-template <bool STIFF, bool GUARD>
+// MERGE: reservoirs that share a time constant are linear and un-clamped in the regular case, so the pair
+// (overland, drain) [k = SK] and the pair (shallow, deep groundwater) [k = GK] can each be carried as ONE
+// outflow: (Ua + Ub)' = (Ua + Ub)*dec + (xa + xb)*cq.  Only their sums enter the river inflow (structure.py:254)
+// and the groundwater ratio (:191).  Used when the caller does not ask for the final state vector.
+template <bool STIFF, bool GUARD, bool MERGE = false>
 struct FastModel {
+    static_assert(!(MERGE && STIFF), "the clamps of structure.py:429-450 act on each reservoir separately");
     static constexpr bool kExactDivide = false;
 
     // per-sample constants
@@ -69,11 +74,11 @@ struct FastModel {
 
     __device__ void set_states(const double *st)
     {
-        u_ove = st[0] / k_s;
-        u_dra = st[1] / k_s;
+        u_ove = MERGE ? (st[0] + st[1]) / k_s : st[0] / k_s;
+        u_dra = MERGE ? 0.0 : st[1] / k_s;
         u_int = st[2] / k_f;
-        u_sgw = st[3] / k_g;
-        u_dgw = st[4] / k_g;
+        u_sgw = MERGE ? (st[3] + st[4]) / k_g : st[3] / k_g;
+        u_dgw = MERGE ? 0.0 : st[4] / k_g;
         const double m3_to_mm = 1.0 / mm_to_m3;
         l0 = st[5] * m3_to_mm;
         l1 = st[6] * m3_to_mm;
@@ -158,8 +163,8 @@ struct FastModel {
     __device__ void step(double rain_in, double peva_in, bool /*last*/)
     {
         // outflows of this step are the reservoir states at its start (structure.py:427, :487)
-        q_gw = u_sgw + u_dgw;
-        q_in = ((u_ove + u_dra) + u_int) + q_gw;
+        q_gw = MERGE ? u_sgw : u_sgw + u_dgw;
+        q_in = MERGE ? (u_ove + u_int) + u_sgw : ((u_ove + u_dra) + u_int) + q_gw;
         double q_r = u_riv;
         // river (structure.py:487-498) in outflow units: tmp / rk = U + (q_in - U) * dt / rk
         double u_new = fma(q_in - u_riv, a_r, u_riv);
@@ -200,11 +205,17 @@ struct FastModel {
             leak(l3, p4, s1 * 0.25, p3, inf, sh, dp);
             leak(l4, p5, s1 * 0.2, p2, inf, sh, dp);
             leak(l5, p6, s1 * (1.0 / 6.0), s1, inf, sh, dp);
-            u_ove = clamp(fma(u_ove, dec_s, of * cq_s));
-            u_dra = clamp(fma(u_dra, dec_s, df * cq_s));
-            u_int = clamp(fma(u_int, dec_f, inf * cq_f));
-            u_sgw = clamp(fma(u_sgw, dec_g, sh * cq_g));
-            u_dgw = clamp(fma(u_dgw, dec_g, dp * cq_g));
+            if (MERGE) {
+                u_ove = fma(u_ove, dec_s, (of + df) * cq_s);
+                u_int = fma(u_int, dec_f, inf * cq_f);
+                u_sgw = fma(u_sgw, dec_g, (sh + dp) * cq_g);
+            } else {
+                u_ove = clamp(fma(u_ove, dec_s, of * cq_s));
+                u_dra = clamp(fma(u_dra, dec_s, df * cq_s));
+                u_int = clamp(fma(u_int, dec_f, inf * cq_f));
+                u_sgw = clamp(fma(u_sgw, dec_g, sh * cq_g));
+                u_dgw = clamp(fma(u_dgw, dec_g, dp * cq_g));
+            }
         } else { // :400
             double d = -ex;
             dry(l0, d, pC);
@@ -219,10 +230,12 @@ struct FastModel {
                 dry(l5, d, pC);
             }
             u_ove = clamp(u_ove * dec_s);
-            u_dra = clamp(u_dra * dec_s);
             u_int = clamp(u_int * dec_f);
             u_sgw = clamp(u_sgw * dec_g);
-            u_dgw = clamp(u_dgw * dec_g);
+            if (!MERGE) {
+                u_dra = clamp(u_dra * dec_s);
+                u_dgw = clamp(u_dgw * dec_g);
+            }
         }
     }
 };
@@ -247,7 +260,9 @@ __global__ __launch_bounds__(kWave) void smart_ensemble_fast(KArgs a, const doub
                                                              const double *__restrict__ ws)
 {
     const int cls = wave_class(a);
-    if (cls == 0)
+    if (cls == 0 && a.final_vars == nullptr)
+        run_ensemble<FastModel<false, false, true>, false>(a, forcing, obs, ws, nullptr);
+    else if (cls == 0)
         run_ensemble<FastModel<false, false>, false>(a, forcing, obs, ws, nullptr);
     else if (cls == 1)
         run_ensemble<FastModel<true, false>, false>(a, forcing, obs, ws, nullptr);

@@ -37,6 +37,7 @@ def init(backend=None):
     """Initialise torch.distributed from the environment (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE).
     Returns (rank, world_size, device).  backend defaults to nccl (= RCCL) when a GPU is visible, else gloo."""
     rank, world, local = env_world()
+    backend = backend or os.environ.get('SMART_DIST_BACKEND') or None      # e.g. gloo: two ranks sharing one GPU
     use_gpu = torch.cuda.is_available()
     if use_gpu:
         torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
@@ -54,6 +55,11 @@ def init(backend=None):
 
 def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _host_staged():
+    """gloo moves host memory: device tensors are staged through the CPU (test set-ups only; RCCL takes them as is)."""
+    return dist.get_backend() == 'gloo'
 
 
 def rank_world():
@@ -80,16 +86,19 @@ def gather_rows(local, n_rows_total):
         pad = torch.zeros((per,) + tail, dtype=local.dtype, device=local.device)
         pad[:local.shape[0]] = local
         local = pad
+    device = local.device
+    if device.type != 'cpu' and _host_staged():
+        local = local.cpu()
     out = torch.empty((world * per,) + tail, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
-    return out[:n_rows_total]
+    return out[:n_rows_total].to(device)
 
 
 def max_over_ranks(value, device):
     """Scalar max-reduce (timings)."""
     if not is_distributed():
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device='cpu' if _host_staged() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -97,6 +106,6 @@ def max_over_ranks(value, device):
 def sum_over_ranks(value, device):
     if not is_distributed():
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device='cpu' if _host_staged() else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())

@@ -4,7 +4,7 @@
 `SMART.simulate_ensemble(matrix)`: every row of an [N, 10] parameter matrix in one launch, optionally with the
 objective functions fused, which is what the Monte-Carlo classes call.
 """
-from os import path, makedirs, sep
+from os import makedirs, sep
 
 import numpy as np
 
@@ -24,8 +24,7 @@ class SMART(object):
                  gauged_area_m2=None):
         self._init_common(catchment, catchment_area_m2, start, end, time_delta_simu, time_delta_save, warm_up_days,
                           in_format, out_format, root)
-        if not path.exists(self.out_f):
-            makedirs(self.out_f)
+        makedirs(self.out_f, exist_ok=True)      # every rank of a multi-GPU run gets here at the same time
         ext = '.nc' if self.in_fmt == 'netcdf' else ''
         base = ''.join([self.in_f, self.catchment])
         # forcing on the simulation axis, observations on the report axis (smart.py:130-143)
