@@ -34,6 +34,10 @@ struct KArgs {
     double *final_vars; // [C][N][19] | null
 };
 
+#ifndef SMART_NT_STORE
+#define SMART_NT_STORE 0
+#endif
+
 constexpr int kWave = 64;
 constexpr int kWsHead = 8;
 
@@ -99,10 +103,24 @@ __device__ inline double np_pairwise_lds(const double *col, long n)
 // Walk n time steps of one catchment's forcing.  The forcing of a step is the same for all 64 lanes, so it is
 // fetched with scalar loads into SGPRs: kChunk steps (one 64-byte line) per s_load_dwordx16, and the next chunk is
 // requested before the current one is consumed, so the load latency hides behind kChunk model steps.
-constexpr int kChunk = 4;
+#ifndef SMART_CHUNK
+#define SMART_CHUNK 4
+#endif
+constexpr int kChunk = SMART_CHUNK;
 
-template <class Body>
-__device__ __forceinline__ void time_loop(const double2 *__restrict__ f, long n, Body &&body)
+// Branch class of one step for the whole wavefront, from the per-lane rain excess: 0 = every lane dry,
+// 1 = every lane wet, 2 = mixed.  (All 64 lanes of the one-wave workgroup are always active.)
+__device__ __forceinline__ int wave_step_class(double ex)
+{
+    const unsigned long long wet = __builtin_amdgcn_ballot_w64(ex >= 0.0);
+    return wet == 0ull ? 0 : (wet == ~0ull ? 1 : 2);
+}
+
+// The rain excess and the branch class of the kChunk steps of a chunk are computed together, ahead of the steps:
+// the wet/dry decision of a step is then a scalar compare on a value that has been sitting in an SGPR for a
+// while, instead of a vector compare -> EXEC manipulation -> branch chain on the critical path of every step.
+template <class Model, class Body>
+__device__ __forceinline__ void time_loop(const Model &m, const double2 *__restrict__ f, long n, Body &&body)
 {
     const long n_chunks = n / kChunk;
     double2 cur[kChunk], nxt[kChunk];
@@ -116,18 +134,28 @@ __device__ __forceinline__ void time_loop(const double2 *__restrict__ f, long n,
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
             nxt[j] = f[pre + j];
+        double ex[kChunk];
+        int cls[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+            ex[j] = m.excess(cur[j].x, cur[j].y);
+            cls[j] = wave_step_class(ex[j]);
+        }
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
-            body(cur[j]);
+            body(cur[j], ex[j], cls[j]);
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
             cur[j] = nxt[j];
     }
-    for (long t = n_chunks * kChunk; t < n; ++t)
-        body(f[t]);
+    for (long t = n_chunks * kChunk; t < n; ++t) {
+        const double2 v = f[t];
+        const double ex = m.excess(v.x, v.y);
+        body(v, ex, wave_step_class(ex));
+    }
 }
 
-// The launch body.  Model supplies: setup(area, dt, p), set_states(st12), step(rain, peva, capture),
+// The launch body.  Model supplies: setup(area, dt, p), set_states(st12), excess(rain, peva), step(rain, peva, ex, cls),
 // members q_out, q_in (sum of the five catchment outflows), q_gw (shallow + deep), get_vars(v19).
 //
 // forcing / obs / ws arrive as separate __restrict__ kernel parameters: only then can the compiler prove that
@@ -187,7 +215,7 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
     const double2 *__restrict__ f = forcing + c * a.T;
 
     // ---- warm-up over the first W steps of the same forcing; only the states survive (structure.py:118-121)
-    time_loop(f, a.W, [&](const double2 v) { m.step(v.x, v.y, false); });
+    time_loop(m, f, a.W, [&](const double2 v, const double ex, const int cls) { m.step(v.x, v.y, ex, cls); });
 
     // ---- the run proper (structure.py:143-146, 181-195)
     const bool summary = a.report_type == 1;
@@ -202,8 +230,8 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
     double A = 0.0, B = 0.0, C1 = 0.0, C2 = 0.0, C3 = 0.0; // objective-function moments
     double acc = 0.0;                    // running sum of the current report interval
     long k = 0, r = 0, len = a.first_len;
-    time_loop(f, a.T, [&](const double2 v) {
-        m.step(v.x, v.y, false);
+    time_loop(m, f, a.T, [&](const double2 v, const double ex, const int cls) {
+        m.step(v.x, v.y, ex, cls);
         if (NP_MEAN)
             lds[k * kWave + lane] = m.q_out;
         else
@@ -223,7 +251,13 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
                 den_raw += m.q_in;
             }
             if (a.discharge && live)
+#if SMART_NT_STORE
+                // written once, never re-read by this launch: keep the 2.9 GB stream from evicting the 1.4 MB of
+                // forcing that every wavefront re-reads from L2
+                __builtin_nontemporal_store(val, &a.discharge[(c * a.R + r) * a.ld + n]);
+#else
                 a.discharge[(c * a.R + r) * a.ld + n] = val;
+#endif
             if (want_obj) {
                 const double e = obs[r];
                 if (e == e) { // not NaN: montecarlo.py:195-196

@@ -24,6 +24,13 @@
 #ifndef SMART_FAST_EARLY_EXIT
 #define SMART_FAST_EARLY_EXIT 1
 #endif
+// Tuning knobs, A/B-measured on MI355X at the headline size (tools/ab_variants.sh, same box, interleaved):
+//   SMART_FAST_EARLY_EXIT 1: 27.0 ms vs 28.5 ms without the wave-uniform early exits;
+//   SMART_FAST_LOOKAHEAD  0: branching on the wave class computed a chunk ahead (separate all-wet / all-dry /
+//                            mixed bodies, no EXEC juggling) doubles the loop body and is 9 % SLOWER (29.6 vs 27.1 ms).
+#ifndef SMART_FAST_LOOKAHEAD
+#define SMART_FAST_LOOKAHEAD 0
+#endif
 
 namespace smart {
 
@@ -160,7 +167,77 @@ struct FastModel {
         }
     }
 
-    __device__ void step(double rain_in, double peva_in, bool /*last*/)
+    // rain excess of a step (structure.py:353-355); evaluated a few steps ahead by time_loop()
+    __device__ double excess(double rain_in, double peva_in) const { return fma(rain_in, pT, -peva_in); }
+
+    // wet branch of structure.py:359-399 for the lanes that are active
+    __device__ __forceinline__ void wet_lanes(double ex)
+    {
+        const double tot = ((l0 + l1) + (l2 + l3)) + (l4 + l5);
+        const double hp = hz * tot;
+        const double s1 = sz * tot;
+        const double of = hp * ex;
+        ex = fma(-hp, ex, ex);
+        fill(l0, ex, z);
+#if SMART_FAST_EARLY_EXIT
+        if (__builtin_amdgcn_ballot_w64(ex > 0.0) != 0)
+#endif
+        {
+            fill(l1, ex, z);
+            fill(l2, ex, z);
+            fill(l3, ex, z);
+            fill(l4, ex, z);
+            fill(l5, ex, z);
+        }
+        const double df = pD * ex;
+        double inf = ex - df;
+        double sh = 0.0, dp = 0.0;
+        const double p2 = s1 * s1, p3 = p2 * s1, p4 = p2 * p2, p5 = p4 * s1, p6 = p3 * p3;
+        leak(l0, s1, s1, p6, inf, sh, dp);
+        leak(l1, p2, s1 * 0.5, p5, inf, sh, dp);
+        leak(l2, p3, s1 * (1.0 / 3.0), p4, inf, sh, dp);
+        leak(l3, p4, s1 * 0.25, p3, inf, sh, dp);
+        leak(l4, p5, s1 * 0.2, p2, inf, sh, dp);
+        leak(l5, p6, s1 * (1.0 / 6.0), s1, inf, sh, dp);
+        if (MERGE) {
+            u_ove = fma(u_ove, dec_s, (of + df) * cq_s);
+            u_int = fma(u_int, dec_f, inf * cq_f);
+            u_sgw = fma(u_sgw, dec_g, (sh + dp) * cq_g);
+        } else {
+            u_ove = clamp(fma(u_ove, dec_s, of * cq_s));
+            u_dra = clamp(fma(u_dra, dec_s, df * cq_s));
+            u_int = clamp(fma(u_int, dec_f, inf * cq_f));
+            u_sgw = clamp(fma(u_sgw, dec_g, sh * cq_g));
+            u_dgw = clamp(fma(u_dgw, dec_g, dp * cq_g));
+        }
+    }
+
+    // dry branch of structure.py:400-419 for the lanes that are active
+    __device__ __forceinline__ void dry_lanes(double ex)
+    {
+        double d = -ex;
+        dry(l0, d, pC);
+#if SMART_FAST_EARLY_EXIT
+        if (__builtin_amdgcn_ballot_w64(d > 0.0) != 0)
+#endif
+        {
+            dry(l1, d, pC);
+            dry(l2, d, pC);
+            dry(l3, d, pC);
+            dry(l4, d, pC);
+            dry(l5, d, pC);
+        }
+        u_ove = clamp(u_ove * dec_s);
+        u_int = clamp(u_int * dec_f);
+        u_sgw = clamp(u_sgw * dec_g);
+        if (!MERGE) {
+            u_dra = clamp(u_dra * dec_s);
+            u_dgw = clamp(u_dgw * dec_g);
+        }
+    }
+
+    // cls: branch class of this step for the whole wavefront (0 all dry, 1 all wet, 2 mixed), known in advance
+    __device__ void step(double /*rain_in*/, double /*peva_in*/, double ex, int cls)
     {
         // outflows of this step are the reservoir states at its start (structure.py:427, :487)
         q_gw = MERGE ? u_sgw : u_sgw + u_dgw;
@@ -177,65 +254,18 @@ struct FastModel {
         u_riv = u_new;
         q_out = q_r;
 
-        double ex = fma(rain_in, pT, -peva_in); // structure.py:353-355
-        if (ex >= 0.0) {                        // :359
-            const double tot = ((l0 + l1) + (l2 + l3)) + (l4 + l5);
-            const double hp = hz * tot;
-            const double s1 = sz * tot;
-            const double of = hp * ex;
-            ex = fma(-hp, ex, ex);
-            fill(l0, ex, z);
-#if SMART_FAST_EARLY_EXIT
-            if (__builtin_amdgcn_ballot_w64(ex > 0.0) != 0)
+#if SMART_FAST_LOOKAHEAD
+        if (cls == 1) {
+            wet_lanes(ex);
+        } else if (cls == 0) {
+            dry_lanes(ex);
+        } else
 #endif
-            {
-                fill(l1, ex, z);
-                fill(l2, ex, z);
-                fill(l3, ex, z);
-                fill(l4, ex, z);
-                fill(l5, ex, z);
-            }
-            const double df = pD * ex;
-            double inf = ex - df;
-            double sh = 0.0, dp = 0.0;
-            const double p2 = s1 * s1, p3 = p2 * s1, p4 = p2 * p2, p5 = p4 * s1, p6 = p3 * p3;
-            leak(l0, s1, s1, p6, inf, sh, dp);
-            leak(l1, p2, s1 * 0.5, p5, inf, sh, dp);
-            leak(l2, p3, s1 * (1.0 / 3.0), p4, inf, sh, dp);
-            leak(l3, p4, s1 * 0.25, p3, inf, sh, dp);
-            leak(l4, p5, s1 * 0.2, p2, inf, sh, dp);
-            leak(l5, p6, s1 * (1.0 / 6.0), s1, inf, sh, dp);
-            if (MERGE) {
-                u_ove = fma(u_ove, dec_s, (of + df) * cq_s);
-                u_int = fma(u_int, dec_f, inf * cq_f);
-                u_sgw = fma(u_sgw, dec_g, (sh + dp) * cq_g);
-            } else {
-                u_ove = clamp(fma(u_ove, dec_s, of * cq_s));
-                u_dra = clamp(fma(u_dra, dec_s, df * cq_s));
-                u_int = clamp(fma(u_int, dec_f, inf * cq_f));
-                u_sgw = clamp(fma(u_sgw, dec_g, sh * cq_g));
-                u_dgw = clamp(fma(u_dgw, dec_g, dp * cq_g));
-            }
-        } else { // :400
-            double d = -ex;
-            dry(l0, d, pC);
-#if SMART_FAST_EARLY_EXIT
-            if (__builtin_amdgcn_ballot_w64(d > 0.0) != 0)
-#endif
-            {
-                dry(l1, d, pC);
-                dry(l2, d, pC);
-                dry(l3, d, pC);
-                dry(l4, d, pC);
-                dry(l5, d, pC);
-            }
-            u_ove = clamp(u_ove * dec_s);
-            u_int = clamp(u_int * dec_f);
-            u_sgw = clamp(u_sgw * dec_g);
-            if (!MERGE) {
-                u_dra = clamp(u_dra * dec_s);
-                u_dgw = clamp(u_dgw * dec_g);
-            }
+        {
+            if (ex >= 0.0) // structure.py:359
+                wet_lanes(ex);
+            else // :400
+                dry_lanes(ex);
         }
     }
 };

@@ -79,7 +79,10 @@ struct LiteralModel {
         return q;
     }
 
-    __device__ void step(double rain_in, double peva_in, bool /*capture*/)
+    // time_loop() asks for the excess ahead of the step; the literal step recomputes it in the reference's order
+    __device__ double excess(double rain_in, double peva_in) const { return rain_in * pT - peva_in; }
+
+    __device__ void step(double rain_in, double peva_in, double /*ex*/, int /*cls*/)
     {
         const double z = pZ / 6.0; // structure.py:329-337
         double l[6];
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(kWave) void smart_onestep_literal(long n, const dou
     LiteralModel m;
     m.setup(x[0], x[1], p);
     m.set_states(st);
-    m.step(x[2], x[3], true);
+    m.step(x[2], x[3], 0.0, 2);
     double v[19];
     m.get_vars(v);
 #pragma unroll
