@@ -47,7 +47,10 @@ extern "C" {
                              /* bit-identical to the CPU oracle configured with the product chain for   */
                              /* s'**i (the only place where CPython calls libm)                         */
 #define SMART_MATH_FAST 1    /* reciprocals hoisted out of the time loop, soil layers kept in mm,       */
-                             /* reservoirs kept as outflows, FMA: <= 1e-11 relative on discharge         */
+                             /* reservoirs kept as outflows, FMA: <= 1e-9 relative on discharge;        */
+                             /* wavefronts holding a sample with delta_sec / (k * 3600) > 2 (where the  */
+                             /* reference's explicit update amplifies rounding differences) run the     */
+                             /* literal arithmetic instead                                              */
 
 /* error codes; the reference raises Exception at the cited places */
 #define SMART_OK 0

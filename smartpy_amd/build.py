@@ -16,11 +16,11 @@ ARCH = 'gfx950'
 # translation unit -> extra flags.  The literal kernels must round every operation separately.
 UNITS = {
     'smart_literal.hip': ['-ffp-contract=off'],
-    'smart_fast.hip': ['-ffp-contract=fast'],
+    'smart_fast.hip': ['-ffp-contract=fast-honor-pragmas'],   # the literal model inside it opts out per function
     'smart_capi.hip': [],
 }
 COMMON = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-fno-gpu-rdc', '-Wall']
-DEPS = ['smart_device.h', os.path.join('..', '..', 'include', 'smart_amd.h')]
+DEPS = ['smart_device.h', 'smart_literal_model.h', os.path.join('..', '..', 'include', 'smart_amd.h')]
 
 
 def hipcc():

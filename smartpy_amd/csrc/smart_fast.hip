@@ -20,6 +20,7 @@
 // Rounding differs from the reference at the 1e-16 level per operation; the recurrence is dissipative, so
 // the discharge stays within ~1e-12 relative of the literal path (gate in tests: 1e-9; contract: 1e-6).
 #include "smart_device.h"
+#include "smart_literal_model.h"
 
 #ifndef SMART_FAST_EARLY_EXIT
 #define SMART_FAST_EARLY_EXIT 1
@@ -280,9 +281,13 @@ __device__ inline int wave_class(const KArgs &a)
     const double dt = a.dt;
     const bool stiff = !(p[6] * 3600.0 >= dt && p[7] * 3600.0 >= dt && p[8] * 3600.0 >= dt && p[9] * 3600.0 >= dt);
     const bool guard = !(p[4] >= 0.0 && p[4] <= 0.5 && p[1] >= 0.0 && p[5] > 0.0);
+    // dt / k > 2: the reference's explicit update multiplies a perturbation by |1 - dt/k| > 1 every step
+    const double half = 0.5 * dt;
+    const bool unstable = !(p[6] * 3600.0 >= half && p[7] * 3600.0 >= half && p[8] * 3600.0 >= half && p[9] * 3600.0 >= half);
     const bool any_stiff = __builtin_amdgcn_ballot_w64(stiff) != 0;
     const bool any_guard = __builtin_amdgcn_ballot_w64(guard) != 0;
-    return any_guard ? 2 : (any_stiff ? 1 : 0);
+    const bool any_unstable = __builtin_amdgcn_ballot_w64(unstable) != 0;
+    return any_unstable ? 3 : (any_guard ? 2 : (any_stiff ? 1 : 0));
 }
 
 __global__ __launch_bounds__(kWave) void smart_ensemble_fast(KArgs a, const double2 *__restrict__ forcing,
@@ -296,8 +301,10 @@ __global__ __launch_bounds__(kWave) void smart_ensemble_fast(KArgs a, const doub
         run_ensemble<FastModel<false, false>, false>(a, forcing, obs, ws, nullptr);
     else if (cls == 1)
         run_ensemble<FastModel<true, false>, false>(a, forcing, obs, ws, nullptr);
-    else
+    else if (cls == 2)
         run_ensemble<FastModel<true, true>, false>(a, forcing, obs, ws, nullptr);
+    else
+        run_ensemble<LiteralModel, false>(a, forcing, obs, ws, nullptr);
 }
 
 void launch_fast(const KArgs &a, dim3 grid, hipStream_t s)

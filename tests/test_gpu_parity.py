@@ -103,7 +103,10 @@ def test_fast_ensemble_vs_reference_exact_oracle(eng, example, report, res, n_da
     assert d <= REL_FAST, d
     assert rel(out.gw.cpu().numpy(), gw) <= 1e-10
     assert rel(out.final_vars.cpu().numpy()[:, 7:], fin[:, 7:], floor=1e-290) <= 1e-8  # states (m3)
-    assert np.all(np.isnan(out.final_vars.cpu().numpy()[:, :7]))
+    # the seven outputs of the last step: not carried by the fast model (NaN); wavefronts that fell back to the
+    # reference's operation order (a row with dt / k > 2) do return them
+    o = out.final_vars.cpu().numpy()[:, :7]
+    assert np.all(np.isnan(o) | (np.abs(o - fin[:, :7]) <= 1e-6 * np.abs(fin[:, :7]) + 1e-300))
 
 
 def test_golden_kat4_and_reference_values(eng, example):
@@ -311,3 +314,83 @@ def test_headline_size_properties(eng, example):
     want = objfn_oracle.objective_matrix(dis, example['flow_obs'], gwo, 0.12667)
     assert rel(obj[rows, :7], want[:, :7]) < 1e-9 and np.array_equal(obj[rows, 7], want[:, 7])
     assert rel(gw[rows], gwo) < 1e-10
+
+
+def _synthetic_forcing(catchment, hourly):
+    """seeded synthetic daily rain / PE, hourly = daily / 24 repeated."""
+    rng = np.random.default_rng(12345 + catchment)
+    days = 3653
+    rain_d = (rng.random(days) < 0.80) * rng.gamma(0.70, 4.57, days)
+    pe_d = np.maximum(0.0, 1.47 * (1 + 0.85 * np.sin(2 * np.pi * ((np.arange(days) % 365.25) - 110) / 365.25)))
+    if hourly:
+        return np.repeat(rain_d / 24, 24), np.repeat(pe_d / 24, 24), rng
+    return rain_d, pe_d, rng
+
+
+def test_config2_daily_1e4_samples(eng, example):
+    """BASELINE config 2: 1e4 LHS samples, daily 10-yr synthetic forcing.  With daily steps the default ranges
+    reach dt / k > 2 (RK < 12 h: 11.6 % of the rows, SK < 12 h: 4.6 %): there the reference's explicit update
+    multiplies any rounding difference by |1 - dt/k| (up to 23) per step, so a re-ordered computation drifts by
+    ~1e-5 from it.  Wavefronts holding such a row therefore run the reference's own operation order inside the
+    fast kernel: their discharge equals the literal kernel's bit for bit."""
+    rain, peva, _ = _synthetic_forcing(0, hourly=False)
+    f = forcing_of(rain, peva)
+    params = lhs_oracle.lhs_params(10000, seed=2718)
+    unstable = (params[:, 6:10] * 3600.0 < 43200.0).any(axis=1)
+    assert 0.1 < unstable.mean() < 0.3
+    out = eng.run_ensemble(params, f, example['area'], 86400.0, 365, 1, extra=example['extra'], want_final=True)
+    lit = eng.run_ensemble(params, f, example['area'], 86400.0, 365, 1, extra=example['extra'], math_mode='literal')
+    assert bits_equal(out.discharge.cpu().numpy(), lit.discharge.cpu().numpy())     # every wave holds such a row
+    dis, gw, fin = so.run_batch(example['area'], 86400.0, 3653, 365, rain, peva, params, example['extra'],
+                                so.REPORT_SUMMARY, 1, pow_mode=so.POW_MUL, sum_mode=so.SUM_GPU, want_final=True)
+    assert bits_equal(out.discharge.cpu().numpy(), dis) and bits_equal(out.gw.cpu().numpy(), gw)
+    assert bits_equal(out.final_vars.cpu().numpy()[:, 7:], fin[:, 7:])
+    ref, gw_ref, _ = so.run_batch(example['area'], 86400.0, 3653, 365, rain, peva, params, example['extra'],
+                                  so.REPORT_SUMMARY, 1)                       # reference-exact (libm pow)
+    got = out.discharge.cpu().numpy()
+    assert rel(got[~unstable], ref[~unstable], floor=1e-300) <= REL_FAST
+    assert rel(got, ref, floor=1e-300) <= 1e-3         # ill-conditioned rows: whatever libm's last bit does to them
+    # the well-conditioned part of the space in the genuinely fast variants (clamps + river rule, 1 < dt/k <= 2)
+    ranges = dict(lhs_oracle.RANGES, SK=(12.0, 240.0), RK=(12.0, 96.0))
+    p2 = lhs_oracle.lhs_params(10000, seed=2718, ranges=ranges)
+    fast = eng.run_ensemble(p2, f, example['area'], 86400.0, 365, 1, extra=example['extra'], want_final=True)
+    d2, g2, f2 = so.run_batch(example['area'], 86400.0, 3653, 365, rain, peva, p2, example['extra'],
+                              so.REPORT_SUMMARY, 1, want_final=True)
+    assert ((p2[:, 9] < 24).mean() > 0.1) and ((p2[:, 6] < 24).mean() > 0.03)          # stiff but stable rows
+    assert rel(fast.discharge.cpu().numpy(), d2, floor=1e-300) <= REL_FAST
+    assert rel(fast.gw.cpu().numpy(), g2) <= 1e-10
+    assert rel(fast.final_vars.cpu().numpy()[:, 7:], f2[:, 7:], floor=1e-290) <= 1e-8
+
+
+def test_config5_catchment_by_sample_batch(eng, example):
+    """BASELINE config 5: 64 synthetic catchments x 1e4 samples each, hourly 10 yr, one launch (grid.y = catchment),
+    objective functions fused, no discharge stored.  Spot-checked against the oracle on 2 catchments x 6 rows, plus
+    the properties: each catchment's block equals its own separate launch bit for bit."""
+    import torch
+    C, N = 64, 10000
+    rng0 = np.random.default_rng(99)
+    areas = np.exp(rng0.uniform(np.log(20e6), np.log(2000e6), C))
+    params = lhs_oracle.lhs_params(N, seed=2718)
+    forc = np.empty((C, 87672, 2))
+    obs = np.empty((C, 3653))
+    for c in range(C):
+        r, p, rng = _synthetic_forcing(c, hourly=True)
+        forc[c, :, 0], forc[c, :, 1] = r, p
+        obs[c] = np.abs(rng.normal(2.0, 1.0, 3653)) * areas[c] / 175.46e6
+        obs[c][rng.random(3653) < 0.12] = np.nan
+    d_forc = torch.from_numpy(forc).cuda()
+    out = eng.run_ensemble(params, d_forc, areas, 3600.0, 8760, 24, extra=example['extra'], obs=obs,
+                           gw_obs=0.12667, want_discharge=False)
+    torch.cuda.synchronize()
+    obj, gw = out.objfn.cpu().numpy(), out.gw.cpu().numpy()
+    assert obj.shape == (C, N, 8) and np.all(np.isfinite(obj)) and np.all((gw >= 0) & (gw <= 1))
+    rows = rng0.choice(N, 6, replace=False)
+    for c in (0, 37):
+        one = eng.run_ensemble(params, d_forc[c], areas[c], 3600.0, 8760, 24, extra=example['extra'], obs=obs[c],
+                               gw_obs=0.12667, want_discharge=False)
+        assert torch.equal(one.objfn, out.objfn[c]) and torch.equal(one.gw, out.gw[c])
+        dis, gwo, _ = so.run_batch(areas[c], 3600.0, 87672, 8760, forc[c, :, 0], forc[c, :, 1], params[rows],
+                                   example['extra'], so.REPORT_SUMMARY, 24)
+        want = objfn_oracle.objective_matrix(dis, obs[c], gwo, 0.12667)
+        assert rel(obj[c][rows, :7], want[:, :7]) < 1e-9 and np.array_equal(obj[c][rows, 7], want[:, 7])
+        assert rel(gw[c][rows], gwo) < 1e-10
