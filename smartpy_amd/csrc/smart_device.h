@@ -108,17 +108,8 @@ __device__ inline double np_pairwise_lds(const double *col, long n)
 #endif
 constexpr int kChunk = SMART_CHUNK;
 
-// Branch class of one step for the whole wavefront, from the per-lane rain excess: 0 = every lane dry,
-// 1 = every lane wet, 2 = mixed.  (All 64 lanes of the one-wave workgroup are always active.)
-__device__ __forceinline__ int wave_step_class(double ex)
-{
-    const unsigned long long wet = __builtin_amdgcn_ballot_w64(ex >= 0.0);
-    return wet == 0ull ? 0 : (wet == ~0ull ? 1 : 2);
-}
-
-// The rain excess and the branch class of the kChunk steps of a chunk are computed together, ahead of the steps:
-// the wet/dry decision of a step is then a scalar compare on a value that has been sitting in an SGPR for a
-// while, instead of a vector compare -> EXEC manipulation -> branch chain on the critical path of every step.
+// The rain excess of the kChunk steps of a chunk is evaluated together, ahead of the steps (independent FMAs that
+// fill issue slots while the first step's dependent chain starts).
 template <class Model, class Body>
 __device__ __forceinline__ void time_loop(const Model &m, const double2 *__restrict__ f, long n, Body &&body)
 {
@@ -135,27 +126,23 @@ __device__ __forceinline__ void time_loop(const Model &m, const double2 *__restr
         for (int j = 0; j < kChunk; ++j)
             nxt[j] = f[pre + j];
         double ex[kChunk];
-        int cls[kChunk];
-#pragma unroll
-        for (int j = 0; j < kChunk; ++j) {
-            ex[j] = m.excess(cur[j].x, cur[j].y);
-            cls[j] = wave_step_class(ex[j]);
-        }
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
-            body(cur[j], ex[j], cls[j]);
+            ex[j] = m.excess(cur[j].x, cur[j].y);
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            body(cur[j], ex[j]);
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
             cur[j] = nxt[j];
     }
     for (long t = n_chunks * kChunk; t < n; ++t) {
         const double2 v = f[t];
-        const double ex = m.excess(v.x, v.y);
-        body(v, ex, wave_step_class(ex));
+        body(v, m.excess(v.x, v.y));
     }
 }
 
-// The launch body.  Model supplies: setup(area, dt, p), set_states(st12), excess(rain, peva), step(rain, peva, ex, cls),
+// The launch body.  Model supplies: setup(area, dt, p), set_states(st12), excess(rain, peva), step(rain, peva, ex, acc, num, den),
 // members q_out, q_in (sum of the five catchment outflows), q_gw (shallow + deep), get_vars(v19).
 //
 // forcing / obs / ws arrive as separate __restrict__ kernel parameters: only then can the compiler prove that
@@ -215,7 +202,8 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
     const double2 *__restrict__ f = forcing + c * a.T;
 
     // ---- warm-up over the first W steps of the same forcing; only the states survive (structure.py:118-121)
-    time_loop(m, f, a.W, [&](const double2 v, const double ex, const int cls) { m.step(v.x, v.y, ex, cls); });
+    double sink0 = 0.0, sink1 = 0.0, sink2 = 0.0; // warm-up: the sums are not needed
+    time_loop(m, f, a.W, [&](const double2 v, const double ex) { m.step(v.x, v.y, ex, sink0, sink1, sink2); });
 
     // ---- the run proper (structure.py:143-146, 181-195)
     const bool summary = a.report_type == 1;
@@ -230,14 +218,12 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
     double A = 0.0, B = 0.0, C1 = 0.0, C2 = 0.0, C3 = 0.0; // objective-function moments
     double acc = 0.0;                    // running sum of the current report interval
     long k = 0, r = 0, len = a.first_len;
-    time_loop(m, f, a.T, [&](const double2 v, const double ex, const int cls) {
-        m.step(v.x, v.y, ex, cls);
+    time_loop(m, f, a.T, [&](const double2 v, const double ex) {
+        // the model adds this step's river outflow / groundwater outflow / total catchment outflow to the three
+        // running sums itself, so that those additions sit in the same basic block as the step's dependent chains
+        m.step(v.x, v.y, ex, acc, num, den);
         if (NP_MEAN)
             lds[k * kWave + lane] = m.q_out;
-        else
-            acc += m.q_out;
-        num += m.q_gw;
-        den += m.q_in;
         if (__builtin_expect(++k == len, 0)) { // end of report interval r (wave-uniform, 1 step in `gap`)
             double val;
             if (summary) {

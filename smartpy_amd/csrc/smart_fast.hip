@@ -25,13 +25,9 @@
 #ifndef SMART_FAST_EARLY_EXIT
 #define SMART_FAST_EARLY_EXIT 1
 #endif
-// Tuning knobs, A/B-measured on MI355X at the headline size (tools/ab_variants.sh, same box, interleaved):
-//   SMART_FAST_EARLY_EXIT 1: 27.0 ms vs 28.5 ms without the wave-uniform early exits;
-//   SMART_FAST_LOOKAHEAD  0: branching on the wave class computed a chunk ahead (separate all-wet / all-dry /
-//                            mixed bodies, no EXEC juggling) doubles the loop body and is 9 % SLOWER (29.6 vs 27.1 ms).
-#ifndef SMART_FAST_LOOKAHEAD
-#define SMART_FAST_LOOKAHEAD 0
-#endif
+// (A/B on MI355X at the headline size, tools/ab_variants.sh: 27.0 ms with the wave-uniform early exits, 28.5 ms
+// without.  Branching on a wave class computed a chunk ahead, with separate all-wet / all-dry / mixed bodies and no
+// EXEC juggling, doubled the loop body and was 9 % slower; it is not kept.)
 
 namespace smart {
 
@@ -237,8 +233,10 @@ struct FastModel {
         }
     }
 
-    // cls: branch class of this step for the whole wavefront (0 all dry, 1 all wet, 2 mixed), known in advance
-    __device__ void step(double /*rain_in*/, double /*peva_in*/, double ex, int cls)
+    // River reservoir, outflow sums and the three running sums of the caller.  Called from inside BOTH branches of
+    // the step: these ~10 instructions are independent of the soil layers, and placed in the same basic block as
+    // the serial fill / evaporation chains they fill the issue slots those chains leave empty.
+    __device__ __forceinline__ void route_and_sum(double &acc, double &num, double &den)
     {
         // outflows of this step are the reservoir states at its start (structure.py:427, :487)
         q_gw = MERGE ? u_sgw : u_sgw + u_dgw;
@@ -254,19 +252,19 @@ struct FastModel {
         }
         u_riv = u_new;
         q_out = q_r;
+        acc += q_r;
+        num += q_gw;
+        den += q_in;
+    }
 
-#if SMART_FAST_LOOKAHEAD
-        if (cls == 1) {
+    __device__ void step(double /*rain_in*/, double /*peva_in*/, double ex, double &acc, double &num, double &den)
+    {
+        if (ex >= 0.0) { // structure.py:359
+            route_and_sum(acc, num, den);
             wet_lanes(ex);
-        } else if (cls == 0) {
+        } else { // :400
+            route_and_sum(acc, num, den);
             dry_lanes(ex);
-        } else
-#endif
-        {
-            if (ex >= 0.0) // structure.py:359
-                wet_lanes(ex);
-            else // :400
-                dry_lanes(ex);
         }
     }
 };

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(kWave) void smart_onestep_literal(long n, const dou
     LiteralModel m;
     m.setup(x[0], x[1], p);
     m.set_states(st);
-    m.step(x[2], x[3], 0.0, 2);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    m.step(x[2], x[3], 0.0, s0, s1, s2);
     double v[19];
     m.get_vars(v);
 #pragma unroll

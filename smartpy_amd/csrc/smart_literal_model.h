@@ -92,7 +92,7 @@ struct LiteralModel {
         return rain_in * pT - peva_in;
     }
 
-    __device__ void step(double rain_in, double peva_in, double /*ex*/, int /*cls*/)
+    __device__ void step(double rain_in, double peva_in, double /*ex*/, double &acc, double &num, double &den)
     {
 #pragma clang fp contract(off)
         const double z = pZ / 6.0; // structure.py:329-337
@@ -206,6 +206,9 @@ struct LiteralModel {
         }
         out[6] = q;
         q_out = q;
+        acc += q;
+        num += q_gw;
+        den += q_in;
     }
 };
 
