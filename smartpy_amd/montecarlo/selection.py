@@ -1,13 +1,28 @@
-"""Conditions on objective functions shared by GLUE and Best (glue.py:222-289, best.py:221-287)."""
+"""Conditions on objective functions shared by GLUE and Best (glue.py:222-289, best.py:221-287).
+
+`condition_mask` and `best_rows` accept numpy arrays (what the file-based second stages of the reference hand them)
+as well as torch tensors on any device: on an `[N, 8]` objective matrix that is still on the GPU the behavioural
+mask, its count and the top-k rows are computed there and only the selected rows travel.
+"""
 import numpy as np
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith('torch')
 
 
 def condition_mask(obj_fns, conditions_val, conditions_typ):
     """Boolean mask of the rows meeting every condition.  obj_fns [N, k]; kinds 'equal', 'min', 'max', 'inside',
     'outside' with the reference's semantics -- including 'outside', written there as
     (value <= lower) & (value >= upper), which no value satisfies."""
-    mask = np.ones((obj_fns.shape[0],), dtype=bool)
-    for obj_fn, values, kind in zip(obj_fns.T, conditions_val, conditions_typ):
+    if _is_torch(obj_fns):
+        import torch
+        mask = torch.ones((obj_fns.shape[0],), dtype=torch.bool, device=obj_fns.device)
+        columns = obj_fns.t()
+    else:
+        mask = np.ones((obj_fns.shape[0],), dtype=bool)
+        columns = obj_fns.T
+    for obj_fn, values, kind in zip(columns, conditions_val, conditions_typ):
         if kind in ('equal', 'min', 'max'):
             if len(values) != 1:
                 raise Exception("The tuple for \"{}\" condition does not contain one and only one element.".format(kind))
@@ -44,3 +59,15 @@ def check_shapes(params, fns, values, kinds, what):
     if not ((fns.shape[1] == len(values)) and (fns.shape[1] == len(kinds))):
         raise Exception('The {} function matrix and the conditions matrices '
                         'do not have compatible dimensions.'.format(what))
+
+
+def best_rows(sort_fn, constrained, nb_best):
+    """Indices (into the unconstrained sample) of the nb_best LARGEST values of sort_fn among the rows where
+    `constrained` is true, in ascending order of the value -- best.py:287 `argsort()[-nb_best:]`."""
+    if _is_torch(sort_fn):
+        import torch
+        idx = torch.nonzero(constrained, as_tuple=False)[:, 0]
+        order = torch.argsort(sort_fn[idx], stable=True)
+        return idx[order][-nb_best:]
+    idx = np.nonzero(constrained)[0]
+    return idx[np.argsort(sort_fn[idx])][-nb_best:]

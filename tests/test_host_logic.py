@@ -175,6 +175,39 @@ def test_glue_and_best_selection_rules():
         Best._get_best_sets(params, fns[:, 2:3], [(1.0,)], ['equal'], fns[:, 0:1], 49)
 
 
+def test_selection_on_tensors_matches_numpy():
+    """The same rules on torch tensors (device-side selection of behavioural / best rows)."""
+    import torch
+    from smartpy_amd.montecarlo.selection import condition_mask, best_rows
+    rng = np.random.default_rng(3)
+    fns = rng.normal(size=(500, 4))
+    vals, kinds = [(0.0,), (-1.0, 0.5), (0.2,), (-0.3, 0.3)], ['min', 'inside', 'max', 'outside']
+    m_np = condition_mask(fns[:, :3], vals[:3], kinds[:3])
+    m_t = condition_mask(torch.from_numpy(fns[:, :3]), vals[:3], kinds[:3])
+    assert isinstance(m_t, torch.Tensor) and np.array_equal(m_t.numpy(), m_np) and 0 < m_np.sum() < 500
+    assert int(condition_mask(torch.from_numpy(fns), vals, kinds).sum()) == 0          # 'outside' never holds
+    b_np = best_rows(fns[:, 3], m_np, 7)
+    b_t = best_rows(torch.from_numpy(fns[:, 3]), m_t, 7)
+    assert np.array_equal(b_t.numpy(), b_np) and np.all(np.diff(fns[b_np, 3]) >= 0)
+    assert set(b_np) == set(np.nonzero(m_np)[0][np.argsort(fns[m_np, 3])][-7:])
+
+
+def test_device_latin_hypercube_is_latin():
+    import torch
+    from smartpy_amd.sampling import latin_hypercube_device
+    from smartpy_amd.parameters import Parameters
+    p = Parameters()
+    x = latin_hypercube_device(1000, p.ranges, seed=5, device='cpu')
+    assert x.shape == (1000, 10) and x.dtype == torch.float64
+    lo = np.array([p.ranges[n][0] for n in p.names])
+    hi = np.array([p.ranges[n][1] for n in p.names])
+    strata = np.floor((x.numpy() - lo) / (hi - lo) * 1000).astype(int)
+    assert all(sorted(np.clip(strata[:, j], 0, 999)) == list(range(1000)) for j in range(10))   # one per stratum
+    assert torch.equal(x, latin_hypercube_device(1000, p.ranges, seed=5, device='cpu'))
+    assert not torch.equal(x, latin_hypercube_device(1000, p.ranges, seed=6, device='cpu'))
+    assert abs(np.corrcoef(x[:, 0].numpy(), x[:, 5].numpy())[0, 1]) < 0.15                      # columns independent
+
+
 # ---- sampling database format (montecarlo.py:123-127, 211-262) ---------------------------------------------------
 class _FakeMC(object):
     """Just enough of MonteCarlo to exercise the writer / reader without a model."""
