@@ -141,8 +141,8 @@ int smart_allsteps_hip(double area_m2, double delta_sec, int64_t length_simu, co
 int smart_onestep_hip(int64_t n, const double *in, double *out);
 
 /*
- * Objective functions of an existing discharge matrix (montecarlo.py:193-209 applied to every sample),
- * two-pass like the spotpy formulas.  Device pointers; asynchronous on stream.
+ * Objective functions of an existing discharge matrix (montecarlo.py:193-209 applied to every sample);
+ * the matrix is read once (moments about the observation mean).  Device pointers; asynchronous on stream.
  *   sim[R][ld] sample-minor (the layout smart_run_ensemble_hip writes), obs[R] (NaN = missing),
  *   gw_sim[N] and gw_obs: pass NULL / NaN to skip the GW column; objfn[N][8].
  */

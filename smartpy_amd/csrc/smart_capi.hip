@@ -88,7 +88,7 @@ __device__ inline void obs_stats(const double *obs, long R, double *st, double *
 
 __global__ __launch_bounds__(256) void smart_obs_prepare(const double *obs, long R, double *ws)
 {
-    __shared__ double sh[256];
+    __shared__ double sh[512];
     __shared__ double st[5];
     const long c = blockIdx.x;
     double *w = ws + c * (kWsHead + R);
@@ -97,57 +97,80 @@ __global__ __launch_bounds__(256) void smart_obs_prepare(const double *obs, long
         w[threadIdx.x] = st[threadIdx.x];
 }
 
-// Objective functions of a stored discharge matrix sim[R][ld] (sample-minor): one lane per sample, two
-// passes over the column like the spotpy formulas (mean first, then deviations).  HBM-bound: 2 * 8 * R
-// bytes per sample, every wavefront load a contiguous 512-byte row segment.
-__global__ __launch_bounds__(256) void smart_objfn_matrix(long N, long R, const double *sim, long ld, const double *obs,
-                                                          const double *gw_sim, double gw_obs, double *objfn)
+// Objective functions of a stored discharge matrix sim[R][ld] (sample-minor).  HBM-bound: the matrix is read
+// exactly once, 8 * R bytes per sample, every wavefront load one contiguous 512-byte row segment, UNROLL of them in
+// flight per lane.  Moments are taken about the observation mean (the same one-pass form as the fused path of the
+// time-loop kernel).  A workgroup is WX wavefronts wide along the samples and WR deep along the report rows:
+//   WX = 4, WR = 1 : one lane walks all rows of its sample (large N: enough wavefronts, 2 KB contiguous per row);
+//   WX = 1, WR = 8 : 8 wavefronts share 64 samples and take the rows round-robin, partial moments are reduced
+//                    through LDS in a fixed order (N ~ 1e5: 8x more wavefronts in flight).
+template <int WX, int WR, int UNROLL>
+__global__ __launch_bounds__(WX *WR *kWave) void smart_objfn_matrix(long N, long R, const double *__restrict__ sim,
+                                                                    long ld, const double *__restrict__ obs,
+                                                                    const double *__restrict__ gw_sim, double gw_obs,
+                                                                    double *__restrict__ objfn)
 {
-    __shared__ double sh[256];
+    __shared__ double sh[512];
     __shared__ double st[5];
-    obs_stats(obs, R, st, nullptr, sh);
+    __shared__ double part[WR > 1 ? WR : 1][5][kWave];
+    obs_stats(obs, R, st, nullptr, sh); // every thread stores the same five values to st
     __syncthreads();
-    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N)
-        return;
-    const double cnt = st[0], ebar = st[1], se = st[2], see = st[3];
-    double ss = 0.0;
-    for (long r = 0; r < R; ++r) {
-        const double e = obs[r];
-        if (e == e)
-            ss += sim[r * ld + n];
-    }
-    const double sbar = ss / cnt;
-    double B = 0.0, A = 0.0, vs = 0.0, cv = 0.0;
-    for (long r = 0; r < R; ++r) {
-        const double e = obs[r];
-        if (e == e) {
-            const double s = sim[r * ld + n];
-            const double d = e - s;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int wx = wave % WX, wr = wave / WX;
+    long n = ((long)blockIdx.x * WX + wx) * kWave + lane;
+    const bool live = n < N;
+    if (!live)
+        n = N - 1;
+    const double ebar = st[1];
+    const double *col = sim + n;
+    double A = 0.0, B = 0.0, C1 = 0.0, C2 = 0.0, C3 = 0.0;
+    auto add = [&](double e, double s) {
+        if (e == e) { // montecarlo.py:195-196
+            const double d = s - e, u = s - ebar;
+            A += d;
             B += d * d;
-            A += s - e;
-            const double u = s - sbar;
-            vs += u * u;
-            cv += (e - ebar) * u;
+            C1 += u;
+            C2 += u * u;
+            C3 += (e - ebar) * u;
+        }
+    };
+    long r = wr;
+    for (; r + (UNROLL - 1) * WR < R; r += UNROLL * WR) { // UNROLL independent row loads in flight
+        double s[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j)
+            s[j] = col[(r + j * WR) * ld];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j)
+            add(obs[r + j * WR], s[j]);
+    }
+    for (; r < R; r += WR)
+        add(obs[r], col[r * ld]);
+    double m[5] = {A, B, C1, C2, C3};
+    if (WR > 1) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            part[wr][k][lane] = m[k];
+        __syncthreads();
+        if (wr != 0)
+            return;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            double t = part[0][k][lane];
+#pragma unroll
+            for (int w = 1; w < WR; ++w)
+                t += part[w][k][lane];
+            m[k] = t;
         }
     }
-    double cc = cv / sqrt(vs * see);
-    cc = fmin(fmax(cc, -1.0), 1.0);
-    const double alpha = sqrt(vs / cnt) / sqrt(see / cnt);
-    const double beta = ss / se;
-    double *o = objfn + n * 8;
-    o[0] = 1.0 - B / see;
-    o[1] = 1.0 - sqrt((cc - 1.0) * (cc - 1.0) + (alpha - 1.0) * (alpha - 1.0) + (beta - 1.0) * (beta - 1.0));
-    o[2] = cc;
-    o[3] = alpha;
-    o[4] = beta;
-    o[5] = 100.0 * (A / se);
-    o[6] = sqrt(B / cnt);
-    if (gw_sim && gw_obs == gw_obs) {
-        const double g = gw_sim[n];
-        o[7] = (gw_obs - 0.1 <= g && g <= gw_obs + 0.1) ? 1.0 : 0.0;
-    } else {
-        o[7] = __builtin_nan("");
+    if (live) {
+        double o[8];
+        finish_objectives(st, m[0], m[1], m[2], m[3], m[4], gw_sim ? gw_sim[n] : 0.0,
+                          gw_sim ? gw_obs : __builtin_nan(""), o);
+        double *op = objfn + n * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            op[k] = o[k];
     }
 }
 
@@ -359,8 +382,14 @@ int smart_objfn_hip(int64_t n_samples, int64_t n_reports, const double *sim, int
     int rc = device_ready();
     if (rc)
         return rc;
-    hipLaunchKernelGGL(smart_objfn_matrix, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (long)n_samples, (long)n_reports, sim, (long)ld, obs, gw_sim, gw_obs, objfn);
+    if (n_samples >= 4 * 65536) // >= 4 wavefronts per SIMD even with one lane per sample
+        hipLaunchKernelGGL((smart_objfn_matrix<4, 1, 8>), dim3((unsigned)((n_samples + 4 * kWave - 1) / (4 * kWave))),
+                           dim3(4 * kWave), 0, (hipStream_t)stream, (long)n_samples, (long)n_reports, sim, (long)ld, obs,
+                           gw_sim, gw_obs, objfn);
+    else
+        hipLaunchKernelGGL((smart_objfn_matrix<1, 8, 4>), dim3((unsigned)((n_samples + kWave - 1) / kWave)),
+                           dim3(8 * kWave), 0, (hipStream_t)stream, (long)n_samples, (long)n_reports, sim, (long)ld, obs,
+                           gw_sim, gw_obs, objfn);
     HIP_TRY(hipGetLastError());
     g_err[0] = 0;
     return SMART_OK;

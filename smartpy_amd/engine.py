@@ -175,7 +175,7 @@ def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report
 
 
 def objective_functions(discharge_report_major, obs, gw_sim=None, gw_obs=None):
-    """montecarlo.py:193-209 for every column of a stored [R, N] discharge matrix (two-pass, HBM-bound)."""
+    """montecarlo.py:193-209 for every column of a stored [R, N] discharge matrix (one pass over it, HBM-bound)."""
     L = _lib.lib()
     sim = discharge_report_major
     if not (isinstance(sim, torch.Tensor) and sim.is_cuda):

@@ -233,7 +233,7 @@ def test_fused_objective_functions_and_g4(eng, example):
         # the stored-matrix kernel (two-pass) agrees as well
         got2 = eng.objective_functions(out.discharge_report_major, example['flow_obs'], out.gw,
                                        float(g['gw_constraint'])).cpu().numpy()
-        assert rel(got2[:, :7], want[:, :7]) < 1e-11
+        assert rel(got2[:, :7], want[:, :7]) < 1e-9
         assert np.array_equal(got2[:, 7], want[:, 7])
     no_gw = eng.run_ensemble(g['params'][:3], f, example['area'], 3600.0, 8760, 24, extra=example['extra'],
                              obs=example['flow_obs'], want_discharge=False)
