@@ -394,3 +394,48 @@ def test_config5_catchment_by_sample_batch(eng, example):
         want = objfn_oracle.objective_matrix(dis, obs[c], gwo, 0.12667)
         assert rel(obj[c][rows, :7], want[:, :7]) < 1e-9 and np.array_equal(obj[c][rows, 7], want[:, 7])
         assert rel(gw[c][rows], gwo) < 1e-10
+
+
+@pytest.mark.parametrize('dt,gap', [(900.0, 96), (1800.0, 48), (3600.0, 6), (300.0, 288), (3600.0, 7)])
+def test_other_step_lengths_and_report_gaps(eng, example, dt, gap):
+    """Sub-hourly steps with daily reports (gap 96, 48), gaps below 8 / not a multiple of 8 / above 128 (where the
+    literal kernel's LDS staging of a report interval does not apply and the mean is sequential): literal bit-exact
+    against the oracle in the same configuration, fast within tolerance of the reference-exact one."""
+    per_hour = int(3600 / dt) if dt < 3600 else 1
+    n_rep = 40
+    T = n_rep * gap
+    hours = -(-T // per_hour)
+    rain = np.repeat(example['rain_hourly'][:hours] / per_hour, per_hour)[:T]
+    peva = np.repeat(example['peva_hourly'][:hours] / per_hour, per_hour)[:T]
+    params = load_golden('kat4_batch.npz')['params']
+    W = 5 * gap
+    lit = eng.run_ensemble(params, forcing_of(rain, peva), example['area'], dt, W, gap, extra=example['extra'],
+                           math_mode='literal', want_final=True)
+    d0, g0, f0 = so.run_batch(example['area'], dt, T, W, rain, peva, params, example['extra'], so.REPORT_SUMMARY, gap,
+                              pow_mode=so.POW_MUL, sum_mode=so.SUM_GPU, want_final=True)
+    assert lit.discharge.shape == (32, n_rep)
+    assert bits_equal(lit.discharge.cpu().numpy(), d0) and bits_equal(lit.gw.cpu().numpy(), g0)
+    assert bits_equal(lit.final_vars.cpu().numpy(), f0)
+    fast = eng.run_ensemble(params, forcing_of(rain, peva), example['area'], dt, W, gap, extra=example['extra'])
+    d1, g1, _ = so.run_batch(example['area'], dt, T, W, rain, peva, params, example['extra'], so.REPORT_SUMMARY, gap)
+    assert rel(fast.discharge.cpu().numpy(), d1) <= REL_FAST and rel(fast.gw.cpu().numpy(), g1) <= 1e-10
+    raw = eng.run_ensemble(params, forcing_of(rain, peva), example['area'], dt, W, gap, extra=example['extra'],
+                           report='raw')
+    d2, g2, _ = so.run_batch(example['area'], dt, T, W, rain, peva, params, example['extra'], so.REPORT_RAW, gap)
+    assert rel(raw.discharge.cpu().numpy(), d2) <= REL_FAST and rel(raw.gw.cpu().numpy(), g2) <= 1e-10
+
+
+def test_tiny_runs(eng, example):
+    """Fewer steps than one forcing chunk, one step, one sample."""
+    p = load_golden('kat4_batch.npz')['params'][:3]
+    for T in (1, 2, 3, 5):
+        f = forcing_of(example['rain_hourly'][100:100 + T], example['peva_hourly'][100:100 + T])
+        for mode, tol in (('literal', 0.0), ('fast', REL_FAST)):
+            out = eng.run_ensemble(p, f, example['area'], 3600.0, 0, 1, extra=example['extra'], math_mode=mode)
+            d, g, _ = so.run_batch(example['area'], 3600.0, T, 0, example['rain_hourly'][100:], example['peva_hourly'][100:],
+                                   p, example['extra'], so.REPORT_SUMMARY, 1, pow_mode=so.POW_MUL, sum_mode=so.SUM_GPU)
+            assert out.discharge.shape == (3, T)
+            if mode == 'literal':
+                assert bits_equal(out.discharge.cpu().numpy(), d)
+            else:
+                assert rel(out.discharge.cpu().numpy(), d) <= tol
