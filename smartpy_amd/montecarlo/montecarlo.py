@@ -148,8 +148,16 @@ class MonteCarlo(object):
         """Simulate every row of the sample and write the sampling database (montecarlo.py:132-177)."""
         n = self._sample.shape[0]
         rank, world = sdist.rank_world()
-        lo, hi = sdist.shard_bounds(n, world, rank)
         n_obj = len(self.obj_fn_names)
+        if n == 0:      # e.g. GLUE with no behavioural set: the reference's sampler loops zero times, header only
+            self.obj_fns, self.gw_contributions = np.empty((0, n_obj)), np.empty(0)
+            if rank == 0:
+                self._init_db()
+                self.database.close()
+                self._compress(compression)
+            sdist.barrier()
+            return
+        lo, hi = sdist.shard_bounds(n, world, rank)
         out = self.model.simulate_ensemble(self._sample[lo:hi] if hi > lo else self._sample[:1],
                                            objective_functions=True, gw_constraint=self.constraints['gw'],
                                            save_discharge=self.save_sim, math_mode=self.math_mode)

@@ -128,3 +128,23 @@ def test_lhs_run_sharded_equals_single_process(tmp_path, save_sim):
         assert np.array_equal(a, np.load(os.path.join(root2, 'objfns_w2_r%d.npy' % r)))
     # the observed series was written next to it (montecarlo.py:88)
     assert os.path.exists(os.path.join(root2, 'out', 'Catchment', 'Catchment.obs.flow'))
+
+
+def test_second_stage_with_no_behavioural_set_writes_header_only(tmp_path):
+    """GLUE on a sampling database with a condition nothing meets: zero simulations, header-only output, like the
+    reference's sampler looping zero times (glue.py:222-289 can return an empty array)."""
+    root = _make_root(str(tmp_path / 'one'))
+    _worker_lhs(0, 1, 0, root, False)
+    from smartpy_amd.montecarlo import GLUE, Best
+    glue = GLUE('Catchment', root, 'csv', 'csv', conditioning={'NSE': ('min', (2.0,))})
+    assert glue.behavioural_params.shape == (0, 10)
+    glue.run()
+    lines = open(os.path.join(root, 'out', 'Catchment', 'Catchment.SMART.glue')).read().split('\n')
+    assert lines[0].startswith('NSE,KGE') and lines[1:] == ['']
+    assert glue.obj_fns.shape == (0, 8)
+    with pytest.raises(Exception, match='higher than the sample size'):
+        Best('Catchment', root, 'csv', 'csv', target='NSE', nb_best=14)
+    with pytest.raises(Exception, match='not recognised'):
+        Best('Catchment', root, 'csv', 'csv', target='nse', nb_best=2)
+    best = Best('Catchment', root, 'csv', 'csv', target='KGE', nb_best=3)
+    assert best.best_params.shape == (3, 10) and best.db_file.endswith('Catchment.SMART.3best')
