@@ -16,7 +16,10 @@ ARCH = 'gfx950'
 # translation unit -> extra flags.  The literal kernels must round every operation separately.
 UNITS = {
     'smart_literal.hip': ['-ffp-contract=off'],
-    'smart_fast.hip': ['-ffp-contract=fast-honor-pragmas'],   # the literal model inside it opts out per function
+    # the literal model inside the fast kernel opts out of contraction per function (pragma); no NaN ever enters the
+    # arithmetic (missing observations are tested on their bit pattern), which spares the sNaN-quieting
+    # `v_max_f64 x, x, x` hipcc otherwise puts in front of fmin / fmax (-1.2 % kernel time, A/B measured)
+    'smart_fast.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
     'smart_capi.hip': [],
 }
 COMMON = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-fno-gpu-rdc', '-Wall']

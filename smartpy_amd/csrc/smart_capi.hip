@@ -60,7 +60,7 @@ __device__ inline void obs_stats(const double *obs, long R, double *st, double *
     double cnt = 0.0, s = 0.0;
     for (long r = threadIdx.x; r < R; r += blockDim.x) {
         const double e = obs[r];
-        if (e == e) {
+        if (!is_nan_bits(e)) {
             cnt += 1.0;
             s += e;
         }
@@ -71,7 +71,7 @@ __device__ inline void obs_stats(const double *obs, long R, double *st, double *
     double s2 = 0.0, s1 = 0.0;
     for (long r = threadIdx.x; r < R; r += blockDim.x) {
         const double e = obs[r];
-        const double d = (e == e) ? e - mean : 0.0;
+        const double d = !is_nan_bits(e) ? e - mean : 0.0;
         s2 += d * d;
         s1 += d;
         if (dev)
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(WX *WR *kWave) void smart_objfn_matrix(long N, long
     const double *col = sim + n;
     double A = 0.0, B = 0.0, C1 = 0.0, C2 = 0.0, C3 = 0.0;
     auto add = [&](double e, double s) {
-        if (e == e) { // montecarlo.py:195-196
+        if (!is_nan_bits(e)) { // montecarlo.py:195-196
             const double d = s - e, u = s - ebar;
             A += d;
             B += d * d;

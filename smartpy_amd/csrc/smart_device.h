@@ -39,6 +39,13 @@ struct KArgs {
 #endif
 
 constexpr int kWave = 64;
+
+// NaN test on the bit pattern (missing observation / absent constraint): survives -fno-honor-nans, and for the
+// wave-uniform values it is applied to it is scalar integer work.
+__device__ __forceinline__ bool is_nan_bits(double x)
+{
+    return (__builtin_bit_cast(unsigned long long, x) & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
+}
 constexpr int kWsHead = 8;
 
 // objective functions from the one-pass moments (montecarlo.py:193-209; formulas of spotpy's nashsutcliffe,
@@ -64,7 +71,7 @@ __device__ inline void finish_objectives(const double *st, double A, double B, d
     o[4] = beta;
     o[5] = 100.0 * (A / se);
     o[6] = sqrt(B * inv_n);
-    if (gw_obs == gw_obs) // objfunctions.py:20-24
+    if (!is_nan_bits(gw_obs)) // objfunctions.py:20-24
         o[7] = (gw_obs - 0.1 <= gw_sim && gw_sim <= gw_obs + 0.1) ? 1.0 : 0.0;
     else
         o[7] = __builtin_nan("");
@@ -246,7 +253,7 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
 #endif
             if (want_obj) {
                 const double e = obs[r];
-                if (e == e) { // not NaN: montecarlo.py:195-196
+                if (!is_nan_bits(e)) { // montecarlo.py:195-196
                     const double d = val - e;
                     const double u = val - ebar;
                     A += d;
