@@ -45,11 +45,8 @@ def init(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        kwargs = {}
-        if use_gpu and (backend or 'nccl') == 'nccl':
-            kwargs['device_id'] = device
-        dist.init_process_group(backend=backend or ('nccl' if use_gpu else 'gloo'), rank=rank, world_size=world,
-                                **kwargs)
+        # lazy communicator creation (no device_id): the first collective binds RCCL to the current device, set above
+        dist.init_process_group(backend=backend or ('nccl' if use_gpu else 'gloo'), rank=rank, world_size=world)
     return rank, world, device
 
 
@@ -71,7 +68,10 @@ def rank_world():
 
 def barrier():
     if is_distributed():
-        dist.barrier()
+        if dist.get_backend() == 'nccl':
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def gather_rows(local, n_rows_total):
