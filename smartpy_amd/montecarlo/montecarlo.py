@@ -10,7 +10,6 @@ The per-sample protocol methods are kept, with the reference's signatures, for c
 """
 import gzip
 import shutil
-from csv import DictReader
 from io import open
 from os import sep, remove, rename
 
@@ -246,10 +245,14 @@ class MonteCarlo(object):
                         np.array(f.variables['ObjFunctions'][:, :], dtype=np.float32))
         opener = (lambda: gzip.open(file_location + '.gz', 'rt', encoding='utf8')) if decompression_csv else \
             (lambda: open(file_location, 'r', encoding='utf8'))
-        obj_fns, params = [], []
+        # columns are looked up by header name like the reference's DictReader; the table itself is parsed in bulk
+        # (a 1e6-row database takes seconds instead of minutes) -- text -> float64 -> float32, as np.array(str) does
         with opener() as f:
-            for row in DictReader(f):
-                obj_fns.append([row[name] for name in obj_fn_names])
-                params.append([row[name] for name in param_names])
-        return np.array(params, dtype=np.float32).reshape(-1, len(param_names)), \
-            np.array(obj_fns, dtype=np.float32).reshape(-1, len(obj_fn_names))
+            header = f.readline().rstrip('\r\n').split(',')
+            try:
+                cols = [header.index(name) for name in list(param_names) + list(obj_fn_names)]
+            except ValueError as e:
+                raise KeyError(str(e))
+            table = np.loadtxt(f, delimiter=',', usecols=cols, dtype=np.float64, ndmin=2)
+        table = table.astype(np.float32).reshape(-1, len(cols))
+        return np.ascontiguousarray(table[:, :len(param_names)]), np.ascontiguousarray(table[:, len(param_names):])
