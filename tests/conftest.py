@@ -29,3 +29,13 @@ def example():
         'rain_hourly': np.repeat(g['rain_daily'] / 24, 24), 'peva_hourly': np.repeat(g['peva_daily'] / 24, 24),
         'area': float(g['area']), 'params': g['params'], 'extra': extra,
     }
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _native_libraries():
+    """Make sure the in-tree HIP library and the oracle are built before any test needs them (no-ops when they are
+    up to date; hipcc cross-compiles without a GPU).  The product itself never builds anything implicitly."""
+    from smartpy_amd import build as hip_build
+    hip_build.build()
+    from oracle import smart_oracle
+    smart_oracle.build()
