@@ -224,6 +224,9 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
     double num_raw = 0.0, den_raw = 0.0; // ... over the reported rows only (raw, structure.py:194-195)
     double A = 0.0, B = 0.0, C1 = 0.0, C2 = 0.0, C3 = 0.0; // objective-function moments
     double acc = 0.0;                    // running sum of the current report interval
+    double q_out_total = 0.0;            // ... and of all of them (models that derive the gw sums from balances)
+    if constexpr (Model::kBalanceSums)
+        m.begin_run();
     long k = 0, r = 0, len = a.first_len;
     time_loop(m, f, a.T, [&](const double2 v, const double ex) {
         // the model adds this step's river outflow / groundwater outflow / total catchment outflow to the three
@@ -266,10 +269,14 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
             ++r;
             k = 0;
             len = a.gap;
+            if (Model::kBalanceSums)
+                q_out_total += acc;
             acc = 0.0;
         }
     });
 
+    if constexpr (Model::kBalanceSums)
+        m.balance_sums(q_out_total, num, den);
     const double gw = summary ? num / den : num_raw / den_raw;
     if (live)
         a.gw[c * a.N + n] = gw;

@@ -25,6 +25,9 @@
 #ifndef SMART_FAST_EARLY_EXIT
 #define SMART_FAST_EARLY_EXIT 1
 #endif
+#ifndef SMART_FAST_BALANCE_SUMS
+#define SMART_FAST_BALANCE_SUMS 1
+#endif
 // (A/B on MI355X at the headline size, tools/ab_variants.sh: 27.0 ms with the wave-uniform early exits, 28.5 ms
 // without.  Branching on a wave class computed a chunk ahead, with separate all-wet / all-dry / mixed bodies and no
 // EXEC juggling, doubled the loop body and was 9 % slower; it is not kept.)
@@ -197,9 +200,12 @@ struct FastModel {
         leak(l4, p5, s1 * 0.2, p2, inf, sh, dp);
         leak(l5, p6, s1 * (1.0 / 6.0), s1, inf, sh, dp);
         if (MERGE) {
+            const double xg = sh + dp;
             u_ove = fma(u_ove, dec_s, (of + df) * cq_s);
             u_int = fma(u_int, dec_f, inf * cq_f);
-            u_sgw = fma(u_sgw, dec_g, (sh + dp) * cq_g);
+            u_sgw = fma(u_sgw, dec_g, xg * cq_g);
+            if (kBalanceSums)
+                xg_sum += xg;
         } else {
             u_ove = clamp(fma(u_ove, dec_s, of * cq_s));
             u_dra = clamp(fma(u_dra, dec_s, df * cq_s));
@@ -253,8 +259,31 @@ struct FastModel {
         u_riv = u_new;
         q_out = q_r;
         acc += q_r;
-        num += q_gw;
-        den += q_in;
+        if (!kBalanceSums) {
+            num += q_gw;
+            den += q_in;
+        }
+    }
+
+    // ---- groundwater ratio without per-step sums (regular merged variant) -------------------------------------
+    // Both sums of structure.py:191 follow from the linear updates themselves:
+    //   river  U' = U + (q_in - U) a_r        =>  sum_t q_in = sum_t U(t) + (U(T) - U(0)) / a_r,  sum_t U(t) = sum of Q_out
+    //   gw     G' = G (1 - a_g) + x cq_g      =>  sum_t G(t) = (G(0) - G(T) + cq_g sum_t x(t)) / a_g
+    // so the step only adds the groundwater inflow on wet steps; num / den are assembled once at the end.
+    static constexpr bool kBalanceSums = SMART_FAST_BALANCE_SUMS && MERGE;
+    double g0, r0, xg_sum;
+
+    __device__ void begin_run()
+    {
+        g0 = u_sgw;
+        r0 = u_riv;
+        xg_sum = 0.0;
+    }
+
+    __device__ void balance_sums(double q_out_total, double &num, double &den) const
+    {
+        num = fma(cq_g, xg_sum, g0 - u_sgw) / (1.0 - dec_g);
+        den = fma(u_riv - r0, inv_a_r, q_out_total);
     }
 
     __device__ void step(double /*rain_in*/, double /*peva_in*/, double ex, double &acc, double &num, double &den)

@@ -18,6 +18,7 @@ namespace smart {
 
 struct LiteralModel {
     static constexpr bool kExactDivide = true;
+    static constexpr bool kBalanceSums = false;
 
     double area, dt;
     double pT, pC, pH, pD, pS, pZ, sk, fk, gk, rk;
