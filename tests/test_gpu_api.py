@@ -164,3 +164,26 @@ def test_smartcpp_module_contract(example):
     assert np.allclose(row, k1['first48'][1], rtol=1e-13, atol=0)
     assert structure.run_one_step(example['area'], 3600.0, example['rain_hourly'][0], example['peva_hourly'][0],
                                   *example['params'], *k1['initial_run'][7:]) == tuple(row)
+
+
+@pytest.mark.parametrize('in_fmt,out_fmt', [('csv', 'csv'), ('netcdf', 'csv'), ('csv', 'netcdf')])
+def test_run_lhs_terminates_like_the_reference_smoke_test(root, in_fmt, out_fmt):
+    """Mirror of the reference's tests/test_run_mc_lhs.py: sample_size=5, save_sim=True, compression=True, for the
+    input / output formats.  Without the optional netCDF4 package the NetCDF variants raise the reference's own
+    message (inout.py:146-147, montecarlo.py:119-121) instead of running."""
+    from smartpy_amd.montecarlo import LHS
+    try:
+        import netCDF4  # noqa: F401
+        have_netcdf = True
+    except ImportError:
+        have_netcdf = False
+    if 'netcdf' in (in_fmt, out_fmt) and not have_netcdf:
+        with pytest.raises(Exception, match="requires the package 'netCDF4'"):
+            LHS(catchment='Catchment', root_f=root, in_format=in_fmt, out_format=out_fmt, sample_size=5, parallel='seq',
+                save_sim=True).run(compression=True)
+        return
+    lhs = LHS(catchment='Catchment', root_f=root, in_format=in_fmt, out_format=out_fmt, sample_size=5, parallel='seq',
+              save_sim=True)
+    lhs.run(compression=True)
+    assert os.path.exists(os.path.join(root, 'out', 'Catchment', 'Catchment.SMART.lhs.gz'))
+    assert lhs.obj_fns.shape == (5, 8) and np.all(np.isfinite(lhs.obj_fns))
