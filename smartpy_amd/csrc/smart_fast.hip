@@ -25,6 +25,9 @@
 #ifndef SMART_FAST_EARLY_EXIT
 #define SMART_FAST_EARLY_EXIT 1
 #endif
+#ifndef SMART_FAST_DRY_EXIT2
+#define SMART_FAST_DRY_EXIT2 1
+#endif
 #ifndef SMART_FAST_BALANCE_SUMS
 #define SMART_FAST_BALANCE_SUMS 1
 #endif
@@ -221,14 +224,21 @@ struct FastModel {
         double d = -ex;
         dry(l0, d, pC);
 #if SMART_FAST_EARLY_EXIT
+        // the demand is met by the top layer for every lane of the wave on 57 % of the dry steps, by the top two on
+        // 77 %, and reaches the bottom on 11 % (64 random LHS rows, synthetic hourly forcing): two exits, then all
         if (__builtin_amdgcn_ballot_w64(d > 0.0) != 0)
 #endif
         {
             dry(l1, d, pC);
-            dry(l2, d, pC);
-            dry(l3, d, pC);
-            dry(l4, d, pC);
-            dry(l5, d, pC);
+#if SMART_FAST_EARLY_EXIT && SMART_FAST_DRY_EXIT2
+            if (__builtin_amdgcn_ballot_w64(d > 0.0) != 0)
+#endif
+            {
+                dry(l2, d, pC);
+                dry(l3, d, pC);
+                dry(l4, d, pC);
+                dry(l5, d, pC);
+            }
         }
         u_ove = clamp(u_ove * dec_s);
         u_int = clamp(u_int * dec_f);
@@ -317,7 +327,10 @@ __device__ inline int wave_class(const KArgs &a)
     return any_unstable ? 3 : (any_guard ? 2 : (any_stiff ? 1 : 0));
 }
 
-__global__ __launch_bounds__(kWave) void smart_ensemble_fast(KArgs a, const double2 *__restrict__ forcing,
+#ifndef SMART_FAST_MIN_WAVES
+#define SMART_FAST_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(kWave, SMART_FAST_MIN_WAVES) void smart_ensemble_fast(KArgs a, const double2 *__restrict__ forcing,
                                                              const double *__restrict__ obs,
                                                              const double *__restrict__ ws)
 {
