@@ -15,10 +15,18 @@
 //   * the clamps V < 0 -> 0 (structure.py:429-450) and the river's 95 % rule (:492-496) can only fire when
 //     k*3600 < dt, and the "leak < level" guards (:383,390,397) only when s' >= 1: each wavefront tests its
 //     own 64 parameter rows once, before the time loop, and takes the STIFF / GUARD instantiation of the
-//     loop only if one of its lanes needs it (a wave-uniform branch outside the loop).
+//     loop only if one of its lanes needs it (a wave-uniform branch outside the loop);
+//   * reservoirs that share a time constant are merged and the two sums behind the groundwater ratio come
+//     from mass balances (MERGE, below) when the caller does not ask for the final state vector;
+//   * a wavefront holding a sample with dt / k > 2, where the reference's own update amplifies rounding
+//     differences, runs the literal model (smart_literal_model.h) instead.
 //
-// Rounding differs from the reference at the 1e-16 level per operation; the recurrence is dissipative, so
-// the discharge stays within ~1e-12 relative of the literal path (gate in tests: 1e-9; contract: 1e-6).
+// Rounding differs from the reference at the 1e-16 level per operation; the recurrence is dissipative (for
+// dt / k <= 2), so the discharge stays within ~1e-12 relative of the literal path (measured 4e-13 over 512 LHS
+// rows x 10 years hourly; gate in tests: 1e-9; contract: 1e-6).
+//
+// Tuning knobs (macros) are kept so that tools/ab_variants.sh can A/B them on one box; the defaults are the
+// measured winners.  Tried and not kept: see DESIGN.md section 4.1.
 #include "smart_device.h"
 #include "smart_literal_model.h"
 
@@ -31,9 +39,6 @@
 #ifndef SMART_FAST_BALANCE_SUMS
 #define SMART_FAST_BALANCE_SUMS 1
 #endif
-// (A/B on MI355X at the headline size, tools/ab_variants.sh: 27.0 ms with the wave-uniform early exits, 28.5 ms
-// without.  Branching on a wave class computed a chunk ahead, with separate all-wet / all-dry / mixed bodies and no
-// EXEC juggling, doubled the loop body and was 9 % slower; it is not kept.)
 
 namespace smart {
 
