@@ -439,3 +439,25 @@ def test_tiny_runs(eng, example):
                 assert bits_equal(out.discharge.cpu().numpy(), d)
             else:
                 assert rel(out.discharge.cpu().numpy(), d) <= tol
+
+
+@pytest.mark.parametrize('n,ld', [(1, 1), (63, 64), (1000, 1000), (4097, 4160), (262144 + 37, 262144 + 64)])
+def test_stored_matrix_objective_functions_geometries(eng, n, ld):
+    """smart_objfn_hip on both workgroup geometries (8 wavefronts per 64 samples below 262,144 samples, one lane per
+    sample above), ragged sizes and a padded leading dimension, against the two-pass numpy restatement."""
+    import torch
+    R = 501
+    rng = np.random.default_rng(n)
+    obs = np.abs(rng.normal(3.0, 1.5, R))
+    obs[rng.random(R) < 0.15] = np.nan
+    g = torch.Generator(device='cuda').manual_seed(n)
+    buf = torch.rand((R, ld), dtype=torch.float64, device='cuda', generator=g) * 6
+    gw = torch.rand(n, dtype=torch.float64, device='cuda', generator=g) * 0.4
+    got = eng.objective_functions(buf[:, :n], obs, gw, 0.12667).cpu().numpy()
+    assert got.shape == (n, 8)
+    cols = np.unique(np.concatenate([[0, n - 1], rng.integers(0, n, 12)]))
+    sim = buf[:, :n].cpu().numpy()
+    want = objfn_oracle.objective_matrix(sim[:, cols].T, obs, gw.cpu().numpy()[cols], 0.12667)
+    assert rel(got[cols, :7], want[:, :7]) < 1e-9 and np.array_equal(got[cols, 7], want[:, 7])
+    no_gw = eng.objective_functions(buf[:, :n], obs).cpu().numpy()
+    assert np.all(np.isnan(no_gw[:, 7])) and np.array_equal(no_gw[:, :7], got[:, :7])
