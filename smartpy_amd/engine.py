@@ -86,9 +86,50 @@ def n_reports(n_steps, gap, report_type):
     return int(_lib.lib().smart_n_reports(n_steps, gap, report_type))
 
 
+_GROUP_CACHE = {}     # (data_ptr, version, N, dt) -> (gather, inverse) | None   (one entry: the last matrix seen)
+
+
+def variant_classes(params, delta_sec):
+    """Which arithmetic variant of the fast kernel a parameter row needs -- the rules of wave_class() in
+    csrc/smart_fast.hip: 0 regular, 1 stiff (some k*3600 < dt: clamps / river rule reachable), 2 guarded
+    (S outside [0, 0.5], C < 0 or Z <= 0), 3 ill-conditioned (some dt / (k*3600) > 2: literal arithmetic)."""
+    k = params[:, 6:10] * 3600.0
+    cls = torch.zeros(params.shape[0], dtype=torch.int64, device=params.device)
+    cls[~(k >= delta_sec).all(dim=1)] = 1
+    cls[~((params[:, 4] >= 0.0) & (params[:, 4] <= 0.5) & (params[:, 1] >= 0.0) & (params[:, 5] > 0.0))] = 2
+    cls[~(k >= 0.5 * delta_sec).all(dim=1)] = 3
+    return cls
+
+
+def _variant_grouping(params, delta_sec):
+    """A wavefront runs ONE variant for its 64 lanes, the most general one any of its rows needs.  To keep a row's
+    arithmetic (and cost) independent of its neighbours, rows are grouped by variant before the launch, each group
+    padded to whole wavefronts with copies of its last row.  Returns (gather [N_run], inverse [N]) or None when the
+    matrix needs no regrouping (one variant only -- always the case for hourly steps with the default ranges)."""
+    key = (params.data_ptr(), params._version, params.shape[0], float(delta_sec))
+    if key in _GROUP_CACHE:
+        return _GROUP_CACHE[key]
+    cls = variant_classes(params, delta_sec)
+    result = None
+    if int(cls.min()) != int(cls.max()):
+        pieces = []
+        for c in range(4):
+            idx = torch.nonzero(cls == c)[:, 0]
+            if idx.numel():
+                pad = (-idx.numel()) % 64
+                pieces.append(torch.cat([idx, idx[-1:].expand(pad)]) if pad else idx)
+        gather = torch.cat(pieces)
+        inverse = torch.empty(params.shape[0], dtype=torch.int64, device=params.device)
+        inverse[gather] = torch.arange(gather.numel(), device=params.device)    # duplicates hold identical results
+        result = (gather, inverse)
+    _GROUP_CACHE.clear()
+    _GROUP_CACHE[key] = result
+    return result
+
+
 def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report='summary', extra=None,
                  initial=None, obs=None, gw_obs=None, math_mode='fast', want_discharge=True, want_objfn=None,
-                 want_final=False, device=None, discharge_out=None):
+                 want_final=False, device=None, discharge_out=None, group_variants=True):
     """One launch of the whole ensemble: the batched form of the spotpy loop over MonteCarlo.simulation /
     objectivefunction (montecarlo.py:153-154,179-209).
 
@@ -144,6 +185,21 @@ def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report
     if gw_obs is not None:
         gw_obs = as_device(np.full(C, gw_obs, dtype=np.float64) if np.ndim(gw_obs) == 0 else gw_obs, device, (C,))
 
+    # rows grouped by arithmetic variant (fast mode, one shared [N, 10] matrix spanning more than one wavefront)
+    grouping = None
+    n_rows = N
+    if group_variants and mmode == MATH_FAST and pstride == 0 and N > 64:
+        grouping = _variant_grouping(params, float(delta_sec))
+        if grouping is not None:
+            gather, inverse = grouping
+            params = params[gather].contiguous()
+            if initial is not None:
+                initial = initial[:, gather].contiguous()
+            N = gather.numel()
+    caller_out = None
+    if grouping is not None and discharge_out is not None:
+        caller_out, discharge_out, want_discharge = discharge_out, None, True
+
     ld = N
     dis = None
     if discharge_out is not None:
@@ -171,6 +227,17 @@ def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report
         e.stream = torch.cuda.current_stream(device).cuda_stream
         _lib.check(L.smart_run_ensemble_hip(ctypes.byref(e)))
     # keep the inputs alive until the launch has been enqueued on the torch stream (it has: the call returned)
+    if grouping is not None:        # back to the caller's row order
+        gw = gw[:, inverse]
+        objfn = None if objfn is None else objfn[:, inverse]
+        fin = None if fin is None else fin[:, inverse]
+        if dis is not None:
+            if caller_out is not None:
+                caller_out[:, :, :n_rows].copy_(torch.index_select(dis, 2, inverse))
+                dis = caller_out
+            else:
+                dis = torch.index_select(dis, 2, inverse)
+        N = n_rows
     return EnsembleResult(dis, gw, objfn, fin, N, squeeze)
 
 
