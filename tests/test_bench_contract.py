@@ -1,0 +1,54 @@
+"""bench.py: the synthetic workload of BASELINE.md section 4 (CPU) and the JSON line of the driver contract (GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_synthetic_forcing_matches_the_survey_figures():
+    """rain mean ~2.5 mm/d with ~20 % dry days (the shipped data: 2.56, 20 %), PE 0.22-2.72 mm/d,
+    wet-step fraction w ~ 0.47."""
+    sys.path.insert(0, ROOT)
+    import bench
+    daily, _ = bench.synthetic_forcing(0, hourly=False)
+    assert daily.shape == (3653, 2)
+    assert abs(daily[:, 0].mean() - 2.54) < 0.05 and abs((daily[:, 0] == 0).mean() - 0.20) < 0.01
+    assert abs(daily[:, 1].min() - 0.22) < 0.01 and abs(daily[:, 1].max() - 2.72) < 0.01
+    hourly, _ = bench.synthetic_forcing(0, hourly=True)
+    assert hourly.shape == (87672, 2) and np.array_equal(hourly[:, 0], np.repeat(daily[:, 0] / 24, 24))
+    w = bench.wet_fraction(hourly, 8760)
+    assert abs(w - 0.473) < 0.002
+    # against a direct count over a T sample
+    T = np.linspace(0.9, 1.1, 2001)
+    f = np.concatenate([hourly[:8760], hourly])[::97]
+    direct = np.mean(f[:, 0][:, None] * T[None, :] - f[:, 1][:, None] >= 0)
+    assert abs(bench.wet_fraction(hourly[::97], 0) - np.mean(hourly[::97, 0][:, None] * T - hourly[::97, 1][:, None] >= 0)) < 2e-3
+    assert 0.4 < direct < 0.55
+    other, _ = bench.synthetic_forcing(5, hourly=False)
+    assert not np.array_equal(other, daily)
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1',
+                                   '--samples', '20000'], cwd=ROOT, stderr=subprocess.DEVNULL).decode()
+    lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['dtype'] == 'f64' and d['vs_baseline'] is None
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['data'] == 'synthetic'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['unit'] == 'TFLOP/s' and r['hbm']['unit'] == 'GB/s'
+    assert abs(d['value'] - 20000 * 96432 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 1e6 and 'sample' in c
+    assert d['value'] > 50 * c['value']          # sanity: the GPU path is orders of magnitude ahead of the host cores
