@@ -480,3 +480,47 @@ def test_stored_matrix_objective_functions_geometries(eng, n, ld):
     assert rel(got[cols, :7], want[:, :7]) < 1e-9 and np.array_equal(got[cols, 7], want[:, 7])
     no_gw = eng.objective_functions(buf[:, :n], obs).cpu().numpy()
     assert np.all(np.isnan(no_gw[:, 7])) and np.array_equal(no_gw[:, :7], got[:, :7])
+
+
+def test_randomized_configurations(eng):
+    """40 seeded random set-ups -- forcing with storms, droughts and exact zeros, areas over two decades, step lengths
+    from 5 min to 1 day, report gaps, warm-up or not, educated guess or not, summary / raw: literal bit-exact against
+    the oracle in its configuration, fast within tolerance of the reference-exact oracle on well-conditioned rows."""
+    rng = np.random.default_rng(20261002)
+    worst_fast = 0.0
+    for case in range(40):
+        dt = float(rng.choice([300.0, 900.0, 3600.0, 10800.0, 86400.0]))
+        gap = int(rng.choice([1, 2, 3, 8, 12, 24, 30]))
+        n_rep = int(rng.integers(5, 60))
+        T = n_rep * gap
+        W = int(rng.integers(0, n_rep // 2 + 1)) * gap if rng.random() < 0.6 else 0
+        scale = dt / 86400.0
+        rain = rng.gamma(0.4, 8.0, T) * (rng.random(T) < rng.uniform(0.2, 0.9)) * scale * rng.choice([1.0, 1.0, 15.0])
+        peva = np.maximum(0.0, rng.normal(1.5, 1.0, T)) * scale
+        peva[rng.random(T) < 0.05] = 0.0
+        area = float(np.exp(rng.uniform(np.log(5e6), np.log(5e9))))
+        n = int(rng.integers(1, 200))
+        params = lhs_oracle.lhs_params(max(n, 2), seed=int(rng.integers(1 << 30)))[:n]
+        extra = {'aar': float(rng.uniform(600, 2500)), 'r-o_ratio': float(rng.uniform(0.2, 0.7)),
+                 'r-o_split': tuple(rng.dirichlet(np.ones(5)))} if rng.random() < 0.7 else None
+        report, rtype = ('summary', so.REPORT_SUMMARY) if rng.random() < 0.7 else ('raw', so.REPORT_RAW)
+        f = forcing_of(rain, peva)
+        lit = eng.run_ensemble(params, f, area, dt, W, gap, report=report, extra=extra, math_mode='literal',
+                               want_final=True)
+        d0, g0, f0 = so.run_batch(area, dt, T, W, rain, peva, params, extra, rtype, gap, pow_mode=so.POW_MUL,
+                                  sum_mode=so.SUM_GPU, want_final=True)
+        tag = 'case %d: dt=%g gap=%d T=%d W=%d n=%d %s extra=%s' % (case, dt, gap, T, W, n, report, extra is not None)
+        assert bits_equal(lit.discharge.cpu().numpy(), d0), tag
+        assert np.array_equal(lit.gw.cpu().numpy(), g0, equal_nan=True), tag
+        assert bits_equal(lit.final_vars.cpu().numpy(), f0), tag
+        fast = eng.run_ensemble(params, f, area, dt, W, gap, report=report, extra=extra)
+        d1, g1, _ = so.run_batch(area, dt, T, W, rain, peva, params, extra, rtype, gap)
+        good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
+        if good.any():
+            e = rel(fast.discharge.cpu().numpy()[good], d1[good], floor=1e-300)
+            worst_fast = max(worst_fast, e)
+            assert e <= REL_FAST, tag
+            gg = fast.gw.cpu().numpy()[good]
+            ok = np.isfinite(g1[good])
+            assert rel(gg[ok], g1[good][ok]) <= 1e-9, tag
+    assert worst_fast < 1e-10
