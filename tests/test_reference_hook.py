@@ -60,3 +60,73 @@ def test_unmodified_reference_runs_through_our_smartcpp(tmp_path, monkeypatch, e
     for i, v in zip(g1['report_index'], g1['expected']):
         assert '%.6e' % discharge[i] == '%.6e' % v
     assert np.array_equal(discharge, load_golden('kat1_hourly.npz')['discharge_summary'])
+
+
+def _write_series(path, header, stamps, values, fmt='%.6e'):
+    with open(path, 'w') as f:
+        f.write('DateTime,%s\n' % header)
+        for s, v in zip(stamps, values):
+            f.write('%s,%s\n' % (s.strftime('%Y-%m-%d %H:%M:%S'), v if isinstance(v, str) else fmt % v))
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_input_pipeline_against_the_reference_on_random_files(tmp_path, monkeypatch, seed):
+    """Random rain / PE files (hourly, 3-hourly or daily stamps at random offsets) and irregular flow files (missing
+    days, '', -99, different clock time), random simulation and report steps: the arrays our readers + resamplers
+    produce must equal the reference's (smart.py:130-143), exceptions included."""
+    rng = np.random.default_rng(1000 + seed)
+    d_data = timedelta(hours=int(rng.choice([1, 3, 24])))
+    d_simu = timedelta(hours=int(rng.choice([1, 2, 3, 6, 12, 24])))
+    d_save = timedelta(hours=24)
+    if d_save.total_seconds() % d_simu.total_seconds():
+        d_simu = timedelta(hours=6)
+    t0 = datetime(2001, 3, 1, int(rng.integers(0, 24)))
+    n_data = int(rng.integers(24 * 40, 24 * 60) * 3600 // d_data.total_seconds())
+    stamps = [t0 + k * d_data for k in range(n_data)]
+    root = tmp_path / 'data'
+    cat = root / 'in' / 'C'
+    os.makedirs(cat)
+    _write_series(cat / 'C.rain', 'rain', stamps, rng.gamma(0.5, 3.0, n_data) * (rng.random(n_data) < 0.6))
+    _write_series(cat / 'C.peva', 'peva', stamps, rng.random(n_data) * 0.3)
+    # daily mean flows at some clock time, with holes
+    f0 = datetime(2001, 2, 20, int(rng.integers(0, 24)))
+    fst, fval = [], []
+    for k in range(90):
+        u = rng.random()
+        if u < 0.08:
+            continue                                    # missing row
+        fst.append(f0 + timedelta(days=k))
+        fval.append('' if u < 0.12 else ('-99' if u < 0.16 else '%.3f' % (rng.random() * 20)))
+    _write_series(cat / 'C.flow', 'flow', fst, fval)
+    start = datetime(2001, 3, 8, int(rng.integers(0, 24))) + timedelta(days=int(rng.integers(0, 5)))
+    end = start + timedelta(days=int(rng.integers(5, 25)))
+
+    for name in [m for m in sys.modules if m == 'smartpy' or m.startswith('smartpy.')] + ['smartcpp']:
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    monkeypatch.syspath_prepend(REF)
+    monkeypatch.setattr(sys, 'dont_write_bytecode', True)
+    smartpy = importlib.import_module('smartpy')
+    import smartpy_amd
+    args = ('C', 50e6, start, end, d_simu, d_save, 0, 'csv', 'csv', str(root) + os.sep)
+    try:
+        try:
+            ref = smartpy.SMART(*args, gauged_area_m2=47e6)
+            ref_err = None
+        except Exception as e:                          # e.g. data not sufficient, time deltas not multiples
+            ref, ref_err = None, e
+        try:
+            ours = smartpy_amd.SMART(*args, gauged_area_m2=47e6)
+            our_err = None
+        except Exception as e:
+            ours, our_err = None, e
+    finally:
+        for name in [m for m in sys.modules if m == 'smartpy' or m.startswith('smartpy.')]:
+            sys.modules.pop(name, None)
+    assert (ref_err is None) == (our_err is None), (ref_err, our_err)
+    if ref_err is not None:
+        assert str(ref_err) == str(our_err) or type(ref_err) is type(our_err)
+        print('both raise:', ref_err)
+        return
+    assert ours.timeseries == ref.timeseries and ours.timeseries_report == ref.timeseries_report
+    assert np.array_equal(ours.nd_rain, ref.nd_rain) and np.array_equal(ours.nd_peva, ref.nd_peva)
+    assert np.array_equal(ours.nd_flow, ref.nd_flow, equal_nan=True)
