@@ -107,6 +107,16 @@ __device__ inline double np_pairwise_lds(const double *col, long n)
     return res;
 }
 
+// Step kinds: a generic step decides wet / dry per lane; StepAllWet is used by the interval loop when every lane of
+// the wavefront is on the wet side for a whole report interval (no compare, no branch).
+struct StepGeneric {};
+struct StepAllWet {};
+
+__device__ __forceinline__ bool same_bits(double x, double y)
+{
+    return __builtin_bit_cast(long long, x) == __builtin_bit_cast(long long, y);
+}
+
 // Walk n time steps of one catchment's forcing.  The forcing of a step is the same for all 64 lanes, so it is
 // fetched with scalar loads into SGPRs: kChunk steps (one 64-byte line) per s_load_dwordx16, and the next chunk is
 // requested before the current one is consumed, so the load latency hides behind kChunk model steps.
@@ -149,8 +159,135 @@ __device__ __forceinline__ void time_loop(const Model &m, const double2 *__restr
     }
 }
 
-// The launch body.  Model supplies: setup(area, dt, p), set_states(st12), excess(rain, peva), step(rain, peva, ex, acc, num, den),
-// members q_out, q_in (sum of the five catchment outflows), q_gw (shallow + deep), get_vars(v19).
+// ---- pieces shared by the two launch bodies below ------------------------------------------------------------
+struct LaneCtx {
+    int lane;
+    long c, n; // catchment, sample (clamped to N - 1 for the lanes of the last wavefront beyond the batch)
+    bool live;
+};
+
+__device__ __forceinline__ LaneCtx lane_ctx(const KArgs &a)
+{
+    LaneCtx x;
+    x.lane = threadIdx.x;
+    x.c = blockIdx.y;
+    x.n = (long)blockIdx.x * kWave + x.lane;
+    x.live = x.n < a.N;
+    if (!x.live)
+        x.n = a.N - 1;
+    return x;
+}
+
+// parameters, derived constants and the initial states of structure.py:97-140 (educated guess / given states)
+template <class Model>
+__device__ __forceinline__ void init_model(const KArgs &a, const LaneCtx &x, Model &m)
+{
+    double p[10];
+    {
+        const double *pp = a.params + x.c * a.pstride_c + x.n * 10;
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+            p[i] = pp[i];
+    }
+    const double area = a.area[x.c];
+    m.setup(area, a.dt, p);
+
+    double st[12];
+    if (a.initial) {
+        const double *ip = a.initial + (x.c * a.N + x.n) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            st[i] = ip[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            st[i] = 0.0;
+        if (a.extra) { // structure.py:100-112 / :125-137, same operation order
+            const double *e = a.extra + x.c * 7;
+            const double ro = e[0] * e[1];
+            st[0] = ro * e[2] / 1000 * area / 8766 * p[6];
+            st[1] = ro * e[3] / 1000 * area / 8766 * p[6];
+            st[2] = ro * e[4] / 1000 * area / 8766 * p[7];
+            st[3] = ro * e[5] / 1000 * area / 8766 * p[8];
+            st[4] = ro * e[6] / 1000 * area / 8766 * p[8];
+            st[11] = ro / 1000 * area / 8766 * p[9];
+        }
+        const double half = (p[5] / 12) / 1000 * area; // structure.py:115-116 / :139-140
+#pragma unroll
+        for (int i = 5; i < 11; ++i)
+            st[i] = half;
+    }
+    m.set_states(st);
+}
+
+// what happens at the end of a report interval: the discharge store and the objective-function moments
+struct Reporter {
+    const double *__restrict__ obs; // this catchment's observations | null
+    const double *__restrict__ ws;  // this catchment's workspace (statistics + e - mean) | null
+    double ebar;
+    bool want_obj;
+    double A = 0.0, B = 0.0, C1 = 0.0, C2 = 0.0, C3 = 0.0;
+
+    __device__ __forceinline__ void init(const KArgs &a, const LaneCtx &x, const double *__restrict__ obs_all,
+                                         const double *__restrict__ ws_all)
+    {
+        want_obj = a.objfn != nullptr;
+        ws = ws_all ? ws_all + x.c * (kWsHead + a.R) : nullptr;
+        obs = obs_all ? obs_all + x.c * a.R : nullptr;
+        ebar = want_obj ? ws[1] : 0.0;
+    }
+
+    __device__ __forceinline__ void emit(const KArgs &a, const LaneCtx &x, long r, double val)
+    {
+        if (a.discharge && x.live)
+#if SMART_NT_STORE
+            __builtin_nontemporal_store(val, &a.discharge[(x.c * a.R + r) * a.ld + x.n]);
+#else
+            a.discharge[(x.c * a.R + r) * a.ld + x.n] = val;
+#endif
+        if (want_obj) {
+            const double e = obs[r];
+            if (!is_nan_bits(e)) { // montecarlo.py:195-196
+                const double d = val - e;
+                const double u = val - ebar;
+                A += d;
+                B += d * d;
+                C1 += u;
+                C2 += u * u;
+                C3 += ws[kWsHead + r] * u;
+            }
+        }
+    }
+};
+
+template <class Model>
+__device__ __forceinline__ void write_results(const KArgs &a, const LaneCtx &x, const Model &m, const Reporter &rep,
+                                              double gw)
+{
+    if (x.live)
+        a.gw[x.c * a.N + x.n] = gw;
+    if (rep.want_obj && x.live) {
+        double o[8];
+        finish_objectives(rep.ws, rep.A, rep.B, rep.C1, rep.C2, rep.C3, gw, a.gw_obs ? a.gw_obs[x.c] : __builtin_nan(""),
+                          o);
+        double *op = a.objfn + (x.c * a.N + x.n) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            op[i] = o[i];
+    }
+    if (a.final_vars && x.live) {
+        double v[19];
+        m.get_vars(v);
+        double *fp = a.final_vars + (x.c * a.N + x.n) * 19;
+#pragma unroll
+        for (int i = 0; i < 19; ++i)
+            fp[i] = v[i];
+    }
+}
+
+// The general launch body.  Model supplies: setup(area, dt, p), set_states(st12), excess(rain, peva),
+// step(rain, peva, ex, acc, num, den), members q_out, q_in (sum of the five catchment outflows), q_gw (shallow +
+// deep), get_vars(v19).
 //
 // forcing / obs / ws arrive as separate __restrict__ kernel parameters: only then can the compiler prove that
 // the discharge stores do not clobber them and fetch the wave-uniform forcing with scalar loads (s_load)
@@ -160,53 +297,10 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
                                              const double *__restrict__ obs_all, const double *__restrict__ ws_all,
                                              double *lds)
 {
-    const int lane = threadIdx.x;
-    const long c = blockIdx.y;
-    long n = (long)blockIdx.x * kWave + lane;
-    const bool live = n < a.N;
-    if (!live)
-        n = a.N - 1;
-
-    double p[10];
-    {
-        const double *pp = a.params + c * a.pstride_c + n * 10;
-#pragma unroll
-        for (int i = 0; i < 10; ++i)
-            p[i] = pp[i];
-    }
-    const double area = a.area[c];
-
+    const LaneCtx x = lane_ctx(a);
     Model m;
-    m.setup(area, a.dt, p);
-
-    double st[12];
-    if (a.initial) {
-        const double *ip = a.initial + (c * a.N + n) * 12;
-#pragma unroll
-        for (int i = 0; i < 12; ++i)
-            st[i] = ip[i];
-    } else {
-#pragma unroll
-        for (int i = 0; i < 12; ++i)
-            st[i] = 0.0;
-        if (a.extra) { // structure.py:100-112 / :125-137, same operation order
-            const double *x = a.extra + c * 7;
-            const double ro = x[0] * x[1];
-            st[0] = ro * x[2] / 1000 * area / 8766 * p[6];
-            st[1] = ro * x[3] / 1000 * area / 8766 * p[6];
-            st[2] = ro * x[4] / 1000 * area / 8766 * p[7];
-            st[3] = ro * x[5] / 1000 * area / 8766 * p[8];
-            st[4] = ro * x[6] / 1000 * area / 8766 * p[8];
-            st[11] = ro / 1000 * area / 8766 * p[9];
-        }
-        const double half = (p[5] / 12) / 1000 * area; // structure.py:115-116 / :139-140
-#pragma unroll
-        for (int i = 5; i < 11; ++i)
-            st[i] = half;
-    }
-    m.set_states(st);
-
-    const double2 *__restrict__ f = forcing + c * a.T;
+    init_model(a, x, m);
+    const double2 *__restrict__ f = forcing + x.c * a.T;
 
     // ---- warm-up over the first W steps of the same forcing; only the states survive (structure.py:118-121)
     double sink0 = 0.0, sink1 = 0.0, sink2 = 0.0; // warm-up: the sums are not needed
@@ -214,15 +308,12 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
 
     // ---- the run proper (structure.py:143-146, 181-195)
     const bool summary = a.report_type == 1;
-    const bool want_obj = a.objfn != nullptr;
-    const double *__restrict__ ws = ws_all ? ws_all + c * (kWsHead + a.R) : nullptr;
-    const double *__restrict__ obs = obs_all ? obs_all + c * a.R : nullptr;
-    const double ebar = want_obj ? ws[1] : 0.0;
     const double inv_gap = 1.0 / (double)a.gap;
+    Reporter rep;
+    rep.init(a, x, obs_all, ws_all);
 
     double num = 0.0, den = 0.0;         // groundwater sums over every step (summary, structure.py:191)
     double num_raw = 0.0, den_raw = 0.0; // ... over the reported rows only (raw, structure.py:194-195)
-    double A = 0.0, B = 0.0, C1 = 0.0, C2 = 0.0, C3 = 0.0; // objective-function moments
     double acc = 0.0;                    // running sum of the current report interval
     double q_out_total = 0.0;            // ... and of all of them (models that derive the gw sums from balances)
     if constexpr (Model::kBalanceSums)
@@ -233,12 +324,12 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
         // running sums itself, so that those additions sit in the same basic block as the step's dependent chains
         m.step(v.x, v.y, ex, acc, num, den);
         if (NP_MEAN)
-            lds[k * kWave + lane] = m.q_out;
+            lds[k * kWave + x.lane] = m.q_out;
         if (__builtin_expect(++k == len, 0)) { // end of report interval r (wave-uniform, 1 step in `gap`)
             double val;
             if (summary) {
                 if (NP_MEAN)
-                    val = np_pairwise_lds(lds + lane, len) / (double)a.gap;
+                    val = np_pairwise_lds(lds + x.lane, len) / (double)a.gap;
                 else
                     val = Model::kExactDivide ? acc / (double)a.gap : acc * inv_gap;
             } else {
@@ -246,26 +337,7 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
                 num_raw += m.q_gw;
                 den_raw += m.q_in;
             }
-            if (a.discharge && live)
-#if SMART_NT_STORE
-                // written once, never re-read by this launch: keep the 2.9 GB stream from evicting the 1.4 MB of
-                // forcing that every wavefront re-reads from L2
-                __builtin_nontemporal_store(val, &a.discharge[(c * a.R + r) * a.ld + n]);
-#else
-                a.discharge[(c * a.R + r) * a.ld + n] = val;
-#endif
-            if (want_obj) {
-                const double e = obs[r];
-                if (!is_nan_bits(e)) { // montecarlo.py:195-196
-                    const double d = val - e;
-                    const double u = val - ebar;
-                    A += d;
-                    B += d * d;
-                    C1 += u;
-                    C2 += u * u;
-                    C3 += ws[kWsHead + r] * u;
-                }
-            }
+            rep.emit(a, x, r, val);
             ++r;
             k = 0;
             len = a.gap;
@@ -277,25 +349,85 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
 
     if constexpr (Model::kBalanceSums)
         m.balance_sums(q_out_total, num, den);
-    const double gw = summary ? num / den : num_raw / den_raw;
-    if (live)
-        a.gw[c * a.N + n] = gw;
-    if (want_obj && live) {
-        double o[8];
-        finish_objectives(ws, A, B, C1, C2, C3, gw, a.gw_obs ? a.gw_obs[c] : __builtin_nan(""), o);
-        double *op = a.objfn + (c * a.N + n) * 8;
+    write_results(a, x, m, rep, summary ? num / den : num_raw / den_raw);
+}
+
+// ---- piecewise-constant forcing ------------------------------------------------------------------------------
+// Is the forcing of every report interval one value repeated `gap` times?  (Hourly steps disaggregated from daily
+// data: timeframe.py:167-186 splits each daily value equally over its 24 steps -- the reference's shipped example,
+// its own regression test and the synthetic benchmark forcing all have this shape.)  Every wavefront answers the
+// question for itself before the time loop: 64 lanes x 4 steps per iteration, bit-pattern compares against the first
+// step of the interval, ~0.1 ms for ten years of hourly steps.
+__device__ __forceinline__ bool forcing_is_piecewise_constant(const double2 *__restrict__ f, long T, long gap)
+{
+    bool same = true;
+    for (long t0 = (long)threadIdx.x * 4; t0 < T; t0 += kWave * 4) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            op[i] = o[i];
+        for (int j = 0; j < 4; ++j) {
+            const long t = t0 + j < T ? t0 + j : T - 1;
+            const double2 v = f[t], h = f[(t / gap) * gap];
+            same = same && same_bits(v.x, h.x) && same_bits(v.y, h.y);
+        }
     }
-    if (a.final_vars && live) {
-        double v[19];
-        m.get_vars(v);
-        double *fp = a.final_vars + (c * a.N + n) * 19;
-#pragma unroll
-        for (int i = 0; i < 19; ++i)
-            fp[i] = v[i];
+    return __builtin_amdgcn_ballot_w64(!same) == 0;
+}
+
+// Launch body for summary reports over piecewise-constant forcing (Model::kIntervals).  The loop runs over report
+// intervals, not steps: one scalar load, one rain-excess evaluation and one wave-uniform wet / dry decision per
+// interval, then
+//   * dry lanes -> Model::dry_interval(): the routing half of the `gap` steps collapses to one 4 x 4 linear map (the
+//                   reservoirs only drain: constant coefficients per sample), the soil half to one subtraction when
+//                   the top layer covers the demand of the whole interval, else to a short loop;
+//   * wet lanes -> `gap` wet steps back to back, no compare and no branch per step.
+template <class Model>
+__device__ __forceinline__ void run_ensemble_intervals(const KArgs &a, const double2 *__restrict__ forcing,
+                                                       const double *__restrict__ obs_all,
+                                                       const double *__restrict__ ws_all)
+{
+    const LaneCtx x = lane_ctx(a);
+    Model m;
+    init_model(a, x, m);
+    m.setup_intervals(a.gap);
+    const double2 *__restrict__ f = forcing + x.c * a.T;
+    const long gap = a.gap;
+
+    // A per-lane if / else: a wavefront whose lanes all fall on one side skips the other (s_cbranch_execz); in a mixed
+    // wavefront each side runs under its lanes' mask.  Either way a lane's arithmetic depends on its own sample only.
+    auto interval = [&](const double2 v, double &acc, double &num, double &den) {
+        const double ex = m.excess(v.x, v.y);
+        if (ex < 0.0) {
+            m.dry_interval(ex, gap, acc);
+        } else {
+            for (long k = 0; k < gap; ++k)
+                m.step(v.x, v.y, ex, acc, num, den, StepAllWet());
+        }
+    };
+
+    // the value of interval i + 1 is requested (scalar load) before interval i is computed
+    const long n_warm = a.W / gap; // summary reports: W % gap == 0 (checked on the host, structure.py:190)
+    double2 nxt = f[0];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (long w = 0; w < n_warm; ++w) { // warm-up (structure.py:118-121)
+        const double2 v = nxt;
+        nxt = f[(w + 1 < n_warm ? w + 1 : 0) * gap];
+        interval(v, s0, s1, s2);
     }
+
+    Reporter rep;
+    rep.init(a, x, obs_all, ws_all);
+    const double inv_gap = 1.0 / (double)gap;
+    double num = 0.0, den = 0.0, q_out_total = 0.0;
+    m.begin_run();
+    for (long r = 0; r < a.R; ++r) {
+        const double2 v = nxt;
+        nxt = f[(r + 1 < a.R ? r + 1 : r) * gap];
+        double acc = 0.0;
+        interval(v, acc, num, den);
+        rep.emit(a, x, r, acc * inv_gap);
+        q_out_total += acc;
+    }
+    m.balance_sums(q_out_total, num, den);
+    write_results(a, x, m, rep, num / den);
 }
 
 } // namespace smart

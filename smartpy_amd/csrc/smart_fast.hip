@@ -36,6 +36,9 @@
 #ifndef SMART_FAST_DRY_EXIT2
 #define SMART_FAST_DRY_EXIT2 1
 #endif
+#ifndef SMART_FAST_INTERVALS
+#define SMART_FAST_INTERVALS 1
+#endif
 #ifndef SMART_FAST_BALANCE_SUMS
 #define SMART_FAST_BALANCE_SUMS 1
 #endif
@@ -311,6 +314,84 @@ struct FastModel {
             dry_lanes(ex);
         }
     }
+
+    __device__ void step(double r, double e, double ex, double &acc, double &num, double &den, StepGeneric)
+    {
+        step(r, e, ex, acc, num, den);
+    }
+
+    // every lane of the wavefront is wet for the whole report interval: no compare, no branch
+    __device__ void step(double, double, double ex, double &acc, double &num, double &den, StepAllWet)
+    {
+        route_and_sum(acc, num, den);
+        wet_lanes(ex);
+    }
+
+    // ---- a whole report interval without rain excess (run_ensemble_intervals) ---------------------------------
+    // While no lane gets inflow the routing half of the model is linear with constant coefficients:
+    //   U_j' = dec_j U_j  (j = quick, inter, groundwater),   U_riv' = (1 - a_r) U_riv + a_r (U_q + U_i + U_g)
+    // so n steps are one map  U_j(n) = P_j U_j,  U_riv(n) = P_r U_riv + sum_j A_j U_j,  and the interval's sum of
+    // river outflows is  B_r U_riv + sum_j B_j U_j.  The eleven coefficients are built once per sample by running
+    // the recurrence itself n times on unit vectors (no closed form: no cancellation when 1 - a_r is close to dec_j).
+    static constexpr bool kIntervals = MERGE && kBalanceSums;
+    double P_q, P_i, P_g, P_r, A_q, A_i, A_g, B_q, B_i, B_g, B_r;
+
+    __device__ void setup_intervals(long n)
+    {
+        const double b = 1.0 - a_r;
+        double pq = 1.0, pi = 1.0, pg = 1.0, pr = 1.0;
+        double aq = 0.0, ai = 0.0, ag = 0.0;
+        double bq = 0.0, bi = 0.0, bg = 0.0, br = 0.0;
+        for (long k = 0; k < n; ++k) {
+            bq += aq; // contribution of U_q(0) to U_riv(k), summed over k
+            bi += ai;
+            bg += ag;
+            br += pr;
+            aq = fma(b, aq, a_r * pq);
+            ai = fma(b, ai, a_r * pi);
+            ag = fma(b, ag, a_r * pg);
+            pr *= b;
+            pq *= dec_s;
+            pi *= dec_f;
+            pg *= dec_g;
+        }
+        P_q = pq, P_i = pi, P_g = pg, P_r = pr;
+        A_q = aq, A_i = ai, A_g = ag;
+        B_q = bq, B_i = bi, B_g = bg, B_r = br;
+    }
+
+    // `n` consecutive dry steps with the same demand d0 = -ex on every one of them; adds the n river outflows to acc
+    __device__ __forceinline__ void dry_interval(double ex, long n, double &acc)
+    {
+        const double d0 = -ex;
+        const double need = d0 * (double)n;
+        // a lane whose top layer covers the demand of the whole interval takes n subtractions in one -- decided per
+        // lane, so that its rounding does not depend on what its neighbours need; the step-by-step cascade runs only
+        // if some lane of the wavefront needs it (its effect on the covered lanes' top layer is then overwritten)
+        const bool covered = l0 >= need;
+        const double l0_jump = l0 - need;
+        if (__builtin_amdgcn_ballot_w64(!covered) != 0) {
+            for (long k = 0; k < n; ++k) {
+                double d = d0;
+                dry(l0, d, pC);
+                if (__builtin_amdgcn_ballot_w64(d > 0.0) != 0) {
+                    dry(l1, d, pC);
+                    if (__builtin_amdgcn_ballot_w64(d > 0.0) != 0) {
+                        dry(l2, d, pC);
+                        dry(l3, d, pC);
+                        dry(l4, d, pC);
+                        dry(l5, d, pC);
+                    }
+                }
+            }
+        }
+        l0 = covered ? l0_jump : l0;
+        acc += fma(B_r, u_riv, fma(B_q, u_ove, fma(B_i, u_int, B_g * u_sgw)));
+        u_riv = fma(P_r, u_riv, fma(A_q, u_ove, fma(A_i, u_int, A_g * u_sgw)));
+        u_ove *= P_q;
+        u_int *= P_i;
+        u_sgw *= P_g;
+    }
 };
 
 // Which instantiation does this wavefront need?  Decided once from its own 64 parameter rows.
@@ -340,8 +421,14 @@ __global__ __launch_bounds__(kWave, SMART_FAST_MIN_WAVES) void smart_ensemble_fa
                                                              const double *__restrict__ ws)
 {
     const int cls = wave_class(a);
-    if (cls == 0 && a.final_vars == nullptr)
-        run_ensemble<FastModel<false, false, true>, false>(a, forcing, obs, ws, nullptr);
+    if (cls == 0 && a.final_vars == nullptr) {
+        using Merged = FastModel<false, false, true>;
+        if (SMART_FAST_INTERVALS && Merged::kIntervals && a.report_type == 1 && a.gap >= 2 &&
+            forcing_is_piecewise_constant(forcing + (long)blockIdx.y * a.T, a.T, a.gap))
+            run_ensemble_intervals<Merged>(a, forcing, obs, ws);
+        else
+            run_ensemble<Merged, false>(a, forcing, obs, ws, nullptr);
+    }
     else if (cls == 0)
         run_ensemble<FastModel<false, false>, false>(a, forcing, obs, ws, nullptr);
     else if (cls == 1)
