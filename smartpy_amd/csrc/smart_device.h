@@ -372,6 +372,39 @@ __device__ __forceinline__ bool forcing_is_piecewise_constant(const double2 *__r
     return __builtin_amdgcn_ballot_w64(!same) == 0;
 }
 
+// Walk the report intervals of a piecewise-constant forcing: one (rain, peva) pair per interval, fetched with scalar
+// loads kGroup intervals ahead (a dry interval takes ~100 cycles, far less than a load's latency).
+#ifndef SMART_IV_GROUP
+#define SMART_IV_GROUP 4
+#endif
+constexpr int kGroup = SMART_IV_GROUP;
+
+template <class Body>
+__device__ __forceinline__ void interval_loop(const double2 *__restrict__ f, long n_iv, long gap, Body &&body)
+{
+    const long n_groups = n_iv / kGroup;
+    double2 cur[kGroup], nxt[kGroup];
+    if (n_groups > 0) {
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j)
+            cur[j] = f[j * gap];
+    }
+    for (long g = 0; g < n_groups; ++g) {
+        const long pre = (g + 1 < n_groups ? g + 1 : g) * kGroup; // last group: harmless re-load of itself
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j)
+            nxt[j] = f[(pre + j) * gap];
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j)
+            body(g * kGroup + j, cur[j]);
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j)
+            cur[j] = nxt[j];
+    }
+    for (long i = n_groups * kGroup; i < n_iv; ++i)
+        body(i, f[i * gap]);
+}
+
 // Launch body for summary reports over piecewise-constant forcing (Model::kIntervals).  The loop runs over report
 // intervals, not steps: one scalar load, one rain-excess evaluation and one wave-uniform wet / dry decision per
 // interval, then
@@ -403,29 +436,21 @@ __device__ __forceinline__ void run_ensemble_intervals(const KArgs &a, const dou
         }
     };
 
-    // the value of interval i + 1 is requested (scalar load) before interval i is computed
-    const long n_warm = a.W / gap; // summary reports: W % gap == 0 (checked on the host, structure.py:190)
-    double2 nxt = f[0];
+    // ---- warm-up (structure.py:118-121): summary reports need W % gap == 0 (checked on the host, structure.py:190)
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (long w = 0; w < n_warm; ++w) { // warm-up (structure.py:118-121)
-        const double2 v = nxt;
-        nxt = f[(w + 1 < n_warm ? w + 1 : 0) * gap];
-        interval(v, s0, s1, s2);
-    }
+    interval_loop(f, a.W / gap, gap, [&](long, const double2 v) { interval(v, s0, s1, s2); });
 
     Reporter rep;
     rep.init(a, x, obs_all, ws_all);
     const double inv_gap = 1.0 / (double)gap;
     double num = 0.0, den = 0.0, q_out_total = 0.0;
     m.begin_run();
-    for (long r = 0; r < a.R; ++r) {
-        const double2 v = nxt;
-        nxt = f[(r + 1 < a.R ? r + 1 : r) * gap];
+    interval_loop(f, a.R, gap, [&](long r, const double2 v) {
         double acc = 0.0;
         interval(v, acc, num, den);
         rep.emit(a, x, r, acc * inv_gap);
         q_out_total += acc;
-    }
+    });
     m.balance_sums(q_out_total, num, den);
     write_results(a, x, m, rep, num / den);
 }
