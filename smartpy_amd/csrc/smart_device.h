@@ -431,8 +431,7 @@ __device__ __forceinline__ void run_ensemble_intervals(const KArgs &a, const dou
         if (ex < 0.0) {
             m.dry_interval(ex, gap, acc);
         } else {
-            for (long k = 0; k < gap; ++k)
-                m.step(v.x, v.y, ex, acc, num, den, StepAllWet());
+            m.wet_interval(ex, gap, acc, num, den);
         }
     };
 
