@@ -61,6 +61,7 @@ struct FastModel {
     double pT, pC, pD, hz, sz, z;
     double dec_s, dec_f, dec_g, cq_s, cq_f, cq_g; // 1 - dt/k and area/1e3/k per routing constant
     double a_r, inv_a_r;                          // dt / rk and its reciprocal
+    double a_s, a_f, a_g, d_cs;                   // dt / k, D * area/1e3/sk (merged wet step)
     double k_s, k_f, k_g, k_r, mm_to_m3;          // only to convert the states back at the end
     // states
     double l0, l1, l2, l3, l4, l5; // soil layers, mm
@@ -90,6 +91,10 @@ struct FastModel {
         cq_f = mm_to_m3 * ik_f;
         cq_g = mm_to_m3 * ik_g;
         a_r = dt / k_r;
+        a_s = dt * ik_s;
+        a_f = dt * ik_f;
+        a_g = dt * ik_g;
+        d_cs = pD * cq_s;
         inv_a_r = k_r / dt;
     }
 
@@ -190,7 +195,8 @@ struct FastModel {
     __device__ __forceinline__ void wet_lanes(double ex)
     {
         if (kLeakBalance) {
-            wet_balance(ex, layer_sum());
+            const double e_h = ex * hz;
+            wet_balance(ex, e_h, e_h * cq_s, layer_sum());
             return;
         }
         const double tot = layer_sum();
@@ -253,26 +259,24 @@ struct FastModel {
         ex = t - l;
     }
 
-    // returns the layer sum after the step
-    __device__ __forceinline__ double wet_balance(double ex, const double tot)
+    // returns the layer sum after the step.  e_h = ex H / Z and e_hc = e_h area/1e3/sk are constant over a wet
+    // interval; the reservoirs are updated as u -= u dt/k; u += x c, both in place (no loop-carried copies).
+    __device__ __forceinline__ double wet_balance(const double ex, const double e_h, const double e_hc, const double tot)
     {
-        const double hp = hz * tot;
         const double s1 = sz * tot;
-        const double of = hp * ex;
-        ex = fma(-hp, ex, ex);
-        const double ex_in = ex;
-        fill3(l0, ex, z);
+        const double ex_in = fma(-e_h, tot, ex); // excess left after the overland share H tot/Z ex (:363-365)
+        double rem = ex_in;
+        fill3(l0, rem, z);
 #if SMART_FAST_EARLY_EXIT
-        if (__builtin_amdgcn_ballot_w64(ex > 0.0) != 0)
+        if (__builtin_amdgcn_ballot_w64(rem > 0.0) != 0)
 #endif
         {
-            fill3(l1, ex, z);
-            fill3(l2, ex, z);
-            fill3(l3, ex, z);
-            fill3(l4, ex, z);
-            fill3(l5, ex, z);
+            fill3(l1, rem, z);
+            fill3(l2, rem, z);
+            fill3(l3, rem, z);
+            fill3(l4, rem, z);
+            fill3(l5, rem, z);
         }
-        const double filled = tot + (ex_in - ex);
         const double p2 = s1 * s1, p3 = p2 * s1, p4 = p2 * p2, p5 = p4 * s1, p6 = p3 * p3;
         l0 = fma(-l0, s1, l0);
         l1 = fma(-l1, p2, l1);
@@ -294,12 +298,17 @@ struct FastModel {
         l4 = fma(-l4, p2, l4);
         l5 = fma(-l5, s1, l5);
         const double after_all = layer_sum();
-        const double xq = fma(pD, ex, of);                       // overland + drain
-        const double inf = fma(-pD, ex, ex) + (filled - after_int); // saturation excess share + interflow leak
+        // what entered the layers is ex_in - rem, so  F - A = (tot - A) + ex_in - rem, and with the (1 - D) share of
+        // the saturation excess `rem` (:376-377) the interflow reservoir receives (tot - A) + ex_in - D rem
+        const double inf = (tot - after_int) + fma(-pD, rem, ex_in);
         const double xg = after_int - after_all;
-        u_ove = fma(u_ove, dec_s, xq * cq_s);
-        u_int = fma(u_int, dec_f, inf * cq_f);
-        u_sgw = fma(u_sgw, dec_g, xg * cq_g);
+        u_ove = fma(-u_ove, a_s, u_ove);
+        u_int = fma(-u_int, a_f, u_int);
+        u_sgw = fma(-u_sgw, a_g, u_sgw);
+        u_ove = fma(e_hc, tot, u_ove);   // overland  H tot/Z ex
+        u_ove = fma(d_cs, rem, u_ove);   // drain     D rem
+        u_int = fma(inf, cq_f, u_int);
+        u_sgw = fma(xg, cq_g, u_sgw);
         if (kBalanceSums)
             xg_sum += xg;
         return after_all;
@@ -309,10 +318,11 @@ struct FastModel {
     __device__ __forceinline__ void wet_interval(double ex, long n, double &acc, double &num, double &den)
     {
         if (kLeakBalance) {
+            const double e_h = ex * hz, e_hc = e_h * cq_s;
             double tot = layer_sum();
             for (long k = 0; k < n; ++k) {
                 route_and_sum(acc, num, den);
-                tot = wet_balance(ex, tot);
+                tot = wet_balance(ex, e_h, e_hc, tot);
             }
         } else {
             for (long k = 0; k < n; ++k) {
