@@ -34,6 +34,8 @@ TRUTH = [1.0, 1.0, 0.20845296027652363, 0.24606006380093334, 0.00012296588050682
 N_DAYS, WARM_DAYS = 3653, 365
 FP64_VALU_PEAK_TFLOPS = 78.6    # 1/2 of the 157.3 TF fp32 vector peak (MI355X_MICROARCH.md chip table)
 HBM_PEAK_GBS = 8000.0           # same table
+N_SIMD = 256 * 4                # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9                # peak engine clock, same table
 
 
 def synthetic_forcing(catchment=0, hourly=True):
@@ -156,11 +158,20 @@ def main():
         bytes_per_step = (0.0 if args.no_discharge else 8.0 / gap * T / (W + T)) \
             + 16.0 / n_local + (80.0 + 64.0 + 8.0) / (W + T)
         kern_s = launch_ms * 1e-3
-        traffic = None
+        traffic = executed = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
         if os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh).get('hbm_bytes_per_launch')
+                pmc = json.load(fh)
+            traffic = pmc.get('hbm_bytes_per_launch')
+            if pmc.get('valu_insts_per_launch') and n_local == 100000 and not args.no_discharge and args.math == 'fast':
+                # executed view: vector-ALU wave-instructions (PMC SQ_INSTS_VALU of the committed profile of this
+                # same command) x 4 issue cycles, over the issue cycles the chip's 1,024 SIMDs have in one launch
+                insts = float(pmc['valu_insts_per_launch'])
+                executed = {'valu_insts_per_launch': insts,
+                            'valu_insts_per_wave_step': insts / (math.ceil(n_local / 64) * (W + T)),
+                            'issue_frac': insts * 4.0 / (N_SIMD * kern_s * CLOCK_HZ),
+                            'source': 'profiles/traffic_latest.json'}
         line = {
             'metric': 'MC sample-timesteps/sec/GPU; 1e5 LHS x hourly 10-yr forcing',
             'value': value, 'unit': 'sample-timesteps/s', 'n_gpus': world, 'steps': args.steps,
@@ -180,6 +191,10 @@ def main():
                 'flops_per_sample_step': flops_per_step, 'kernel': 'smart_ensemble_' + args.math,
                 'launch_ms': launch_ms,
                 'traffic': traffic,
+                'executed': executed,
+                'note': 'achieved = the reference\'s literal operation count F(w) = 105 + 121 w per sample-step '
+                        '(SURVEY.md 8d) x sample-steps / launch time; the kernel executes fewer operations than '
+                        'that count (DESIGN.md 4.1), so frac can exceed 1 -- `executed` is the instruction-issue view',
                 'hbm': {'bound': 'hbm', 'achieved': steps_per_launch * bytes_per_step / kern_s / 1e9,
                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': steps_per_launch * bytes_per_step / kern_s / 1e9 / HBM_PEAK_GBS,

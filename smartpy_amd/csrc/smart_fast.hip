@@ -42,6 +42,9 @@
 #ifndef SMART_FAST_BALANCE_SUMS
 #define SMART_FAST_BALANCE_SUMS 1
 #endif
+#ifndef SMART_FAST_FILL_EXIT2
+#define SMART_FAST_FILL_EXIT2 0
+#endif
 #ifndef SMART_FAST_LEAK_BALANCE
 #define SMART_FAST_LEAK_BALANCE 1
 #endif
@@ -272,10 +275,15 @@ struct FastModel {
 #endif
         {
             fill3(l1, rem, z);
-            fill3(l2, rem, z);
-            fill3(l3, rem, z);
-            fill3(l4, rem, z);
-            fill3(l5, rem, z);
+#if SMART_FAST_EARLY_EXIT && SMART_FAST_FILL_EXIT2
+            if (__builtin_amdgcn_ballot_w64(rem > 0.0) != 0)
+#endif
+            {
+                fill3(l2, rem, z);
+                fill3(l3, rem, z);
+                fill3(l4, rem, z);
+                fill3(l5, rem, z);
+            }
         }
         const double p2 = s1 * s1, p3 = p2 * s1, p4 = p2 * p2, p5 = p4 * s1, p6 = p3 * p3;
         l0 = fma(-l0, s1, l0);
