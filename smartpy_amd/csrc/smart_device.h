@@ -32,7 +32,16 @@ struct KArgs {
     double *gw;         // [C][N]
     double *objfn;      // [C][N][8] | null
     double *final_vars; // [C][N][19] | null
+    // time-sliced launch (n_seg > 1): see "time-sliced launch" below
+    int n_seg = 1;            // workgroups per block of 64 samples, each advancing one slice of the time axis
+    long n_catch = 1;         // C
+    long n_blocks = 0;        // ceil(N / 64), blocks per catchment
+    long seg_blocks = 0;      // C * n_blocks padded to a multiple of 8 (a block's slices stay on one XCD)
+    double *seg_state = nullptr; // [seg_blocks][kSegFields][64] hand-over between a block's consecutive slices
+    int *seg_flag = nullptr;     // [seg_blocks] slices completed; then [C] forcing piecewise constant; then [1] error
 };
+
+constexpr int kSegFields = 20;
 
 #ifndef SMART_NT_STORE
 #define SMART_NT_STORE 0
@@ -166,17 +175,19 @@ struct LaneCtx {
     bool live;
 };
 
-__device__ __forceinline__ LaneCtx lane_ctx(const KArgs &a)
+__device__ __forceinline__ LaneCtx lane_ctx(const KArgs &a, long block, long catchment)
 {
     LaneCtx x;
     x.lane = threadIdx.x;
-    x.c = blockIdx.y;
-    x.n = (long)blockIdx.x * kWave + x.lane;
+    x.c = catchment;
+    x.n = block * kWave + x.lane;
     x.live = x.n < a.N;
     if (!x.live)
         x.n = a.N - 1;
     return x;
 }
+
+__device__ __forceinline__ LaneCtx lane_ctx(const KArgs &a) { return lane_ctx(a, (long)blockIdx.x, (long)blockIdx.y); }
 
 // parameters, derived constants and the initial states of structure.py:97-140 (educated guess / given states)
 template <class Model>
@@ -295,9 +306,9 @@ __device__ __forceinline__ void write_results(const KArgs &a, const LaneCtx &x, 
 template <class Model, bool NP_MEAN>
 __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__restrict__ forcing,
                                              const double *__restrict__ obs_all, const double *__restrict__ ws_all,
-                                             double *lds)
+                                             double *lds, long block, long catchment)
 {
-    const LaneCtx x = lane_ctx(a);
+    const LaneCtx x = lane_ctx(a, block, catchment);
     Model m;
     init_model(a, x, m);
     const double2 *__restrict__ f = forcing + x.c * a.T;
@@ -380,29 +391,60 @@ __device__ __forceinline__ bool forcing_is_piecewise_constant(const double2 *__r
 constexpr int kGroup = SMART_IV_GROUP;
 
 template <class Body>
-__device__ __forceinline__ void interval_loop(const double2 *__restrict__ f, long n_iv, long gap, Body &&body)
+__device__ __forceinline__ void interval_loop(const double2 *__restrict__ f, long i0, long i1, long gap, Body &&body)
 {
-    const long n_groups = n_iv / kGroup;
+    const long n_groups = (i1 - i0) / kGroup;
     double2 cur[kGroup], nxt[kGroup];
     if (n_groups > 0) {
 #pragma unroll
         for (int j = 0; j < kGroup; ++j)
-            cur[j] = f[j * gap];
+            cur[j] = f[(i0 + j) * gap];
     }
     for (long g = 0; g < n_groups; ++g) {
-        const long pre = (g + 1 < n_groups ? g + 1 : g) * kGroup; // last group: harmless re-load of itself
+        const long pre = i0 + (g + 1 < n_groups ? g + 1 : g) * kGroup; // last group: harmless re-load of itself
 #pragma unroll
         for (int j = 0; j < kGroup; ++j)
             nxt[j] = f[(pre + j) * gap];
 #pragma unroll
         for (int j = 0; j < kGroup; ++j)
-            body(g * kGroup + j, cur[j]);
+            body(i0 + g * kGroup + j, cur[j]);
 #pragma unroll
         for (int j = 0; j < kGroup; ++j)
             cur[j] = nxt[j];
     }
-    for (long i = n_groups * kGroup; i < n_iv; ++i)
+    for (long i = i0 + n_groups * kGroup; i < i1; ++i)
         body(i, f[i * gap]);
+}
+
+// ---- time-sliced launch ----------------------------------------------------------------------------------------
+// A block of 64 samples is one wavefront for the whole time axis, so a launch of B blocks on S SIMDs lasts as long as
+// the SIMDs that hold ceil(B / S) of them while the others idle (1e5 samples: 1,563 blocks on 1,024 SIMDs, 539 SIMDs
+// with two).  Here the time axis of every block is cut into n_seg slices and each (block, slice) is its own
+// workgroup, id = slice * seg_blocks + (catchment * n_blocks + block): the hardware hands out workgroups in id order as slots free up, so a
+// SIMD that finishes early simply gets more slices.  Slice s of a block starts from the state slice s - 1 left in
+// `seg_state`; it waits for `seg_flag[block] >= s` (its predecessor has a lower id, so it is already resident or
+// finished -- no deadlock; the wait is bounded anyway).  The arithmetic is that of the unsliced run, bit for bit.
+constexpr long kMaxPolls = 1000000; // x ~3 us: a slice takes ~1 ms
+
+__device__ __forceinline__ void wait_for_slice(const KArgs &a, long slot, int seg)
+{
+    int *flag = a.seg_flag + slot;
+    long polls = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
+        __builtin_amdgcn_s_sleep(100);
+        if (++polls > kMaxPolls) { // never seen; leaves a mark instead of a hung GPU
+            __hip_atomic_store(a.seg_flag + a.seg_blocks + a.n_catch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__device__ __forceinline__ void publish_slice(const KArgs &a, long slot, int seg)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (threadIdx.x == 0)
+        __hip_atomic_store(a.seg_flag + slot, seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Launch body for summary reports over piecewise-constant forcing (Model::kIntervals).  The loop runs over report
@@ -415,9 +457,11 @@ __device__ __forceinline__ void interval_loop(const double2 *__restrict__ f, lon
 template <class Model>
 __device__ __forceinline__ void run_ensemble_intervals(const KArgs &a, const double2 *__restrict__ forcing,
                                                        const double *__restrict__ obs_all,
-                                                       const double *__restrict__ ws_all)
+                                                       const double *__restrict__ ws_all, long block, long catchment,
+                                                       int seg)
 {
-    const LaneCtx x = lane_ctx(a);
+    const LaneCtx x = lane_ctx(a, block, catchment);
+    const long slot = catchment * a.n_blocks + block; // this block's place in seg_state / seg_flag
     Model m;
     init_model(a, x, m);
     m.setup_intervals(a.gap);
@@ -435,23 +479,57 @@ __device__ __forceinline__ void run_ensemble_intervals(const KArgs &a, const dou
         }
     };
 
-    // ---- warm-up (structure.py:118-121): summary reports need W % gap == 0 (checked on the host, structure.py:190)
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    interval_loop(f, a.W / gap, gap, [&](long, const double2 v) { interval(v, s0, s1, s2); });
+    // this workgroup's slice [g0, g1) of the W / gap warm-up intervals followed by the R report intervals
+    // (n_seg == 1: everything).  Summary reports need W % gap == 0 (checked on the host, structure.py:190).
+    const long n_warm = a.W / gap, n_all = n_warm + a.R;
+    const long g0 = n_all * seg / a.n_seg, g1 = n_all * (seg + 1) / a.n_seg;
+    const long wa = g0 < n_warm ? g0 : n_warm, wb = g1 < n_warm ? g1 : n_warm;
+    const long ra = g0 > n_warm ? g0 - n_warm : 0, rb = g1 > n_warm ? g1 - n_warm : 0;
+    const bool last = seg == a.n_seg - 1;
 
     Reporter rep;
     rep.init(a, x, obs_all, ws_all);
-    const double inv_gap = 1.0 / (double)gap;
     double num = 0.0, den = 0.0, q_out_total = 0.0;
-    m.begin_run();
-    interval_loop(f, a.R, gap, [&](long r, const double2 v) {
+    double *hand = a.seg_state + (slot * kSegFields) * kWave + x.lane;
+    if (seg > 0) {
+        wait_for_slice(a, slot, seg);
+        m.load_state(hand, kWave);
+        q_out_total = hand[14 * kWave];
+        rep.A = hand[15 * kWave];
+        rep.B = hand[16 * kWave];
+        rep.C1 = hand[17 * kWave];
+        rep.C2 = hand[18 * kWave];
+        rep.C3 = hand[19 * kWave];
+    }
+
+    // ---- warm-up over the first W steps of the same forcing; only the states survive (structure.py:118-121)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    interval_loop(f, wa, wb, gap, [&](long, const double2 v) { interval(v, s0, s1, s2); });
+
+    // ---- the run proper
+    if (ra == 0 && (rb > 0 || last))
+        m.begin_run();
+    const double inv_gap = 1.0 / (double)gap;
+    interval_loop(f, ra, rb, gap, [&](long r, const double2 v) {
         double acc = 0.0;
         interval(v, acc, num, den);
         rep.emit(a, x, r, acc * inv_gap);
         q_out_total += acc;
     });
-    m.balance_sums(q_out_total, num, den);
-    write_results(a, x, m, rep, num / den);
+
+    if (last) {
+        m.balance_sums(q_out_total, num, den);
+        write_results(a, x, m, rep, num / den);
+    } else {
+        m.save_state(hand, kWave);
+        hand[14 * kWave] = q_out_total;
+        hand[15 * kWave] = rep.A;
+        hand[16 * kWave] = rep.B;
+        hand[17 * kWave] = rep.C1;
+        hand[18 * kWave] = rep.C2;
+        hand[19 * kWave] = rep.C3;
+        publish_slice(a, slot, seg);
+    }
 }
 
 } // namespace smart

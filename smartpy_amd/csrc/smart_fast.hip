@@ -397,6 +397,26 @@ struct FastModel {
         }
     }
 
+    // hand-over between two slices of a time-sliced launch (merged variant: 10 states + 3 balance terms)
+    __device__ void save_state(double *p, int stride) const
+    {
+        const double v[13] = {l0, l1, l2, l3, l4, l5, u_ove, u_int, u_sgw, u_riv, g0, r0, xg_sum};
+#pragma unroll
+        for (int i = 0; i < 13; ++i)
+            p[i * stride] = v[i];
+    }
+
+    __device__ void load_state(const double *p, int stride)
+    {
+        double v[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i)
+            v[i] = p[i * stride];
+        l0 = v[0], l1 = v[1], l2 = v[2], l3 = v[3], l4 = v[4], l5 = v[5];
+        u_ove = v[6], u_int = v[7], u_sgw = v[8], u_riv = v[9];
+        g0 = v[10], r0 = v[11], xg_sum = v[12];
+    }
+
     // ---- groundwater ratio without per-step sums (regular merged variant) -------------------------------------
     // Both sums of structure.py:191 follow from the linear updates themselves:
     //   river  U' = U + (q_in - U) a_r        =>  sum_t q_in = sum_t U(t) + (U(T) - U(0)) / a_r,  sum_t U(t) = sum of Q_out
@@ -502,12 +522,12 @@ struct FastModel {
 };
 
 // Which instantiation does this wavefront need?  Decided once from its own 64 parameter rows.
-__device__ inline int wave_class(const KArgs &a)
+__device__ inline int wave_class(const KArgs &a, long block, long catchment)
 {
-    long n = (long)blockIdx.x * kWave + threadIdx.x;
+    long n = block * kWave + threadIdx.x;
     if (n >= a.N)
         n = a.N - 1;
-    const double *p = a.params + (long)blockIdx.y * a.pstride_c + n * 10;
+    const double *p = a.params + catchment * a.pstride_c + n * 10;
     const double dt = a.dt;
     const bool stiff = !(p[6] * 3600.0 >= dt && p[7] * 3600.0 >= dt && p[8] * 3600.0 >= dt && p[9] * 3600.0 >= dt);
     const bool guard = !(p[4] >= 0.0 && p[4] <= 0.5 && p[1] >= 0.0 && p[5] > 0.0);
@@ -527,28 +547,83 @@ __global__ __launch_bounds__(kWave, SMART_FAST_MIN_WAVES) void smart_ensemble_fa
                                                              const double *__restrict__ obs,
                                                              const double *__restrict__ ws)
 {
-    const int cls = wave_class(a);
+    // time-sliced launch: workgroup id = slice * seg_blocks + catchment * n_blocks + block; only the interval engine
+    // is sliced, every other path runs a block's whole time axis in its slice-0 workgroup
+    long block = blockIdx.x, c = blockIdx.y;
+    int seg = 0;
+    if (a.n_seg > 1) {
+        const long slot = blockIdx.x % a.seg_blocks;
+        seg = (int)(blockIdx.x / a.seg_blocks);
+        if (slot >= a.n_catch * a.n_blocks)
+            return;
+        c = slot / a.n_blocks;
+        block = slot % a.n_blocks;
+    }
+    const int cls = wave_class(a, block, c);
     if (cls == 0 && a.final_vars == nullptr) {
         using Merged = FastModel<false, false, true>;
-        if (SMART_FAST_INTERVALS && Merged::kIntervals && a.report_type == 1 && a.gap >= 2 &&
-            forcing_is_piecewise_constant(forcing + (long)blockIdx.y * a.T, a.T, a.gap))
-            run_ensemble_intervals<Merged>(a, forcing, obs, ws);
-        else
-            run_ensemble<Merged, false>(a, forcing, obs, ws, nullptr);
+        bool intervals = SMART_FAST_INTERVALS && Merged::kIntervals && a.report_type == 1 && a.gap >= 2;
+        if (intervals)
+            intervals = a.n_seg > 1 ? a.seg_flag[a.seg_blocks + c] != 0 // answered once by smart_forcing_scan
+                                    : forcing_is_piecewise_constant(forcing + c * a.T, a.T, a.gap);
+        if (intervals)
+            run_ensemble_intervals<Merged>(a, forcing, obs, ws, block, c, seg);
+        else if (seg == 0)
+            run_ensemble<Merged, false>(a, forcing, obs, ws, nullptr, block, c);
+        return;
     }
-    else if (cls == 0)
-        run_ensemble<FastModel<false, false>, false>(a, forcing, obs, ws, nullptr);
+    if (seg != 0)
+        return;
+    if (cls == 0)
+        run_ensemble<FastModel<false, false>, false>(a, forcing, obs, ws, nullptr, block, c);
     else if (cls == 1)
-        run_ensemble<FastModel<true, false>, false>(a, forcing, obs, ws, nullptr);
+        run_ensemble<FastModel<true, false>, false>(a, forcing, obs, ws, nullptr, block, c);
     else if (cls == 2)
-        run_ensemble<FastModel<true, true>, false>(a, forcing, obs, ws, nullptr);
+        run_ensemble<FastModel<true, true>, false>(a, forcing, obs, ws, nullptr, block, c);
     else
-        run_ensemble<LiteralModel, false>(a, forcing, obs, ws, nullptr);
+        run_ensemble<LiteralModel, false>(a, forcing, obs, ws, nullptr, block, c);
 }
 
-void launch_fast(const KArgs &a, dim3 grid, hipStream_t s)
+__global__ void smart_forcing_scan(const double2 *__restrict__ forcing, long T, long gap, int *out)
 {
-    hipLaunchKernelGGL(smart_ensemble_fast, grid, dim3(kWave), 0, s, a, reinterpret_cast<const double2 *>(a.forcing), a.obs, a.ws);
+    const bool pc = forcing_is_piecewise_constant(forcing + (long)blockIdx.x * T, T, gap);
+    if (threadIdx.x == 0)
+        out[blockIdx.x] = pc ? 1 : 0;
+}
+
+// dynamic LDS that lets exactly `per_cu` workgroups of the ensemble kernel be resident on a CU (0: no such size)
+size_t fast_lds_for_residency(int per_cu)
+{
+    static size_t cache[17] = {};
+    static bool known[17] = {};
+    if (per_cu < 1 || per_cu > 16)
+        return 0;
+    if (!known[per_cu]) {
+        size_t found = 0;
+        for (size_t x = (size_t)(160 * 1024 / per_cu) / 256 * 256; x >= 1024 && x > (size_t)(160 * 1024 / (per_cu + 1)) - 2048; x -= 256) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, smart_ensemble_fast, kWave, x) != hipSuccess)
+                break;
+            if (nb == per_cu) {
+                found = x;
+                break;
+            }
+            if (nb > per_cu)
+                break;
+        }
+        cache[per_cu] = found;
+        known[per_cu] = true;
+    }
+    return cache[per_cu];
+}
+
+void launch_fast(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s)
+{
+    if (a.n_seg > 1)
+        hipLaunchKernelGGL(smart_forcing_scan, dim3((unsigned)a.n_catch), dim3(kWave), 0, s,
+                           reinterpret_cast<const double2 *>(a.forcing), a.T, a.gap, a.seg_flag + a.seg_blocks);
+    hipLaunchKernelGGL(smart_ensemble_fast, grid, dim3(kWave), lds_bytes, s, a,
+                       reinterpret_cast<const double2 *>(a.forcing), a.obs, a.ws);
 }
 
 } // namespace smart

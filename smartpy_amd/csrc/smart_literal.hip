@@ -16,9 +16,9 @@ __global__ __launch_bounds__(kWave) void smart_ensemble_literal(KArgs a, const d
 {
     extern __shared__ double lds[];
     if (a.np_mean)
-        run_ensemble<LiteralModel, true>(a, forcing, obs, ws, lds);
+        run_ensemble<LiteralModel, true>(a, forcing, obs, ws, lds, (long)blockIdx.x, (long)blockIdx.y);
     else
-        run_ensemble<LiteralModel, false>(a, forcing, obs, ws, lds);
+        run_ensemble<LiteralModel, false>(a, forcing, obs, ws, lds, (long)blockIdx.x, (long)blockIdx.y);
 }
 
 // smartcpp.onestep stand-in: n independent single steps (structure.py:200-264)
