@@ -524,3 +524,51 @@ def test_randomized_configurations(eng):
             ok = np.isfinite(g1[good])
             assert rel(gg[ok], g1[good][ok]) <= 1e-9, tag
     assert worst_fast < 1e-10
+
+
+# ------------------------------------------------------------------------------------------------------
+# time-sliced launch (smart_device.h): same arithmetic, different schedule
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n_slices', [2, 5, 16])
+def test_time_sliced_launch_is_bit_identical(eng, example, monkeypatch, n_slices):
+    """SMART_TIME_SLICES forces the slicing that a launch with more blocks than SIMDs takes by itself: slices that cut
+    through the warm-up, three catchments, a ragged last block, missing observations, and blocks of the variants
+    that are not sliced (stiff / guard / literal rows) or whose forcing is not piecewise constant."""
+    rng = np.random.default_rng(21)
+    params = lhs_oracle.lhs_params(333, seed=5)
+    params[70, 9] = 0.4          # RK < 1 h: stiff block
+    params[140, 4] = 0.7         # S > 0.5: guard block
+    T, W = 24 * 300, 24 * 50
+    fs = [forcing_of(example['rain_hourly'][c * 500:c * 500 + T] * (0.6 + 0.5 * c),
+                     example['peva_hourly'][c * 500:c * 500 + T]) for c in range(3)]
+    fs[2] = fs[2].copy()
+    fs[2][1000, 0] += 0.01       # catchment 2: not piecewise constant -> flat loop, slice 0 does everything
+    obs = rng.random((3, T // 24)) * 4
+    obs[rng.random((3, T // 24)) < 0.12] = np.nan
+    kw = dict(extra=example['extra'], obs=obs, gw_obs=[0.1, np.nan, 0.3])
+    monkeypatch.setenv('SMART_TIME_SLICES', '0')
+    plain = eng.run_ensemble(params, np.stack(fs), [60e6, 175.46e6, 900e6], 3600.0, W, 24, **kw)
+    monkeypatch.setenv('SMART_TIME_SLICES', str(n_slices))
+    for _ in range(3):
+        cut = eng.run_ensemble(params, np.stack(fs), [60e6, 175.46e6, 900e6], 3600.0, W, 24, **kw)
+        assert bits_equal(cut.discharge.cpu().numpy(), plain.discharge.cpu().numpy())
+        assert bits_equal(cut.gw.cpu().numpy(), plain.gw.cpu().numpy())
+        assert np.array_equal(cut.objfn.cpu().numpy(), plain.objfn.cpu().numpy(), equal_nan=True)
+    # and against the oracle, for the sliced result itself
+    dis, gwo, _ = so.run_batch(60e6, 3600.0, T, W, fs[0][:, 0], fs[0][:, 1], params[:40], example['extra'],
+                               so.REPORT_SUMMARY, 24)
+    assert rel(cut.discharge[0, :40].cpu().numpy(), dis, floor=1e-300) < REL_FAST
+
+
+def test_time_sliced_launch_by_default_above_one_block_per_simd(eng, example, monkeypatch):
+    """70,000 samples = 1,094 blocks > 1,024 SIMDs: sliced without being asked; equal to the unsliced launch."""
+    import torch
+    monkeypatch.delenv('SMART_TIME_SLICES', raising=False)
+    params = torch.from_numpy(lhs_oracle.lhs_params(70000, seed=8)).cuda()
+    T, W = 24 * 400, 24 * 40
+    f = forcing_of(example['rain_hourly'][:T], example['peva_hourly'][:T])
+    kw = dict(extra=example['extra'], obs=example['flow_obs'][:T // 24], gw_obs=0.12667, want_discharge=False)
+    auto = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, **kw)
+    monkeypatch.setenv('SMART_TIME_SLICES', '0')
+    plain = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, **kw)
+    assert torch.equal(auto.objfn, plain.objfn) and torch.equal(auto.gw, plain.gw)
