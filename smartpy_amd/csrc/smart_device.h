@@ -38,7 +38,7 @@ struct KArgs {
     long n_blocks = 0;        // ceil(N / 64), blocks per catchment
     long seg_blocks = 0;      // C * n_blocks padded to a multiple of 8 (a block's slices stay on one XCD)
     double *seg_state = nullptr; // [seg_blocks][kSegFields][64] hand-over between a block's consecutive slices
-    int *seg_flag = nullptr;     // [seg_blocks] slices completed; then [C] forcing piecewise constant; then [1] error
+    int *seg_flag = nullptr;     // [seg_blocks] slices completed; then [C] forcing NOT piecewise constant; then [1] error
 };
 
 constexpr int kSegFields = 20;

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kWave, SMART_FAST_MIN_WAVES) void smart_ensemble_fa
         using Merged = FastModel<false, false, true>;
         bool intervals = SMART_FAST_INTERVALS && Merged::kIntervals && a.report_type == 1 && a.gap >= 2;
         if (intervals)
-            intervals = a.n_seg > 1 ? a.seg_flag[a.seg_blocks + c] != 0 // answered once by smart_forcing_scan
+            intervals = a.n_seg > 1 ? a.seg_flag[a.seg_blocks + c] == 0 // answered once by smart_forcing_scan
                                     : forcing_is_piecewise_constant(forcing + c * a.T, a.T, a.gap);
         if (intervals)
             run_ensemble_intervals<Merged>(a, forcing, obs, ws, block, c, seg);
@@ -584,11 +584,19 @@ __global__ __launch_bounds__(kWave, SMART_FAST_MIN_WAVES) void smart_ensemble_fa
         run_ensemble<LiteralModel, false>(a, forcing, obs, ws, nullptr, block, c);
 }
 
-__global__ void smart_forcing_scan(const double2 *__restrict__ forcing, long T, long gap, int *out)
+// time-sliced launches: the piecewise-constant question is answered once per catchment, by the whole chip (the
+// slices of a block must agree on it).  not_pc[c] is zeroed by the host; any step that differs from the first step
+// of its report interval sets it.
+__global__ void smart_forcing_scan(const double2 *__restrict__ forcing, long T, long gap, int *not_pc)
 {
-    const bool pc = forcing_is_piecewise_constant(forcing + (long)blockIdx.x * T, T, gap);
-    if (threadIdx.x == 0)
-        out[blockIdx.x] = pc ? 1 : 0;
+    const double2 *__restrict__ f = forcing + (long)blockIdx.y * T;
+    bool same = true;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (long)gridDim.x * blockDim.x) {
+        const double2 v = f[t], h = f[(t / gap) * gap];
+        same = same && same_bits(v.x, h.x) && same_bits(v.y, h.y);
+    }
+    if (__builtin_amdgcn_ballot_w64(!same) != 0 && (threadIdx.x & (kWave - 1)) == 0)
+        __hip_atomic_store(not_pc + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // dynamic LDS that lets exactly `per_cu` workgroups of the ensemble kernel be resident on a CU (0: no such size)
@@ -620,7 +628,7 @@ size_t fast_lds_for_residency(int per_cu)
 void launch_fast(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s)
 {
     if (a.n_seg > 1)
-        hipLaunchKernelGGL(smart_forcing_scan, dim3((unsigned)a.n_catch), dim3(kWave), 0, s,
+        hipLaunchKernelGGL(smart_forcing_scan, dim3(64, (unsigned)a.n_catch), dim3(256), 0, s,
                            reinterpret_cast<const double2 *>(a.forcing), a.T, a.gap, a.seg_flag + a.seg_blocks);
     hipLaunchKernelGGL(smart_ensemble_fast, grid, dim3(kWave), lds_bytes, s, a,
                        reinterpret_cast<const double2 *>(a.forcing), a.obs, a.ws);
