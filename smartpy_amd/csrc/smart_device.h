@@ -447,24 +447,27 @@ __device__ __forceinline__ void publish_slice(const KArgs &a, long slot, int seg
         __hip_atomic_store(a.seg_flag + slot, seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Launch body for summary reports over piecewise-constant forcing (Model::kIntervals).  The loop runs over report
-// intervals, not steps: one scalar load, one rain-excess evaluation and one wave-uniform wet / dry decision per
-// interval, then
+// Launch body of the merged regular variant for summary reports (Model::kIntervals), whole or time-sliced.
+// Piecewise-constant forcing: the loop runs over report intervals, not steps -- one scalar load, one rain-excess
+// evaluation and one wave-uniform wet / dry decision per interval, then
 //   * dry lanes -> Model::dry_interval(): the routing half of the `gap` steps collapses to one 4 x 4 linear map (the
-//                   reservoirs only drain: constant coefficients per sample), the soil half to one subtraction when
-//                   the top layer covers the demand of the whole interval, else to a short loop;
+//                   reservoirs only drain: constant coefficients per sample), the soil half to one evaporation step
+//                   with `gap` times the demand;
 //   * wet lanes -> `gap` wet steps back to back, no compare and no branch per step.
-template <class Model>
-__device__ __forceinline__ void run_ensemble_intervals(const KArgs &a, const double2 *__restrict__ forcing,
-                                                       const double *__restrict__ obs_all,
-                                                       const double *__restrict__ ws_all, long block, long catchment,
-                                                       int seg)
+// Any other forcing: the step loop of run_ensemble(), cut at the same report-interval boundaries.
+template <class Model, bool PIECEWISE>
+__device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double2 *__restrict__ forcing,
+                                                    const double *__restrict__ obs_all,
+                                                    const double *__restrict__ ws_all, long block, long catchment,
+                                                    int seg)
 {
+    constexpr bool piecewise = PIECEWISE; // a template parameter: the two sides share no live value
     const LaneCtx x = lane_ctx(a, block, catchment);
     const long slot = catchment * a.n_blocks + block; // this block's place in seg_state / seg_flag
     Model m;
     init_model(a, x, m);
-    m.setup_intervals(a.gap);
+    if constexpr (piecewise)
+        m.setup_intervals(a.gap);
     const double2 *__restrict__ f = forcing + x.c * a.T;
     const long gap = a.gap;
 
@@ -502,20 +505,39 @@ __device__ __forceinline__ void run_ensemble_intervals(const KArgs &a, const dou
         rep.C3 = hand[19 * kWave];
     }
 
-    // ---- warm-up over the first W steps of the same forcing; only the states survive (structure.py:118-121)
+    // warm-up over the first W steps of the same forcing, only the states survive (structure.py:118-121); then the
+    // run proper.  One branch around both loops: the flat side must not keep the interval coefficients alive.
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    interval_loop(f, wa, wb, gap, [&](long, const double2 v) { interval(v, s0, s1, s2); });
-
-    // ---- the run proper
-    if (ra == 0 && (rb > 0 || last))
-        m.begin_run();
     const double inv_gap = 1.0 / (double)gap;
-    interval_loop(f, ra, rb, gap, [&](long r, const double2 v) {
+    const bool starts_run = ra == 0 && (rb > 0 || last);
+    if constexpr (piecewise) {
+        interval_loop(f, wa, wb, gap, [&](long, const double2 v) { interval(v, s0, s1, s2); });
+        if (starts_run)
+            m.begin_run();
+        interval_loop(f, ra, rb, gap, [&](long r, const double2 v) {
+            double acc = 0.0;
+            interval(v, acc, num, den);
+            rep.emit(a, x, r, acc * inv_gap);
+            q_out_total += acc;
+        });
+    } else {
+        time_loop(m, f + wa * gap, (wb - wa) * gap,
+                  [&](const double2 v, const double ex) { m.step(v.x, v.y, ex, s0, s1, s2); });
+        if (starts_run)
+            m.begin_run();
+        long k = 0, r = ra;
         double acc = 0.0;
-        interval(v, acc, num, den);
-        rep.emit(a, x, r, acc * inv_gap);
-        q_out_total += acc;
-    });
+        time_loop(m, f + ra * gap, (rb - ra) * gap, [&](const double2 v, const double ex) {
+            m.step(v.x, v.y, ex, acc, num, den);
+            if (__builtin_expect(++k == gap, 0)) { // end of report interval r (wave-uniform)
+                rep.emit(a, x, r, acc * inv_gap);
+                ++r;
+                k = 0;
+                q_out_total += acc;
+                acc = 0.0;
+            }
+        });
+    }
 
     if (last) {
         m.balance_sums(q_out_total, num, den);

@@ -461,7 +461,7 @@ struct FastModel {
         wet_lanes(ex);
     }
 
-    // ---- a whole report interval without rain excess (run_ensemble_intervals) ---------------------------------
+    // ---- a whole report interval without rain excess (run_ensemble_merged) ------------------------------------
     // While no lane gets inflow the routing half of the model is linear with constant coefficients:
     //   U_j' = dec_j U_j  (j = quick, inter, groundwater),   U_riv' = (1 - a_r) U_riv + a_r (U_q + U_i + U_g)
     // so n steps are one map  U_j(n) = P_j U_j,  U_riv(n) = P_r U_riv + sum_j A_j U_j,  and the interval's sum of
@@ -562,13 +562,14 @@ __global__ __launch_bounds__(kWave, SMART_FAST_MIN_WAVES) void smart_ensemble_fa
     const int cls = wave_class(a, block, c);
     if (cls == 0 && a.final_vars == nullptr) {
         using Merged = FastModel<false, false, true>;
-        bool intervals = SMART_FAST_INTERVALS && Merged::kIntervals && a.report_type == 1 && a.gap >= 2;
-        if (intervals)
-            intervals = a.n_seg > 1 ? a.seg_flag[a.seg_blocks + c] == 0 // answered once by smart_forcing_scan
-                                    : forcing_is_piecewise_constant(forcing + c * a.T, a.T, a.gap);
-        if (intervals)
-            run_ensemble_intervals<Merged>(a, forcing, obs, ws, block, c, seg);
-        else if (seg == 0)
+        if (SMART_FAST_INTERVALS && Merged::kIntervals && a.report_type == 1 && a.gap >= 2) {
+            const bool piecewise = a.n_seg > 1 ? a.seg_flag[a.seg_blocks + c] == 0 // answered by smart_forcing_scan
+                                               : forcing_is_piecewise_constant(forcing + c * a.T, a.T, a.gap);
+            if (piecewise)
+                run_ensemble_merged<Merged, true>(a, forcing, obs, ws, block, c, seg);
+            else
+                run_ensemble_merged<Merged, false>(a, forcing, obs, ws, block, c, seg);
+        } else if (seg == 0)
             run_ensemble<Merged, false>(a, forcing, obs, ws, nullptr, block, c);
         return;
     }
