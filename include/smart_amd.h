@@ -62,6 +62,7 @@ extern "C" {
                                  /* -- np.reshape raises                         (structure.py:190)     */
 #define SMART_E_NO_DEVICE (-6)   /* no HIP device / HIP runtime error (text in smart_last_error)        */
 #define SMART_E_MODE (-7)        /* unknown math mode                                                   */
+#define SMART_E_IO (-8)          /* a database file could not be opened / written                       */
 
 /*
  * One ensemble launch = the whole per-sample loop that spotpy's sampler drives
@@ -148,6 +149,25 @@ int smart_onestep_hip(int64_t n, const double *in, double *out);
  */
 int smart_objfn_hip(int64_t n_samples, int64_t n_reports, const double *sim, int64_t ld, const double *obs,
                     const double *gw_sim, double gw_obs, double *objfn, void *stream);
+
+/*
+ * Sampling database, CSV flavour -- the rows MonteCarlo.save writes one by one (montecarlo.py:211-231): every value
+ * cast to float32 and printed '%.6e', comma separated, one '\n'-terminated line per sample.  HOST pointers, no
+ * device involved.  Appends n_rows lines of n_cols values (row-major float32 table: objective functions, parameters,
+ * optionally the simulated series -- the caller writes the header line, montecarlo.py:122-127) to `path`.
+ * n_threads <= 0: one per core, at most 16.  Characters identical to Python's '%.6e' % numpy.float32(x).
+ */
+int smart_db_append_rows(const char *path, const float *table, int64_t n_rows, int64_t n_cols, int32_t n_threads);
+
+/*
+ * ... and reading them back: GLUE / Best / Total take their sample from an LHS database (montecarlo.py:233-262,
+ * DictReader + numpy.array(rows, dtype=float32)).  `text` = the file's bytes after the header line, `len` of them;
+ * every line holds n_cols values; the n_use columns listed in `cols` (indices into the header) are parsed
+ * (text -> correctly rounded double -> float32, as numpy does) into out[row][0..n_use).  Returns the number of rows
+ * (<= max_rows) or a negative SMART_E_* code.
+ */
+int64_t smart_db_parse_rows(const char *text, int64_t len, int64_t n_cols, const int32_t *cols, int32_t n_use,
+                            float *out, int64_t max_rows, int32_t n_threads);
 
 /* Device bookkeeping */
 int smart_device_count(void);           /* number of visible HIP devices (0 if none / no driver)      */

@@ -40,6 +40,11 @@ SYMBOLS = {
     'smart_onestep_hip': (ctypes.c_int, [ctypes.c_int64, _dp, _dp]),
     'smart_objfn_hip': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, _dp, ctypes.c_int64, _dp, _dp,
                                        ctypes.c_double, _dp, _dp]),
+    'smart_db_append_rows': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int64,
+                                            ctypes.c_int64, ctypes.c_int32]),
+    'smart_db_parse_rows': (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.POINTER(ctypes.c_int32), ctypes.c_int32,
+                                             ctypes.POINTER(ctypes.c_float), ctypes.c_int64, ctypes.c_int32]),
     'smart_device_count': (ctypes.c_int, []),
     'smart_abi_version': (ctypes.c_int, []),
     'smart_last_error': (ctypes.c_char_p, []),

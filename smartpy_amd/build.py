@@ -21,6 +21,7 @@ UNITS = {
     # `v_max_f64 x, x, x` hipcc otherwise puts in front of fmin / fmax (-1.2 % kernel time, A/B measured)
     'smart_fast.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
     'smart_capi.hip': [],
+    'smart_hostio.cpp': ['-pthread'],      # host only: the sampling-database writer
 }
 COMMON = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-fno-gpu-rdc', '-Wall']
 DEPS = ['smart_device.h', 'smart_literal_model.h', os.path.join('..', '..', 'include', 'smart_amd.h')]
@@ -47,7 +48,7 @@ def build(force=False, verbose=False, extra_flags=(), lib_path=LIB):
     suffix = '' if lib_path == LIB else '.' + os.path.basename(lib_path)
     for unit, flags in UNITS.items():
         src = os.path.join(CSRC, unit)
-        obj = os.path.join(CSRC, unit.replace('.hip', suffix + '.o'))
+        obj = os.path.join(CSRC, os.path.splitext(unit)[0] + suffix + '.o')
         if force or _stale(obj, [src] + deps):
             cmd = [cc] + COMMON + flags + list(extra_flags) + ['-c', src, '-o', obj]
             if verbose:
@@ -55,7 +56,7 @@ def build(force=False, verbose=False, extra_flags=(), lib_path=LIB):
             subprocess.check_call(cmd)
         objs.append(obj)
     if force or _stale(lib_path, objs):
-        cmd = [cc, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', lib_path] + objs
+        cmd = [cc, '-shared', '-fPIC', '-pthread', '--offload-arch=' + ARCH, '-o', lib_path] + objs
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)

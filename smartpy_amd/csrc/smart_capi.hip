@@ -18,7 +18,7 @@ size_t fast_lds_for_residency(int per_cu);
 
 static thread_local char g_err[512] = "";
 
-static int fail(int code, const char *fmt, ...)
+int fail(int code, const char *fmt, ...) // also used by smart_hostio.cpp
 {
     va_list ap;
     va_start(ap, fmt);

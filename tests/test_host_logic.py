@@ -260,6 +260,61 @@ def test_sampling_database_csv_round_trip(tmp_path, save_sim):
     assert np.array_equal(p2, params) and np.array_equal(f2, fns)
 
 
+def test_native_row_writer_prints_what_python_prints(tmp_path):
+    """smart_db_append_rows (the library's host-side writer behind _write_rows) against '%.6e' % numpy.float32(x),
+    character for character: random bit patterns over the whole float32 range, rounding ties, decade boundaries,
+    subnormals, signed zeros, infinities and NaN."""
+    import ctypes
+    import io
+    from smartpy_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(4)
+    bits = rng.integers(0, 2 ** 32, size=(20000, 9), dtype=np.uint64).astype(np.uint32).view(np.float32)
+    special = np.array([1999999.5, 2999999.5, 1000000.5, 9999999.5, 9999999.0, 1e7, 999999.94, 0.1, 1e-5, 1e10,
+                        9.9999995e9, 0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 3.4028235e38], dtype=np.float32)
+    halves = (np.arange(1000003, 1000003 + 7 * 18 * 50, 7, dtype=np.float32) + np.float32(0.5)).reshape(-1, 18)
+    subnormal = np.arange(1, 18 * 40 + 1, dtype=np.uint32).view(np.float32).reshape(-1, 18)
+    for table in (bits, np.stack([special, -special]), halves, subnormal):
+        table = np.ascontiguousarray(table, dtype=np.float32)
+        path = str(tmp_path / 'rows.csv')
+        open(path, 'w').write('header\n')
+        _lib.check(L.smart_db_append_rows(path.encode(), table.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                          table.shape[0], table.shape[1], 3))
+        want = io.StringIO()
+        for row in table:
+            want.write(','.join('%.6e' % x for x in row) + '\n')
+        assert open(path).read() == 'header\n' + want.getvalue()
+    with pytest.raises(_lib.SmartEngineError, match='cannot open'):
+        _lib.check(L.smart_db_append_rows(str(tmp_path / 'no' / 'dir.csv').encode(),
+                                          table.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 1, 18, 0))
+
+
+def test_native_row_parser_reads_what_numpy_reads():
+    """smart_db_parse_rows (behind _get_sampled_sets_from_file) against str -> float64 -> float32, the conversion
+    numpy.array(rows_of_str, dtype=float32) performs in the reference (montecarlo.py:262)."""
+    import ctypes
+    from smartpy_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(9)
+    t = (rng.standard_normal((3000, 12)) * 10.0 ** rng.integers(-20, 20, (3000, 12))).astype(np.float32)
+    t[3, 2], t[4, 5], t[5, 7] = np.nan, np.inf, -np.inf
+    text = ''.join(','.join('%.6e' % x for x in row) + ('\r\n' if i % 7 == 0 else '\n') for i, row in enumerate(t))
+    text = text + '\n'                                   # a trailing empty line is not a row
+    want = np.array([[np.float32(float(c)) for c in ln.split(',')] for ln in text.split()], dtype=np.float32)
+    cols = np.array([11, 0, 4, 4, 7], dtype=np.int32)
+    out = np.full((3001, 5), -1, dtype=np.float32)
+    body = text.encode()
+    n = L.smart_db_parse_rows(body, len(body), 12, cols.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 5,
+                              out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 3001, 3)
+    assert n == 3000 and np.array_equal(out[:n], want[:, cols], equal_nan=True)
+    bad = body.replace(b',', b';', 1)
+    assert L.smart_db_parse_rows(bad, len(bad), 12, cols.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 5,
+                                 out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 3001, 1) < 0
+    assert b'malformed' in L.smart_last_error()
+    assert L.smart_db_parse_rows(body, len(body), 12, cols.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 5,
+                                 out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 10, 1) < 0      # no room
+
+
 # ---- sharding arithmetic -----------------------------------------------------------------------------------------
 def test_shard_bounds_cover_the_rows_exactly():
     from smartpy_amd.distributed import shard_bounds, shard_counts
