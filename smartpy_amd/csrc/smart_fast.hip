@@ -64,7 +64,8 @@ struct FastModel {
     double pT, pC, pD, hz, sz, z;
     double dec_s, dec_f, dec_g, cq_s, cq_f, cq_g; // 1 - dt/k and area/1e3/k per routing constant
     double a_r, inv_a_r;                          // dt / rk and its reciprocal
-    double a_s, a_f, a_g, d_cs;                   // dt / k, D * area/1e3/sk (merged wet step)
+    double a_s, a_f, a_g;                         // dt / k
+    double car_s, car_f, car_g, om_ar;            // merged variant: a_r * area/1e3/k per reservoir, 1 - a_r
     double k_s, k_f, k_g, k_r, mm_to_m3;          // only to convert the states back at the end
     // states
     double l0, l1, l2, l3, l4, l5; // soil layers, mm
@@ -97,18 +98,28 @@ struct FastModel {
         a_s = dt * ik_s;
         a_f = dt * ik_f;
         a_g = dt * ik_g;
-        d_cs = pD * cq_s;
+        car_s = a_r * cq_s;
+        car_f = a_r * cq_f;
+        car_g = a_r * cq_g;
+        om_ar = 1.0 - a_r;
         inv_a_r = k_r / dt;
     }
 
     __device__ void set_states(const double *st)
     {
-        u_ove = MERGE ? (st[0] + st[1]) / k_s : st[0] / k_s;
-        u_dra = MERGE ? 0.0 : st[1] / k_s;
-        u_int = st[2] / k_f;
-        u_sgw = MERGE ? (st[3] + st[4]) / k_g : st[3] / k_g;
-        u_dgw = MERGE ? 0.0 : st[4] / k_g;
         const double m3_to_mm = 1.0 / mm_to_m3;
+        if (MERGE) { // merged reservoirs are carried as volumes in mm: y' = y (1 - dt/k) + x, outflow = y area/1e3/k
+            u_ove = (st[0] + st[1]) * m3_to_mm;
+            u_int = st[2] * m3_to_mm;
+            u_sgw = (st[3] + st[4]) * m3_to_mm;
+            u_dra = u_dgw = 0.0;
+        } else {     // the others as outflows U = V / k
+            u_ove = st[0] / k_s;
+            u_dra = st[1] / k_s;
+            u_int = st[2] / k_f;
+            u_sgw = st[3] / k_g;
+            u_dgw = st[4] / k_g;
+        }
         l0 = st[5] * m3_to_mm;
         l1 = st[6] * m3_to_mm;
         l2 = st[7] * m3_to_mm;
@@ -126,10 +137,10 @@ struct FastModel {
 #pragma unroll
         for (int i = 0; i < 7; ++i)
             v[i] = __builtin_nan("");
-        v[7] = u_ove * k_s;
+        v[7] = MERGE ? u_ove * mm_to_m3 : u_ove * k_s; // (merged: the pair's total; not reachable through the API)
         v[8] = u_dra * k_s;
-        v[9] = u_int * k_f;
-        v[10] = u_sgw * k_g;
+        v[9] = MERGE ? u_int * mm_to_m3 : u_int * k_f;
+        v[10] = MERGE ? u_sgw * mm_to_m3 : u_sgw * k_g;
         v[11] = u_dgw * k_g;
         v[12] = l0 * mm_to_m3;
         v[13] = l1 * mm_to_m3;
@@ -194,12 +205,20 @@ struct FastModel {
 
     __device__ double layer_sum() const { return ((l0 + l1) + (l2 + l3)) + (l4 + l5); }
 
+    // y = y * a + x with the result in y's own register (v_fma_f64, dst = src0).  hipcc prefers v_fmac_f64 into the
+    // register of the dying addend and then pays a v_mov_b64 per loop-carried value at the end of every step.
+    __device__ static void fma_in_place(double &y, double a, double x)
+    {
+        asm("v_fma_f64 %0, %0, %1, %2" : "+v"(y) : "v"(a), "v"(x));
+    }
+
+
     // wet branch of structure.py:359-399 for the lanes that are active
     __device__ __forceinline__ void wet_lanes(double ex)
     {
         if (kLeakBalance) {
-            const double e_h = ex * hz;
-            wet_balance(ex, e_h, e_h * cq_s, layer_sum());
+            double tot = layer_sum();
+            wet_balance(ex, ex * hz, tot);
             return;
         }
         const double tot = layer_sum();
@@ -230,9 +249,9 @@ struct FastModel {
         leak(l5, p6, s1 * (1.0 / 6.0), s1, inf, sh, dp);
         if (MERGE) {
             const double xg = sh + dp;
-            u_ove = fma(u_ove, dec_s, (of + df) * cq_s);
-            u_int = fma(u_int, dec_f, inf * cq_f);
-            u_sgw = fma(u_sgw, dec_g, xg * cq_g);
+            u_ove = fma(u_ove, dec_s, of + df);
+            u_int = fma(u_int, dec_f, inf);
+            u_sgw = fma(u_sgw, dec_g, xg);
             if (kBalanceSums)
                 xg_sum += xg;
         } else {
@@ -262,9 +281,9 @@ struct FastModel {
         ex = t - l;
     }
 
-    // returns the layer sum after the step.  e_h = ex H / Z and e_hc = e_h area/1e3/sk are constant over a wet
-    // interval; the reservoirs are updated as u -= u dt/k; u += x c, both in place (no loop-carried copies).
-    __device__ __forceinline__ double wet_balance(const double ex, const double e_h, const double e_hc, const double tot)
+    // `tot` = layer sum at the start of the step in, at its end out (same register: see fma_in_place).
+    // e_h = ex H / Z is constant over a wet interval.
+    __device__ __forceinline__ void wet_balance(const double ex, const double e_h, double &tot)
     {
         const double s1 = sz * tot;
         const double ex_in = fma(-e_h, tot, ex); // excess left after the overland share H tot/Z ex (:363-365)
@@ -305,32 +324,28 @@ struct FastModel {
         l3 = fma(-l3, p3, l3);
         l4 = fma(-l4, p2, l4);
         l5 = fma(-l5, s1, l5);
-        const double after_all = layer_sum();
         // what entered the layers is ex_in - rem, so  F - A = (tot - A) + ex_in - rem, and with the (1 - D) share of
         // the saturation excess `rem` (:376-377) the interflow reservoir receives (tot - A) + ex_in - D rem
         const double inf = (tot - after_int) + fma(-pD, rem, ex_in);
-        const double xg = after_int - after_all;
-        u_ove = fma(-u_ove, a_s, u_ove);
-        u_int = fma(-u_int, a_f, u_int);
-        u_sgw = fma(-u_sgw, a_g, u_sgw);
-        u_ove = fma(e_hc, tot, u_ove);   // overland  H tot/Z ex
-        u_ove = fma(d_cs, rem, u_ove);   // drain     D rem
-        u_int = fma(inf, cq_f, u_int);
-        u_sgw = fma(xg, cq_g, u_sgw);
+        fma_in_place(u_ove, dec_s, fma(pD, rem, e_h * tot)); // overland H tot/Z ex + drain D rem
+        fma_in_place(u_int, dec_f, inf);
+        const double upper = (l0 + l1) + (l2 + l3), lower = l4 + l5;
+        asm("v_add_f64 %0, %1, %2" : "+v"(tot) : "v"(upper), "v"(lower)); // tot = layer sum after the step, in place
+        const double xg = after_int - tot;
+        fma_in_place(u_sgw, dec_g, xg);
         if (kBalanceSums)
             xg_sum += xg;
-        return after_all;
     }
 
     // `n` wet steps with the same rain excess: the layer sum is handed from step to step
     __device__ __forceinline__ void wet_interval(double ex, long n, double &acc, double &num, double &den)
     {
         if (kLeakBalance) {
-            const double e_h = ex * hz, e_hc = e_h * cq_s;
+            const double e_h = ex * hz;
             double tot = layer_sum();
             for (long k = 0; k < n; ++k) {
                 route_and_sum(acc, num, den);
-                tot = wet_balance(ex, e_h, e_hc, tot);
+                wet_balance(ex, e_h, tot);
             }
         } else {
             for (long k = 0; k < n; ++k) {
@@ -377,11 +392,20 @@ struct FastModel {
     __device__ __forceinline__ void route_and_sum(double &acc, double &num, double &den)
     {
         // outflows of this step are the reservoir states at its start (structure.py:427, :487)
-        q_gw = MERGE ? u_sgw : u_sgw + u_dgw;
-        q_in = MERGE ? (u_ove + u_int) + u_sgw : ((u_ove + u_dra) + u_int) + q_gw;
         double q_r = u_riv;
-        // river (structure.py:487-498) in outflow units: tmp / rk = U + (q_in - U) * dt / rk
-        double u_new = fma(q_in - u_riv, a_r, u_riv);
+        double u_new;
+        if (MERGE) {
+            // river (structure.py:487-498) in outflow units: U' = U (1 - dt/rk) + dt/rk * sum_j y_j area/1e3/k_j
+            u_new = u_riv;
+            fma_in_place(u_new, om_ar, fma(car_s, u_ove, fma(car_f, u_int, car_g * u_sgw)));
+            q_gw = cq_g * u_sgw; // only the raw-report and non-balance paths read these two
+            q_in = fma(cq_s, u_ove, fma(cq_f, u_int, q_gw));
+        } else {
+            q_gw = u_sgw + u_dgw;
+            q_in = ((u_ove + u_dra) + u_int) + q_gw;
+            // tmp / rk = U + (q_in - U) * dt / rk
+            u_new = fma(q_in - u_riv, a_r, u_riv);
+        }
         if (STIFF) {
             if (u_new < 0.0) { // 95 % rule, reachable only when rk < dt
                 q_r = 0.95 * fma(u_riv, inv_a_r, q_in);
@@ -434,7 +458,7 @@ struct FastModel {
 
     __device__ void balance_sums(double q_out_total, double &num, double &den) const
     {
-        num = fma(cq_g, xg_sum, g0 - u_sgw) / (1.0 - dec_g);
+        num = cq_g * (xg_sum + (g0 - u_sgw)) / (1.0 - dec_g); // the reservoir is carried in mm: outflow = y cq_g
         den = fma(u_riv - r0, inv_a_r, q_out_total);
     }
 
@@ -490,8 +514,9 @@ struct FastModel {
             pg *= dec_g;
         }
         P_q = pq, P_i = pi, P_g = pg, P_r = pr;
-        A_q = aq, A_i = ai, A_g = ag;
-        B_q = bq, B_i = bi, B_g = bg, B_r = br;
+        // the reservoirs are carried as volumes in mm, their outflows are y * area/1e3/k
+        A_q = aq * cq_s, A_i = ai * cq_f, A_g = ag * cq_g;
+        B_q = bq * cq_s, B_i = bi * cq_f, B_g = bg * cq_g, B_r = br;
     }
 
     // `n` consecutive dry steps with the same demand d0 = -ex on every one of them; adds the n river outflows to acc
