@@ -269,6 +269,24 @@ struct Reporter {
             }
         }
     }
+
+    // The same with the observation e = obs[r] and w = e - mean(e) requested ahead of time by the caller
+    // (interval_loop_obs): no scalar-load latency between the last step of the interval and the moments.
+    __device__ __forceinline__ void emit_prefetched(const KArgs &a, const LaneCtx &x, long r, double val, double e,
+                                                    double w)
+    {
+        if (a.discharge && x.live)
+            a.discharge[(x.c * a.R + r) * a.ld + x.n] = val;
+        if (want_obj && !is_nan_bits(e)) { // montecarlo.py:195-196
+            const double d = val - e;
+            const double u = val - ebar;
+            A += d;
+            B += d * d;
+            C1 += u;
+            C2 += u * u;
+            C3 += w * u;
+        }
+    }
 };
 
 template <class Model>
@@ -416,6 +434,25 @@ __device__ __forceinline__ void interval_loop(const double2 *__restrict__ f, lon
         body(i, f[i * gap]);
 }
 
+// The same walk for the run proper: the observation of each interval and its deviation from the mean
+// (Reporter::emit_prefetched) are requested one interval ahead of their use (an interval takes 700-7,000 cycles).
+template <class Body>
+__device__ __forceinline__ void interval_loop_obs(const double2 *__restrict__ f, const double *__restrict__ obs,
+                                                  const double *__restrict__ dev, long i0, long i1, long gap,
+                                                  Body &&body)
+{
+    if (i1 <= i0)
+        return;
+    double e = obs[i0], w = dev[i0];
+    interval_loop(f, i0, i1, gap, [&](long i, const double2 v) {
+        const long nx = i + 1 < i1 ? i + 1 : i;
+        const double e_nx = obs[nx], w_nx = dev[nx];
+        body(i, v, e, w);
+        e = e_nx;
+        w = w_nx;
+    });
+}
+
 // ---- time-sliced launch ----------------------------------------------------------------------------------------
 // A block of 64 samples is one wavefront for the whole time axis, so a launch of B blocks on S SIMDs lasts as long as
 // the SIMDs that hold ceil(B / S) of them while the others idle (1e5 samples: 1,563 blocks on 1,024 SIMDs, 539 SIMDs
@@ -514,12 +551,22 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         interval_loop(f, wa, wb, gap, [&](long, const double2 v) { interval(v, s0, s1, s2); });
         if (starts_run)
             m.begin_run();
-        interval_loop(f, ra, rb, gap, [&](long r, const double2 v) {
-            double acc = 0.0;
-            interval(v, acc, num, den);
-            rep.emit(a, x, r, acc * inv_gap);
-            q_out_total += acc;
-        });
+        if (rep.want_obj) {
+            interval_loop_obs(f, rep.obs, rep.ws + kWsHead, ra, rb, gap,
+                              [&](long r, const double2 v, const double e, const double w) {
+                                  double acc = 0.0;
+                                  interval(v, acc, num, den);
+                                  rep.emit_prefetched(a, x, r, acc * inv_gap, e, w);
+                                  q_out_total += acc;
+                              });
+        } else {
+            interval_loop(f, ra, rb, gap, [&](long r, const double2 v) {
+                double acc = 0.0;
+                interval(v, acc, num, den);
+                rep.emit(a, x, r, acc * inv_gap);
+                q_out_total += acc;
+            });
+        }
     } else {
         time_loop(m, f + wa * gap, (wb - wa) * gap,
                   [&](const double2 v, const double ex) { m.step(v.x, v.y, ex, s0, s1, s2); });

@@ -1,6 +1,6 @@
 """Cycles per wave-step of the fast kernel on forcing that is wet everywhere / dry everywhere / the bench's mix,
 at 1 and 2 waves per SIMD (N = 65536 / 131072).  Objectives fused, discharge stored, hourly steps, gap 24."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np
 import torch
@@ -28,13 +28,13 @@ extra = {'aar': 1200, 'r-o_ratio': 0.45, 'r-o_split': (0.10, 0.15, 0.15, 0.30, 0
 for n in (65536, 131072):
     np.random.seed(2718)
     params = torch.as_tensor(sampling.latin_hypercube(n, bench.ranges if hasattr(bench, "ranges") else __import__("smartpy_amd.parameters", fromlist=["x"]).Parameters().ranges, seed=2718), device=dev)
-    obs = torch.rand(days, dtype=torch.float64, device=dev) + 0.5
+    obs = None if os.environ.get('NO_OBS') else torch.rand(days, dtype=torch.float64, device=dev) + 0.5
     for name, f in cases.items():
         ft = torch.as_tensor(f, device=dev)
         ts = []
         for rep in range(4):
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            engine.run_ensemble(params, ft, 175.46e6, 3600.0, W, 24, extra=extra, obs=obs, gw_obs=0.12667)
+            engine.run_ensemble(params, ft, 175.46e6, 3600.0, W, 24, extra=extra, obs=obs, gw_obs=0.12667 if obs is not None else None, want_discharge=not os.environ.get('NO_DIS'))
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         t = min(ts[1:])
         waves_per_simd = n / 65536
