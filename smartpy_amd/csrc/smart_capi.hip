@@ -229,15 +229,8 @@ static int device_ready()
 // residency limit the launch ends with a tail of whole blocks; sliced 16 ways the hardware dispatcher evens both out
 // (measured -14 % at 1e5 samples, -33 % at 1.4e5, -17 % at 4e5; tools/debug/time_slices_sweep.py).  At or below one
 // block per SIMD there is nothing to even out and the hand-over costs 10 %.  SMART_TIME_SLICES = 0 / n overrides.
-static int plan_time_slices(const SmartEnsemble *e, const KArgs &a, int *per_simd)
+static int plan_time_slices(const SmartEnsemble *e, const KArgs &a, int *per_simd, double *load)
 {
-    if (e->report_type != SMART_REPORT_SUMMARY || a.gap < 2 || e->final_vars)
-        return 1;
-    const long n_all = a.W / a.gap + a.R;
-    const char *env = getenv("SMART_TIME_SLICES");
-    const int forced = env ? atoi(env) : -1;
-    if (forced == 0 || n_all < 64)
-        return 1;
     static int n_simd = 0;
     if (!n_simd) {
         int dev = 0, cus = 0;
@@ -248,7 +241,15 @@ static int plan_time_slices(const SmartEnsemble *e, const KArgs &a, int *per_sim
     }
     const long blocks = (a.N + kWave - 1) / kWave * e->n_catchments;
     const long cap = (blocks + n_simd - 1) / n_simd;
-    *per_simd = (int)(cap < 1 ? 1 : cap);
+    *per_simd = (int)(cap < 1 ? 1 : cap); // blocks of 64 samples per SIMD, rounded up
+    *load = (double)blocks / (double)n_simd;
+    if (e->report_type != SMART_REPORT_SUMMARY || a.gap < 2 || e->final_vars)
+        return 1;
+    const long n_all = a.W / a.gap + a.R;
+    const char *env = getenv("SMART_TIME_SLICES");
+    const int forced = env ? atoi(env) : -1;
+    if (forced == 0 || n_all < 64)
+        return 1;
     if (forced > 0)
         return forced < n_all / 4 ? forced : (int)(n_all / 4);
     if (blocks <= n_simd)
@@ -301,7 +302,14 @@ static int run(const SmartEnsemble *e)
     }
 
     int per_simd = 0;
-    const int n_seg = plan_time_slices(e, a, &per_simd);
+    double load = 0.0; // blocks of 64 samples per SIMD
+    const int n_seg = plan_time_slices(e, a, &per_simd, &load);
+    // early exits in the interval engine pay off once the SIMDs have two or more waves to issue from
+    // (FastModel::kExits; measured: off wins by 5 % at 1.53 blocks per SIMD, on wins by 4 % at 2.0, by 7 % at 15)
+    {
+        const char *env = getenv("SMART_EXITS");
+        a.exits = env ? atoi(env) != 0 : load >= 1.75;
+    }
     if (n_seg <= 1) {
         launch_fast(a, grid, 0, s);
         HIP_TRY(hipGetLastError());

@@ -32,6 +32,7 @@ struct KArgs {
     double *gw;         // [C][N]
     double *objfn;      // [C][N][8] | null
     double *final_vars; // [C][N][19] | null
+    int exits = 1;            // interval engine with (1) or without (0) wave-uniform early exits, FastModel::kExits
     // time-sliced launch (n_seg > 1): see "time-sliced launch" below
     int n_seg = 1;            // workgroups per block of 64 samples, each advancing one slice of the time axis
     long n_catch = 1;         // C

@@ -42,11 +42,8 @@
 #ifndef SMART_FAST_BALANCE_SUMS
 #define SMART_FAST_BALANCE_SUMS 1
 #endif
-#ifndef SMART_DRY_IV_EXITS
-#define SMART_DRY_IV_EXITS 0 // wave-uniform exits in the evaporation cascade of a dry interval: 0 / 1 / 2 measured, no difference
-#endif
-#ifndef SMART_FILL_EXITS
-#define SMART_FILL_EXITS 0 // ... in the filling cascade of a wet step: 0 / 1 / 2 measured, straight-line code wins by 3 %
+#ifndef SMART_WET_UNROLL
+#define SMART_WET_UNROLL 1
 #endif
 #ifndef SMART_FAST_LEAK_BALANCE
 #define SMART_FAST_LEAK_BALANCE 1
@@ -58,7 +55,8 @@ namespace smart {
 // (overland, drain) [k = SK] and the pair (shallow, deep groundwater) [k = GK] can each be carried as ONE
 // outflow: (Ua + Ub)' = (Ua + Ub)*dec + (xa + xb)*cq.  Only their sums enter the river inflow (structure.py:254)
 // and the groundwater ratio (:191).  Used when the caller does not ask for the final state vector.
-template <bool STIFF, bool GUARD, bool MERGE = false>
+// EXITS: wave-uniform early exits inside the interval engine's cascades (see kExits below).
+template <bool STIFF, bool GUARD, bool MERGE = false, bool EXITS = true>
 struct FastModel {
     static_assert(!(MERGE && STIFF), "the clamps of structure.py:429-450 act on each reservoir separately");
     static constexpr bool kExactDivide = false;
@@ -277,6 +275,12 @@ struct FastModel {
     // >= 1e-3 mm), unbiased.  Filling as t = l + ex; l = min(t, z); ex = t - l (3 instead of 4 per layer).
     static constexpr bool kLeakBalance = SMART_FAST_LEAK_BALANCE && MERGE && !GUARD;
 
+    // Wave-uniform early exits in the filling cascade of a wet step (no lane has excess left after the top layer: 32 %
+    // of the wet steps) and in the evaporation cascade of a dry interval.  They trade ~5 vector instructions per step
+    // for a compare and a branch: a win when the SIMD has three waves to issue from (vector-ALU bound: -7 % at 1e6
+    // samples), a loss when it has one or two (latency bound: +5 % at 1e5).  The launch picks (KArgs::exits).
+    static constexpr bool kExits = EXITS;
+
     __device__ static void fill3(double &l, double &ex, double z)
     {
         const double t = l + ex;
@@ -292,20 +296,12 @@ struct FastModel {
         const double ex_in = fma(-e_h, tot, ex); // excess left after the overland share H tot/Z ex (:363-365)
         double rem = ex_in;
         fill3(l0, rem, z);
-#if SMART_FILL_EXITS >= 1
-        if (__builtin_amdgcn_ballot_w64(rem > 0.0) != 0)
-#endif
-        {
+        if (!kExits || __builtin_amdgcn_ballot_w64(rem > 0.0) != 0) {
             fill3(l1, rem, z);
-#if SMART_FILL_EXITS >= 2
-            if (__builtin_amdgcn_ballot_w64(rem > 0.0) != 0)
-#endif
-            {
-                fill3(l2, rem, z);
-                fill3(l3, rem, z);
-                fill3(l4, rem, z);
-                fill3(l5, rem, z);
-            }
+            fill3(l2, rem, z);
+            fill3(l3, rem, z);
+            fill3(l4, rem, z);
+            fill3(l5, rem, z);
         }
         const double p2 = s1 * s1, p3 = p2 * s1, p4 = p2 * p2, p5 = p4 * s1, p6 = p3 * p3;
         l0 = fma(-l0, s1, l0);
@@ -346,6 +342,7 @@ struct FastModel {
         if (kLeakBalance) {
             const double e_h = ex * hz;
             double tot = layer_sum();
+#pragma unroll SMART_WET_UNROLL
             for (long k = 0; k < n; ++k) {
                 route_and_sum(acc, num, den);
                 wet_balance(ex, e_h, tot);
@@ -532,15 +529,9 @@ struct FastModel {
         // arithmetic does not depend on its wave neighbours; the early exits only skip identity operations.
         double d = -ex * (double)n;
         dry(l0, d, pC);
-#if SMART_DRY_IV_EXITS >= 1
-        if (__builtin_amdgcn_ballot_w64(d > 0.0) != 0)
-#endif
-        {
+        if (!kExits || __builtin_amdgcn_ballot_w64(d > 0.0) != 0) {
             dry(l1, d, pC);
-#if SMART_DRY_IV_EXITS >= 2
-            if (__builtin_amdgcn_ballot_w64(d > 0.0) != 0)
-#endif
-            {
+            if (!kExits || __builtin_amdgcn_ballot_w64(d > 0.0) != 0) {
                 dry(l2, d, pC);
                 dry(l3, d, pC);
                 dry(l4, d, pC);
@@ -599,8 +590,10 @@ __global__ __launch_bounds__(kWave, SMART_FAST_MIN_WAVES) void smart_ensemble_fa
         if (SMART_FAST_INTERVALS && Merged::kIntervals && a.report_type == 1 && a.gap >= 2) {
             const bool piecewise = a.n_seg > 1 ? a.seg_flag[a.seg_blocks + c] == 0 // answered by smart_forcing_scan
                                                : forcing_is_piecewise_constant(forcing + c * a.T, a.T, a.gap);
-            if (piecewise)
+            if (piecewise && a.exits)
                 run_ensemble_merged<Merged, true>(a, forcing, obs, ws, block, c, seg);
+            else if (piecewise)
+                run_ensemble_merged<FastModel<false, false, true, false>, true>(a, forcing, obs, ws, block, c, seg);
             else
                 run_ensemble_merged<Merged, false>(a, forcing, obs, ws, block, c, seg);
         } else if (seg == 0)
