@@ -572,3 +572,19 @@ def test_time_sliced_launch_by_default_above_one_block_per_simd(eng, example, mo
     monkeypatch.setenv('SMART_TIME_SLICES', '0')
     plain = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, **kw)
     assert torch.equal(auto.objfn, plain.objfn) and torch.equal(auto.gw, plain.gw)
+
+
+def test_early_exits_do_not_change_results(eng, example, monkeypatch):
+    """The interval engine runs with or without wave-uniform early exits depending on the load of the launch
+    (KArgs::exits); the exits only skip operations that would leave every lane unchanged."""
+    params = lhs_oracle.lhs_params(500, seed=31)
+    T, W = 24 * 500, 24 * 100
+    f = forcing_of(example['rain_hourly'][:T], example['peva_hourly'][:T])
+    kw = dict(extra=example['extra'], obs=example['flow_obs'][:T // 24], gw_obs=0.12667)
+    monkeypatch.setenv('SMART_EXITS', '0')
+    off = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, **kw)
+    monkeypatch.setenv('SMART_EXITS', '1')
+    on = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, **kw)
+    assert bits_equal(on.discharge.cpu().numpy(), off.discharge.cpu().numpy())
+    assert bits_equal(on.gw.cpu().numpy(), off.gw.cpu().numpy())
+    assert np.array_equal(on.objfn.cpu().numpy(), off.objfn.cpu().numpy())
