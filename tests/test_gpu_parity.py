@@ -588,3 +588,52 @@ def test_early_exits_do_not_change_results(eng, example, monkeypatch):
     assert bits_equal(on.discharge.cpu().numpy(), off.discharge.cpu().numpy())
     assert bits_equal(on.gw.cpu().numpy(), off.gw.cpu().numpy())
     assert np.array_equal(on.objfn.cpu().numpy(), off.objfn.cpu().numpy())
+
+
+def test_randomized_interval_engine(eng, monkeypatch):
+    """30 seeded random set-ups with forcing that is constant over each report interval (what the interval engine
+    takes): storms, droughts, exact zeros, gaps 2..48, warm-up or not, forced time slices and exits at random --
+    fast mode within tolerance of the reference-exact oracle on well-conditioned rows."""
+    rng = np.random.default_rng(20261003)
+    worst = 0.0
+    for case in range(30):
+        dt = float(rng.choice([900.0, 3600.0, 10800.0]))
+        gap = int(rng.choice([2, 3, 8, 24, 48]))
+        n_rep = int(rng.integers(64, 200))
+        T = n_rep * gap
+        W = int(rng.integers(0, n_rep // 2 + 1)) * gap if rng.random() < 0.7 else 0
+        scale = dt / 86400.0 * gap
+        rain_iv = rng.gamma(0.4, 8.0, n_rep) * (rng.random(n_rep) < rng.uniform(0.2, 0.9)) * rng.choice([1.0, 1.0, 15.0])
+        peva_iv = np.maximum(0.0, rng.normal(1.5, 1.0, n_rep))
+        peva_iv[rng.random(n_rep) < 0.08] = 0.0
+        rain = np.repeat(rain_iv * scale / gap, gap)
+        peva = np.repeat(peva_iv * scale / gap, gap)
+        area = float(np.exp(rng.uniform(np.log(5e6), np.log(5e9))))
+        n = int(rng.integers(1, 300))
+        params = lhs_oracle.lhs_params(max(n, 2), seed=int(rng.integers(1 << 30)))[:n]
+        extra = {'aar': float(rng.uniform(600, 2500)), 'r-o_ratio': float(rng.uniform(0.2, 0.7)),
+                 'r-o_split': tuple(rng.dirichlet(np.ones(5)))} if rng.random() < 0.7 else None
+        obs = rng.random(n_rep) * 3
+        obs[rng.random(n_rep) < 0.15] = np.nan
+        slices, exits = rng.choice(['', '0', '3', '9']), rng.choice(['', '0', '1'])
+        for name, val in (('SMART_TIME_SLICES', slices), ('SMART_EXITS', exits)):
+            if val:
+                monkeypatch.setenv(name, str(val))
+            else:
+                monkeypatch.delenv(name, raising=False)
+        fast = eng.run_ensemble(params, forcing_of(rain, peva), area, dt, W, gap, extra=extra, obs=obs, gw_obs=0.2)
+        d1, g1, _ = so.run_batch(area, dt, T, W, rain, peva, params, extra, so.REPORT_SUMMARY, gap)
+        tag = 'case %d: dt=%g gap=%d T=%d W=%d n=%d extra=%s slices=%r exits=%r' % (
+            case, dt, gap, T, W, n, extra is not None, slices, exits)
+        good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
+        if good.any():
+            e = rel(fast.discharge.cpu().numpy()[good], d1[good], floor=1e-300)
+            worst = max(worst, e)
+            assert e <= REL_FAST, tag
+            ok = np.isfinite(g1[good])
+            assert rel(fast.gw.cpu().numpy()[good][ok], g1[good][ok]) <= 1e-9, tag
+            want = objfn_oracle.objective_matrix(d1[good], obs, g1[good], 0.2)
+            got = fast.objfn.cpu().numpy()[good]
+            fin = np.isfinite(want[:, :7]).all(axis=1)
+            assert rel(got[fin, :7], want[fin, :7], floor=1e-12) <= 1e-7, tag
+    assert worst < 1e-10
