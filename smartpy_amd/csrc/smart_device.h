@@ -462,7 +462,7 @@ __device__ __forceinline__ void interval_loop_obs(const double2 *__restrict__ f,
 // SIMD that finishes early simply gets more slices.  Slice s of a block starts from the state slice s - 1 left in
 // `seg_state`; it waits for `seg_flag[block] >= s` (its predecessor has a lower id, so it is already resident or
 // finished -- no deadlock; the wait is bounded anyway).  The arithmetic is that of the unsliced run, bit for bit.
-constexpr long kMaxPolls = 1000000; // x ~3 us: a slice takes ~1 ms
+constexpr long kMaxPolls = 20000000; // x ~3 us = a minute; a slice takes ~1 ms and waits for one predecessor
 
 __device__ __forceinline__ void wait_for_slice(const KArgs &a, long slot, int seg)
 {
