@@ -19,11 +19,18 @@
 //   * reservoirs that share a time constant are merged and the two sums behind the groundwater ratio come
 //     from mass balances (MERGE, below) when the caller does not ask for the final state vector;
 //   * a wavefront holding a sample with dt / k > 2, where the reference's own update amplifies rounding
-//     differences, runs the literal model (smart_literal_model.h) instead.
+//     differences, runs the literal model (smart_literal_model.h) instead;
+//   * summary reports over forcing that is constant within the report interval (daily data spread over the hours,
+//     the reference's own input pipeline) advance one interval at a time (run_ensemble_merged in smart_device.h):
+//     a dry interval is ONE evaporation step with gap times the demand plus a precomputed linear routing map
+//     (dry_interval), a wet interval is `gap` straight-line wet steps whose leak amounts come from mass balance
+//     (wet_balance: 74 vector instructions per step against 117 in the step loop);
+//   * launches with more blocks of 64 samples than SIMDs are time-sliced (smart_device.h) so that the hardware
+//     dispatcher evens out what a whole-run-per-wavefront mapping leaves idle.
 //
 // Rounding differs from the reference at the 1e-16 level per operation; the recurrence is dissipative (for
-// dt / k <= 2), so the discharge stays within ~1e-12 relative of the literal path (measured 4e-13 over 512 LHS
-// rows x 10 years hourly; gate in tests: 1e-9; contract: 1e-6).
+// dt / k <= 2), so the discharge stays within ~1e-12 relative of the reference (measured 1.5e-12 at most over 256 LHS
+// rows x 10 years hourly, median 2.5e-14; gate in tests: 1e-9; contract: 1e-6).
 //
 // Tuning knobs (macros) are kept so that tools/ab_variants.sh can A/B them on one box; the defaults are the
 // measured winners.  Tried and not kept: see DESIGN.md section 4.1.
@@ -41,9 +48,6 @@
 #endif
 #ifndef SMART_FAST_BALANCE_SUMS
 #define SMART_FAST_BALANCE_SUMS 1
-#endif
-#ifndef SMART_WET_UNROLL
-#define SMART_WET_UNROLL 1
 #endif
 #ifndef SMART_FAST_LEAK_BALANCE
 #define SMART_FAST_LEAK_BALANCE 1
@@ -342,7 +346,6 @@ struct FastModel {
         if (kLeakBalance) {
             const double e_h = ex * hz;
             double tot = layer_sum();
-#pragma unroll SMART_WET_UNROLL
             for (long k = 0; k < n; ++k) {
                 route_and_sum(acc, num, den);
                 wet_balance(ex, e_h, tot);
