@@ -184,6 +184,8 @@ def main():
                        'samples_per_gpu': n_local, 'n_steps': T, 'n_warm': W, 'math_mode': args.math,
                        'wet_fraction': w, 'parallelism': 'sample-shard x%d' % world},
             'per_gpu': value / world,
+            # the same rate counting the simulated steps only (the warm-up replays W of them)
+            'value_without_warmup': world * n_local * T * args.steps / elapsed,
             'roofline': {
                 'bound': 'valu-fp64', 'achieved': steps_per_launch * flops_per_step / kern_s / 1e12,
                 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
