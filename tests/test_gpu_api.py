@@ -187,3 +187,31 @@ def test_run_lhs_terminates_like_the_reference_smoke_test(root, in_fmt, out_fmt)
     lhs.run(compression=True)
     assert os.path.exists(os.path.join(root, 'out', 'Catchment', 'Catchment.SMART.lhs.gz'))
     assert lhs.obj_fns.shape == (5, 8) and np.all(np.isfinite(lhs.obj_fns))
+
+
+def test_rccl_code_path_with_a_single_rank_group():
+    """A box with one GPU cannot hold a two-rank RCCL group, but a one-rank group runs the very calls the multi-GPU
+    path makes on device tensors (all_gather_into_tensor, all_reduce, barrier with device_ids): the backend-specific
+    half of smartpy_amd/distributed.py that the gloo tests on CPU cannot reach."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29631', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+import torch, torch.distributed as dist
+from smartpy_amd import distributed as sd
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1)
+sd.is_distributed = lambda: True                      # a world of one is "not distributed" for the product
+x = torch.arange(27, dtype=torch.float64, device='cuda').reshape(3, 9)
+out = sd.gather_rows(x, 3)
+assert out.is_cuda and torch.equal(out, x)
+assert sd.max_over_ranks(2.5, x.device) == 2.5 and sd.sum_over_ranks(1.5, x.device) == 1.5
+sd.barrier()
+dist.destroy_process_group()
+print('rccl ok')
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and 'rccl ok' in r.stdout, r.stdout + r.stderr
