@@ -142,6 +142,14 @@ int smart_allsteps_hip(double area_m2, double delta_sec, int64_t length_simu, co
 int smart_onestep_hip(int64_t n, const double *in, double *out);
 
 /*
+ * run_one_step_river (structure.py:461-503) on its own: the river reservoir with its 95 % rule.  HOST pointers;
+ * synchronous; n independent steps.  in[n][4] = time_gap_sec, r_in_q_riv, r_p_rk [hours], r_s_v_riv ;
+ * out[n][2] = r_out_q_riv, r_s_v_riv.  (run_one_step_catchment, :267-458, is the first six outputs and the eleven
+ * catchment states of smart_onestep_hip: the river does not feed back.)
+ */
+int smart_river_step_hip(int64_t n, const double *in, double *out);
+
+/*
  * Objective functions of an existing discharge matrix (montecarlo.py:193-209 applied to every sample);
  * the matrix is read once (moments about the observation mean).  Device pointers; asynchronous on stream.
  *   sim[R][ld] sample-minor (the layout smart_run_ensemble_hip writes), obs[R] (NaN = missing),

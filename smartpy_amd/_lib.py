@@ -38,6 +38,7 @@ SYMBOLS = {
     'smart_allsteps_hip': (ctypes.c_int, [ctypes.c_double, ctypes.c_double, ctypes.c_int64, _dp, _dp, _dp, _dp,
                                           ctypes.c_int32, ctypes.c_int64, _dp, _dp, _dp]),
     'smart_onestep_hip': (ctypes.c_int, [ctypes.c_int64, _dp, _dp]),
+    'smart_river_step_hip': (ctypes.c_int, [ctypes.c_int64, _dp, _dp]),
     'smart_objfn_hip': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, _dp, ctypes.c_int64, _dp, _dp,
                                        ctypes.c_double, _dp, _dp]),
     'smart_db_append_rows': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int64,

@@ -13,6 +13,7 @@
 namespace smart {
 void launch_literal(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s);
 void launch_onestep(long n, const double *in, double *out, hipStream_t s);
+void launch_river(long n, const double *in, double *out, hipStream_t s);
 void launch_fast(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s);
 size_t fast_lds_for_residency(int per_cu);
 
@@ -441,6 +442,31 @@ int smart_onestep_hip(int64_t n, const double *in, double *out)
     (void)hipFree(dev);
     if (err != hipSuccess)
         return hip_fail(err, "smart_onestep_hip");
+    g_err[0] = 0;
+    return SMART_OK;
+}
+
+int smart_river_step_hip(int64_t n, const double *in, double *out)
+{
+    if (!in || !out)
+        return fail(SMART_E_NULL, "smart_river_step_hip: NULL argument");
+    if (n < 1)
+        return fail(SMART_E_SIZE, "smart_river_step_hip: n must be >= 1");
+    int rc = device_ready();
+    if (rc)
+        return rc;
+    double *dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, (size_t)n * (4 + 2) * sizeof(double)));
+    hipError_t err = hipMemcpy(dev, in, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        launch_river(n, dev, dev + n * 4, nullptr);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess)
+        err = hipMemcpy(out, dev + n * 4, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (err != hipSuccess)
+        return hip_fail(err, "smart_river_step_hip");
     g_err[0] = 0;
     return SMART_OK;
 }

@@ -47,6 +47,24 @@ __global__ __launch_bounds__(kWave) void smart_onestep_literal(long n, const dou
         out[i * 19 + k] = v[k];
 }
 
+// run_one_step_river stand-in: n independent river steps; in = (dt, q_in, rk [hours], V), out = (q_out, V')
+__global__ __launch_bounds__(kWave) void smart_river_literal(long n, const double *in, double *out)
+{
+    const long i = (long)blockIdx.x * kWave + threadIdx.x;
+    if (i >= n)
+        return;
+    const double *x = in + i * 4;
+    double v = x[3];
+    const double q = LiteralModel::river(x[0], x[1], x[2] * 3600.0, v); // :482
+    out[i * 2] = q;
+    out[i * 2 + 1] = v;
+}
+
+void launch_river(long n, const double *in, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(smart_river_literal, dim3((unsigned)((n + kWave - 1) / kWave)), dim3(kWave), 0, s, n, in, out);
+}
+
 void launch_literal(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s)
 {
     hipLaunchKernelGGL(smart_ensemble_literal, grid, dim3(kWave), lds_bytes, s, a, reinterpret_cast<const double2 *>(a.forcing), a.obs, a.ws);

@@ -76,6 +76,21 @@ struct LiteralModel {
     }
 
     // one linear reservoir, structure.py:427-450
+    // run_one_step_river, structure.py:461-503, with rk already in seconds: outflow of the step, v updated
+    __device__ static double river(double dt, double q_in, double rk, double &v)
+    {
+        double q = v / rk; // :487
+        const double v_old = v;
+        const double tmp = v_old + (q_in - q) * dt; // :490
+        if (tmp < 0.0) {                            // :492-496
+            q = 0.95 * (q_in + v_old / dt);
+            v += (q_in - q) * dt;
+        } else {
+            v = tmp; // :498
+        }
+        return q;
+    }
+
     __device__ static double route(double &v, double k, double x_mm, double area, double dt)
     {
 #pragma clang fp contract(off)
@@ -196,15 +211,7 @@ struct LiteralModel {
         // river, structure.py:487-498; inflow summed left to right (:254)
         q_in = out[1] + out[2] + out[3] + out[4] + out[5];
         q_gw = out[4] + out[5];
-        double q = v_riv / rk;
-        const double v_old = v_riv;
-        const double tmp = v_old + (q_in - q) * dt;
-        if (tmp < 0.0) {
-            q = 0.95 * (q_in + v_old / dt);
-            v_riv += (q_in - q) * dt;
-        } else {
-            v_riv = tmp;
-        }
+        const double q = river(dt, q_in, rk, v_riv);
         out[6] = q;
         q_out = q;
         acc += q;

@@ -298,3 +298,13 @@ def onestep_batch(inputs):
     out = np.empty((x.shape[0], 19), dtype=np.float64)
     _lib.check(L.smart_onestep_hip(x.shape[0], x.ctypes.data, out.ctypes.data))
     return out
+
+
+def river_step_batch(inputs):
+    """[n, 4] (time_gap_sec, r_in_q_riv, r_p_rk [h], r_s_v_riv) -> [n, 2] (r_out_q_riv, r_s_v_riv): n independent
+    calls of run_one_step_river (structure.py:461-503) in one launch."""
+    L = _lib.lib()
+    x = np.ascontiguousarray(inputs, dtype=np.float64)
+    out = np.empty((x.shape[0], 2), dtype=np.float64)
+    _lib.check(L.smart_river_step_hip(x.shape[0], x.ctypes.data, out.ctypes.data))
+    return out

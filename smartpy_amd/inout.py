@@ -5,6 +5,8 @@ outputs, in the reference's formats (inout.py:35-310).  Series are returned as n
 simulation / report axes, ready to be uploaded to the GPU; the resampling itself is in timeframe.py.
 NetCDF needs the optional netCDF4 package, exactly as in the reference (inout.py:25-28).
 """
+import argparse
+from collections import OrderedDict
 from csv import DictReader, writer
 from datetime import datetime, timedelta
 
@@ -15,7 +17,7 @@ try:
 except ImportError:
     Dataset = None
 
-from .timeframe import check_interval_in_list, get_required_resolution, resample_cumulative, \
+from .timeframe import TimeFrame, check_interval_in_list, get_required_resolution, resample_cumulative, \
     resample_irregular_mean
 from .version import __version__
 
@@ -85,7 +87,7 @@ def get_peva_series_simu(file_location, file_format, start_simu, end_simu, time_
 # ----------------------------------------------------------------------------------------------------------
 # observations
 # ----------------------------------------------------------------------------------------------------------
-def read_flow_file(file_location, file_format):
+def _read_flow_arrays(file_location, file_format):
     """-> (stamps, values) with missing entries dropped: '' / -99 in CSV (inout.py:234-254), NaN in NetCDF
     (inout.py:257-274)."""
     if file_format == 'netcdf':
@@ -128,7 +130,7 @@ def read_flow_file(file_location, file_format):
 def get_discharge_series(file_location, file_format, start_report, end_report, catchment_area, gauged_area):
     """Observed discharge per report stamp, rescaled by catchment / gauged area, NaN where missing
     (inout.py:61-78; the daily-mean / hourly-replication assumption of :77-78 is the reference's)."""
-    stamps, values = read_flow_file(file_location, file_format)
+    stamps, values = _read_flow_arrays(file_location, file_format)
     scaling_factor = catchment_area / gauged_area
     first_day = (start_report - timedelta(days=2)).date()
     last_day = (end_report + timedelta(days=1)).date()
@@ -230,3 +232,145 @@ def write_flow_netcdf_file_from_nds(series_report, discharge, netcdf_file, paral
             (np.asarray(series_report, dtype='datetime64[us]') - np.datetime64('1970-01-01T00:00:00')) / \
             np.timedelta64(1, 's')
         f.variables['flow'][0:len(series_report)] = discharge
+
+
+# ----------------------------------------------------------------------------------------------------------
+# The reference's dictionary-returning readers (inout.py:35-78, 143-274, 313-322), for scripts that call them
+# directly: same names, arguments, results and error texts, on top of the array readers above.
+# ----------------------------------------------------------------------------------------------------------
+def read_csv_time_series_with_delta_check(csv_file, key_header, val_header):
+    """-> (dict stamp -> value, first stamp, last stamp, interval); regular spacing enforced (inout.py:192-209)."""
+    try:
+        with open(csv_file, 'r', encoding='utf8') as f:
+            data = dict()
+            stamps = []
+            try:
+                for row in DictReader(f):
+                    stamp = datetime.strptime(row[key_header], _DT)
+                    data[stamp] = np.float64(row[val_header])
+                    stamps.append(stamp)
+            except KeyError:
+                raise Exception('Field {} or {} does not exist in {}.'.format(key_header, val_header, csv_file))
+        start, end, interval = check_interval_in_list(stamps, csv_file)
+        return data, start, end, interval
+    except IOError:
+        raise Exception('File {} could not be found.'.format(csv_file))
+
+
+def read_netcdf_time_series_with_delta_check(netcdf_file, key_variable, val_variable):
+    """inout.py:212-231."""
+    if not Dataset:
+        raise Exception(_NO_NETCDF_IN)
+    try:
+        with Dataset(netcdf_file, 'r') as f:
+            f.set_auto_mask(False)
+            try:
+                stamps = [datetime(1970, 1, 1) + timedelta(seconds=float(t)) for t in f.variables[key_variable][:]]
+                data = dict(zip(stamps, f.variables[val_variable][:]))
+            except KeyError:
+                raise Exception('Variable {} or {} does not exist in {}.'.format(key_variable, val_variable,
+                                                                                 netcdf_file))
+        start, end, interval = check_interval_in_list(stamps, netcdf_file)
+        return data, start, end, interval
+    except IOError:
+        raise Exception('File {} could not be found.'.format(netcdf_file))
+
+
+def read_csv_time_series_with_missing_check(csv_file, key_header, val_header):
+    """-> OrderedDict stamp -> value without the missing entries ('' or -99) (inout.py:234-253)."""
+    try:
+        with open(csv_file, 'r', encoding='utf8') as f:
+            data = OrderedDict()
+            try:
+                for row in DictReader(f):
+                    try:
+                        if row[val_header] != '' and np.float64(row[val_header]) != -99.0:
+                            data[datetime.strptime(row[key_header], _DT)] = np.float64(row[val_header])
+                    except ValueError:
+                        raise Exception('Field {} in {} cannot be converted to float '
+                                        'at {}.'.format(val_header, csv_file, row[key_header]))
+            except KeyError:
+                raise Exception('Field {} or {} does not exist in {}.'.format(key_header, val_header, csv_file))
+        return data
+    except IOError:
+        raise Exception('File {} could not be found.'.format(csv_file))
+
+
+def read_netcdf_time_series_with_missing_check(netcdf_file, key_variable, val_variable):
+    """inout.py:256-274."""
+    if not Dataset:
+        raise Exception(_NO_NETCDF_IN)
+    try:
+        with Dataset(netcdf_file, 'r') as f:
+            data = OrderedDict()
+            try:
+                stamps = [datetime(1970, 1, 1) + timedelta(seconds=float(t)) for t in f.variables[key_variable][:]]
+                for stamp, flow in zip(stamps, f.variables[val_variable][:]):
+                    if not np.isnan(flow):
+                        data[stamp] = flow
+            except KeyError:
+                raise Exception('Variable {} or {} does not exist in {}.'.format(key_variable, val_variable,
+                                                                                 netcdf_file))
+        return data
+    except IOError:
+        raise Exception('File {} could not be found.'.format(netcdf_file))
+
+
+def _read_with(reader_csv, reader_netcdf, file_location, file_format, variable):
+    if file_format == 'netcdf':
+        if not Dataset:
+            raise Exception(_NO_NETCDF_IN)
+        return reader_netcdf(file_location, key_variable='DateTime', val_variable=variable)
+    return reader_csv(file_location, key_header='DateTime', val_header=variable)
+
+
+def read_rain_file(file_location, file_format):
+    """inout.py:143-151."""
+    return _read_with(read_csv_time_series_with_delta_check, read_netcdf_time_series_with_delta_check,
+                      file_location, file_format, 'rain')
+
+
+def read_peva_file(file_location, file_format):
+    """inout.py:154-162."""
+    return _read_with(read_csv_time_series_with_delta_check, read_netcdf_time_series_with_delta_check,
+                      file_location, file_format, 'peva')
+
+
+def read_flow_file(file_location, file_format):
+    """inout.py:165-174."""
+    return _read_with(read_csv_time_series_with_missing_check, read_netcdf_time_series_with_missing_check,
+                      file_location, file_format, 'flow')
+
+
+def _keyed(first, last, gap, values):
+    return OrderedDict(zip(TimeFrame._series(first, last, gap), values.tolist()))
+
+
+def get_dict_rain_series_simu(file_location, file_format, start_simu, end_simu, time_delta_simu):
+    """inout.py:35-45: rain per simulation step, keyed by the simulation stamps."""
+    return _keyed(start_simu, end_simu, time_delta_simu,
+                  get_rain_series_simu(file_location, file_format, start_simu, end_simu, time_delta_simu))
+
+
+def get_dict_peva_series_simu(file_location, file_format, start_simu, end_simu, time_delta_simu):
+    """inout.py:48-58."""
+    return _keyed(start_simu, end_simu, time_delta_simu,
+                  get_peva_series_simu(file_location, file_format, start_simu, end_simu, time_delta_simu))
+
+
+def get_dict_discharge_series(file_location, file_format, start_report, end_report, catchment_area, gauged_area):
+    """inout.py:61-78: rescaled observed discharge per daily report stamp, NaN where missing."""
+    return _keyed(start_report, end_report, timedelta(days=1),
+                  get_discharge_series(file_location, file_format, start_report, end_report, catchment_area,
+                                       gauged_area))
+
+
+def valid_file_format(fmt):
+    """argparse type (inout.py:313-322)."""
+    if fmt.lower() == "netcdf":
+        if Dataset:
+            return "netcdf"
+        raise argparse.ArgumentTypeError("NetCDF4 module is not installed, please choose another file format.")
+    if fmt.lower() == "csv":
+        return "csv"
+    raise argparse.ArgumentTypeError("File format not recognised: '{0}'.".format(fmt))

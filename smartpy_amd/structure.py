@@ -77,3 +77,22 @@ def run_one_step(area_m2, time_delta_sec, c_in_rain, c_in_peva,
         c_s_v_h2o_ove, c_s_v_h2o_dra, c_s_v_h2o_int, c_s_v_h2o_sgw, c_s_v_h2o_dgw,
         c_s_v_h2o_ly1, c_s_v_h2o_ly2, c_s_v_h2o_ly3, c_s_v_h2o_ly4, c_s_v_h2o_ly5, c_s_v_h2o_ly6,
         r_s_v_riv).tolist())
+
+
+def run_one_step_catchment(area_m2, time_gap_sec, c_in_rain, c_in_peva,
+                           c_p_t, c_p_c, c_p_h, c_p_d, c_p_s, c_p_z, c_p_sk, c_p_fk, c_p_gk,
+                           c_s_v_ove, c_s_v_dra, c_s_v_int, c_s_v_sgw, c_s_v_dgw,
+                           c_s_v_ly1, c_s_v_ly2, c_s_v_ly3, c_s_v_ly4, c_s_v_ly5, c_s_v_ly6):
+    """structure.py:267-458 -> tuple of 17 floats: actual evapotranspiration and the five outflows, then the five
+    reservoir and six soil-layer volumes.  The river does not feed back into the catchment, so this is the catchment
+    part of one full step on the GPU (river left empty)."""
+    v = engine.onestep(area_m2, time_gap_sec, c_in_rain, c_in_peva,
+                       c_p_t, c_p_c, c_p_h, c_p_d, c_p_s, c_p_z, c_p_sk, c_p_fk, c_p_gk, 1.0,
+                       c_s_v_ove, c_s_v_dra, c_s_v_int, c_s_v_sgw, c_s_v_dgw,
+                       c_s_v_ly1, c_s_v_ly2, c_s_v_ly3, c_s_v_ly4, c_s_v_ly5, c_s_v_ly6, 0.0).tolist()
+    return tuple(v[0:6] + v[7:18])
+
+
+def run_one_step_river(time_gap_sec, r_in_q_riv, r_p_rk, r_s_v_riv):
+    """structure.py:461-503 -> (r_out_q_riv, r_s_v_riv)."""
+    return tuple(engine.river_step_batch([[time_gap_sec, r_in_q_riv, r_p_rk, r_s_v_riv]])[0].tolist())

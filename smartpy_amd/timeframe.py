@@ -9,6 +9,8 @@ their re-averaging (timeframe.py:236-309) -- is done in the reference's operatio
 at 0.0 and adds the stamps from the latest backwards), so the arrays are bit-identical to the reference's
 (tests/test_host_logic.py against tests/golden/forcing_example.npz).
 """
+import argparse
+from collections import OrderedDict
 from datetime import datetime, timedelta
 from math import gcd
 
@@ -61,6 +63,14 @@ class TimeFrame(object):
         if not self.save_gap.total_seconds() % self.simu_gap.total_seconds() == 0:
             raise Exception("Save Gap is not greater and a multiple of Simulation Gap.")
         return self.save_start - self.save_gap + self.simu_gap, self.save_end
+
+    def _get_list_save_dt_with_initial_conditions(self):
+        """timeframe.py:95-104: report stamps with one leading stamp for the initial conditions."""
+        return self._series(self.save_start - self.save_gap, self.save_end, self.save_gap)
+
+    def _get_list_simu_dt_with_initial_conditions(self):
+        """timeframe.py:106-115."""
+        return self._series(self.simu_start - self.simu_gap, self.simu_end, self.simu_gap)
 
     def get_gap_simu(self):
         return self.simu_gap
@@ -195,3 +205,111 @@ def resample_irregular_mean(stamps, values, start_report, end_report, delta_lo, 
         ok &= have[last - j]
     out[ok] = acc[ok] / div_lo
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# The reference's dictionary-keyed helpers (timeframe.py:130-141, 167-309), for scripts that call them directly.
+# Same names, arguments, results and error texts; the work is done by the array routines above, so the values are
+# the ones the GPU path is fed with.
+# ----------------------------------------------------------------------------------------------------------
+def valid_date(s):
+    """argparse type 'dd/mm/YYYY_HH:MM:SS' (timeframe.py:130-134)."""
+    try:
+        return datetime.strptime(s, "%d/%m/%Y_%H:%M:%S")
+    except ValueError:
+        raise argparse.ArgumentTypeError("Not a valid date: '{0}'.".format(s))
+
+
+def valid_delta_min(n):
+    """argparse type: minutes -> timedelta (timeframe.py:137-141)."""
+    try:
+        return timedelta(minutes=int(n))
+    except ValueError:
+        raise argparse.ArgumentTypeError("Not a valid time delta: '{0}'.".format(n))
+
+
+def _divisor(delta_lo, delta_hi, what):
+    divisor, remainder = divmod(_isec(delta_lo), _isec(delta_hi))
+    if remainder != 0:
+        raise Exception("{} Resolution: Time Deltas are not multiples of each other.".format(what))
+    if divisor < 1:
+        raise Exception("{} Resolution: Low resolution lower than higher resolution "
+                        "{} < {}.".format(what, delta_lo, delta_hi))
+    return divisor
+
+
+def increase_time_resolution_of_regular_cumulative_data(dict_info, start_lo, end_lo, time_delta_lo, time_delta_hi):
+    """Each value split equally over its sub-steps, written backwards from its stamp (timeframe.py:167-186)."""
+    divisor = _divisor(time_delta_lo, time_delta_hi, "Increase")
+    stamps = TimeFrame._series(start_lo, end_lo, time_delta_lo)
+    portions = np.array([dict_info[t] for t in stamps], dtype=np.float64) / divisor
+    out = dict()
+    for t, v in zip(stamps, portions):
+        for k in range(divisor):
+            out[t - k * time_delta_hi] = v
+    return out
+
+
+def decrease_time_resolution_of_regular_cumulative_data(dict_info, start_lo, end_lo, time_delta_lo, time_delta_hi):
+    """Each low-resolution stamp sums its sub-steps, latest first (timeframe.py:189-208)."""
+    divisor = _divisor(time_delta_lo, time_delta_hi, "Decrease")
+    stamps = TimeFrame._series(start_lo, end_lo, time_delta_lo)
+    total = np.zeros(len(stamps), dtype=np.float64)
+    for k in range(divisor):
+        total += np.array([dict_info[t - k * time_delta_hi] for t in stamps], dtype=np.float64)
+    return dict(zip(stamps, total))
+
+
+def rescale_time_resolution_of_regular_cumulative_data(dict_data, start_data, end_data, time_delta_data,
+                                                       time_delta_res, start_simu, end_simu, time_delta_simu):
+    """timeframe.py:211-233: onto the common grid if the data are coarser than it, then onto the simulation stamps."""
+    fine = dict_data
+    if time_delta_data > time_delta_res:
+        fine = increase_time_resolution_of_regular_cumulative_data(dict_data, start_data, end_data,
+                                                                   time_delta_data, time_delta_res)
+    return decrease_time_resolution_of_regular_cumulative_data(fine, start_simu, end_simu, time_delta_simu,
+                                                               time_delta_res)
+
+
+def increase_time_resolution_of_irregular_mean_data(dict_info, time_delta_lo, time_delta_hi):
+    """Mean values replicated backwards onto the fine grid, over the span back to the previous stamp -- one standard
+    interval for the first stamp and after a gap of 1.5 intervals or more (timeframe.py:236-271)."""
+    stamps = list(dict_info)
+    lo = _isec(time_delta_lo)
+    secs = np.array([_sec(t) for t in stamps], dtype=np.int64)
+    span = np.diff(secs, prepend=secs[0] - lo) if len(secs) else secs
+    span = np.where(span >= 1.5 * lo, lo, span)
+    out = dict()
+    for t, width in zip(stamps, span):
+        divisor = _divisor(timedelta(seconds=int(width)), time_delta_hi, "Increase")
+        try:
+            value = float(dict_info[t])
+        except ValueError:          # a string that is not a number: no data for this stamp
+            value = float('nan')
+        for k in range(divisor):
+            if out.get(t - k * time_delta_hi):
+                raise Exception("Increase Resolution: Overwriting already existing data for datetime.")
+            out[t - k * time_delta_hi] = value
+    return out
+
+
+def decrease_time_resolution_of_irregular_mean_data(dict_info, dt_start, dt_end, time_delta_hi, time_delta_lo):
+    """Arithmetic mean of the sub-steps ending at each low-resolution stamp, NaN if one is missing
+    (timeframe.py:274-301)."""
+    divisor = _divisor(time_delta_lo, time_delta_hi, "Decrease")
+    out = OrderedDict()
+    for t in TimeFrame._series(dt_start, dt_end, time_delta_lo):
+        try:
+            total = 0.0
+            for k in range(divisor):
+                total += dict_info[t - k * time_delta_hi]
+            out[t] = total / divisor
+        except (KeyError, TypeError):
+            out[t] = float('nan')
+    return out
+
+
+def rescale_time_resolution_of_irregular_mean_data(dict_data, start_data, end_data, time_delta_lo, time_delta_hi):
+    """timeframe.py:304-309."""
+    fine = increase_time_resolution_of_irregular_mean_data(dict_data, time_delta_lo, time_delta_hi)
+    return decrease_time_resolution_of_irregular_mean_data(fine, start_data, end_data, time_delta_hi, time_delta_lo)

@@ -17,6 +17,8 @@ import tempfile
 import types
 from datetime import datetime, timedelta
 
+from collections import OrderedDict
+
 import numpy as np
 
 REF = '/root/reference'
@@ -106,6 +108,86 @@ def resampling_vectors(root):
     save('kat10_resampling.npz', **out)
 
 
+def dict_helper_vectors(root):
+    """The reference's dictionary-keyed helpers called directly (timeframe.py:167-309, inout.py:35-78): results as
+    (seconds since 1970, value) arrays."""
+    from smartpy import timeframe as tf, inout as io
+    epoch = datetime(1970, 1, 1)
+
+    def unpack(d):
+        keys = list(d)
+        return (np.array([(k - epoch).total_seconds() for k in keys]), np.array([d[k] for k in keys], dtype=np.float64))
+
+    rng = np.random.default_rng(11)
+    out = {}
+    # regular cumulative data: 40 daily values at 09:00 -> 3-hourly simulation stamps from 12:00 (common grid 3 h)
+    start = datetime(2010, 3, 1, 9)
+    daily = {start + timedelta(days=k): float(v) for k, v in enumerate(rng.gamma(0.7, 4.0, 40))}
+    out['reg_in_t'], out['reg_in_v'] = unpack(daily)
+    res = tf.get_required_resolution(start, datetime(2010, 3, 2, 12), timedelta(days=1), timedelta(hours=3))
+    out['reg_res_sec'] = res.total_seconds()
+    inc = tf.increase_time_resolution_of_regular_cumulative_data(daily, start, start + timedelta(days=39),
+                                                                 timedelta(days=1), res)
+    out['reg_inc_t'], out['reg_inc_v'] = unpack(inc)
+    dec = tf.decrease_time_resolution_of_regular_cumulative_data(inc, datetime(2010, 3, 2, 12), datetime(2010, 4, 5, 12),
+                                                                 timedelta(hours=6), res)
+    out['reg_dec_t'], out['reg_dec_v'] = unpack(dec)
+    resc = tf.rescale_time_resolution_of_regular_cumulative_data(daily, start, start + timedelta(days=39),
+                                                                 timedelta(days=1), res, datetime(2010, 3, 2, 12),
+                                                                 datetime(2010, 4, 5, 12), timedelta(hours=3))
+    out['reg_resc_t'], out['reg_resc_v'] = unpack(resc)
+    # irregular mean data: daily means with a 3-day gap and a missing first neighbour
+    days = [0, 1, 2, 3, 7, 8, 9, 10, 11, 13, 14]
+    flows = OrderedDict((datetime(2010, 3, 1) + timedelta(days=k), float(v)) for k, v in zip(days, rng.random(len(days)) * 5))
+    out['irr_in_t'], out['irr_in_v'] = unpack(flows)
+    inc = tf.increase_time_resolution_of_irregular_mean_data(flows, timedelta(days=1), timedelta(hours=1))
+    out['irr_inc_t'], out['irr_inc_v'] = unpack(inc)
+    resc = tf.rescale_time_resolution_of_irregular_mean_data(flows, datetime(2010, 3, 1, 9), datetime(2010, 3, 15, 9),
+                                                             timedelta(days=1), timedelta(hours=1))
+    out['irr_resc_t'], out['irr_resc_v'] = unpack(resc)
+    # the readers on the shipped example files
+    loc = os.path.join(root, 'in', 'Catchment', 'Catchment')
+    rain = io.get_dict_rain_series_simu(loc + '.rain', 'csv', datetime(2007, 1, 1, 12), datetime(2007, 2, 1, 9),
+                                        timedelta(hours=3))
+    out['rain_3h_t'], out['rain_3h_v'] = unpack(rain)
+    flow = io.get_dict_discharge_series(loc + '.flow', 'csv', datetime(2007, 1, 1, 9), datetime(2007, 3, 1, 9),
+                                        175.46e6, 175.97e6)
+    out['flow_t'], out['flow_v'] = unpack(flow)
+    raw, first, last, step = io.read_peva_file(loc + '.peva', 'csv')
+    out['peva_raw_n'] = len(raw)
+    out['peva_raw_first'] = (first - epoch).total_seconds()
+    out['peva_raw_last'] = (last - epoch).total_seconds()
+    out['peva_raw_step'] = step.total_seconds()
+    out['flow_raw_n'] = len(io.read_flow_file(loc + '.flow', 'csv'))
+    save('kat11_dict_helpers.npz', **out)
+
+
+def api_surface():
+    """Public names of the reference's modules with the parameter names of every function / method: the inventory
+    tests/test_host_logic.py::test_public_surface_has_every_name_of_the_reference checks the package against."""
+    import inspect
+    import json
+    mods = ['smartpy', 'smartpy.smart', 'smartpy.structure', 'smartpy.inout', 'smartpy.timeframe', 'smartpy.parameters',
+            'smartpy.objfunctions', 'smartpy.montecarlo', 'smartpy.montecarlo.montecarlo', 'smartpy.montecarlo.lhs',
+            'smartpy.montecarlo.glue', 'smartpy.montecarlo.best', 'smartpy.montecarlo.total', 'smartpy.version']
+    out = {}
+    for name in mods:
+        mod = importlib.import_module(name)
+        entry = {}
+        for n, o in vars(mod).items():
+            if n.startswith('_'):
+                continue
+            if inspect.isfunction(o) and o.__module__ == mod.__name__:
+                entry[n] = list(inspect.signature(o).parameters)
+            elif inspect.isclass(o) and o.__module__ == mod.__name__:
+                entry[n] = {k: (list(inspect.signature(v).parameters) if inspect.isfunction(v) else None)
+                            for k, v in vars(o).items() if not k.startswith('__') and callable(v)}
+        out[name] = entry
+    with open(os.path.join(OUT, 'api_surface.json'), 'w') as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print('api_surface.json', sum(len(v) for v in out.values()), 'names')
+
+
 def main():
     scratch = tempfile.mkdtemp(prefix='smart_golden_')
     shutil.copytree(os.path.join(REF, 'tests', 'data'), os.path.join(scratch, 'data'))
@@ -116,6 +198,8 @@ def main():
             os.chmod(os.path.join(dirpath, f), 0o644)
 
     resampling_vectors(root)
+    dict_helper_vectors(root)
+    api_surface()
     if '--only-resampling' in sys.argv:
         shutil.rmtree(scratch)
         return

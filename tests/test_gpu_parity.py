@@ -64,6 +64,41 @@ def test_onestep_literal_bit_exact_on_kat6(eng):
     assert bits_equal(one, want[7])
 
 
+def test_river_step_bit_exact_on_the_reference_tables(eng):
+    """run_one_step_river (structure.py:461-503) on the GPU against the rows of the reference's own storage tables
+    (kat5: daily steps with RK < 24 h, where the 95 % rule fires): no pow in the river, so bit for bit."""
+    from smartpy_amd import structure
+    g = load_golden('kat5_river.npz')
+    rows, want = [], []
+    for p, tab in zip(g['params'], g['tables']):
+        q_in = tab[1:, 1] + tab[1:, 2] + tab[1:, 3] + tab[1:, 4] + tab[1:, 5]          # left to right, :254
+        rows.append(np.stack([np.full(len(q_in), 86400.0), q_in, np.full(len(q_in), p[9]), tab[:-1, 18]], axis=1))
+        want.append(tab[1:, [6, 18]])
+    rows, want = np.concatenate(rows), np.concatenate(want)
+    got = eng.river_step_batch(rows)
+    assert bits_equal(got, want)
+    fired = np.abs(want[:, 0] - rows[:, 3] / (rows[:, 2] * 3600)) > 1e-9 * np.abs(want[:, 0])
+    assert fired.sum() > 50
+    k = int(np.flatnonzero(fired)[0])
+    assert structure.run_one_step_river(*rows[k]) == tuple(want[k])
+
+
+def test_catchment_step_is_the_catchment_part_of_the_full_step(eng):
+    """run_one_step_catchment (structure.py:267-458): 17 values, equal to outputs 0..5 and states 7..17 of
+    run_one_step on the same inputs (kat6 vectors of the reference)."""
+    from smartpy_amd import structure
+    g = load_golden('kat6_steps.npz')
+    for k in (0, 7, 100, 333, 629):
+        args = [g['area'][k], g['dt'][k], g['rain'][k], g['peva'][k]] + list(g['params'][k][:9]) + \
+            list(g['states'][k][:11])
+        got = structure.run_one_step_catchment(*args)
+        assert len(got) == 17
+        want = np.concatenate([g['out'][k][0:6], g['out'][k][7:18]])
+        assert rel(got, want) < 1e-12
+        full = structure.run_one_step(*(args[:13] + [g['params'][k][9]] + args[13:] + [g['states'][k][11]]))
+        assert tuple(full[0:6]) + tuple(full[7:18]) == got
+
+
 # ------------------------------------------------------------------------------------------------------
 # ensembles against the oracle
 # ------------------------------------------------------------------------------------------------------

@@ -315,6 +315,92 @@ def test_native_row_parser_reads_what_numpy_reads():
                                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 10, 1) < 0      # no room
 
 
+def test_dictionary_helpers_match_the_reference():
+    """The reference's dictionary-keyed helpers (timeframe.py:167-309, inout.py:35-78,143-274) under their own
+    names: the calls of tests/golden/make_golden.py::dict_helper_vectors repeated here, keys and values bit for bit."""
+    from collections import OrderedDict
+    from smartpy_amd import timeframe as tf, inout as io
+    g = load_golden('kat11_dict_helpers.npz')
+    epoch = datetime(1970, 1, 1)
+
+    def same(d, tag):
+        keys = list(d)
+        t = np.array([(k - epoch).total_seconds() for k in keys])
+        v = np.array([d[k] for k in keys], dtype=np.float64)
+        assert np.array_equal(t, g[tag + '_t']), tag
+        assert np.array_equal(v.view(np.int64), g[tag + '_v'].view(np.int64)), tag
+
+    def as_dict(tag, kind=dict):
+        return kind((epoch + timedelta(seconds=float(t)), float(v)) for t, v in zip(g[tag + '_t'], g[tag + '_v']))
+
+    start = datetime(2010, 3, 1, 9)
+    daily = as_dict('reg_in')
+    res = tf.get_required_resolution(start, datetime(2010, 3, 2, 12), timedelta(days=1), timedelta(hours=3))
+    assert res.total_seconds() == float(g['reg_res_sec'])
+    inc = tf.increase_time_resolution_of_regular_cumulative_data(daily, start, start + timedelta(days=39),
+                                                                 timedelta(days=1), res)
+    same(inc, 'reg_inc')
+    same(tf.decrease_time_resolution_of_regular_cumulative_data(inc, datetime(2010, 3, 2, 12), datetime(2010, 4, 5, 12),
+                                                                timedelta(hours=6), res), 'reg_dec')
+    same(tf.rescale_time_resolution_of_regular_cumulative_data(daily, start, start + timedelta(days=39),
+                                                               timedelta(days=1), res, datetime(2010, 3, 2, 12),
+                                                               datetime(2010, 4, 5, 12), timedelta(hours=3)), 'reg_resc')
+    flows = as_dict('irr_in', OrderedDict)
+    same(tf.increase_time_resolution_of_irregular_mean_data(flows, timedelta(days=1), timedelta(hours=1)), 'irr_inc')
+    same(tf.rescale_time_resolution_of_irregular_mean_data(flows, datetime(2010, 3, 1, 9), datetime(2010, 3, 15, 9),
+                                                           timedelta(days=1), timedelta(hours=1)), 'irr_resc')
+    with pytest.raises(Exception, match='Time Deltas are not multiples of each other'):
+        tf.increase_time_resolution_of_regular_cumulative_data(daily, start, start, timedelta(days=1), timedelta(hours=5))
+    with pytest.raises(Exception, match='Decrease Resolution: Time Deltas are not multiples'):
+        tf.decrease_time_resolution_of_regular_cumulative_data(daily, start, start, timedelta(hours=1), timedelta(hours=2))
+    loc = os.path.join(GOLDEN, 'data', 'in', 'Catchment', 'Catchment')
+    same(io.get_dict_rain_series_simu(loc + '.rain', 'csv', datetime(2007, 1, 1, 12), datetime(2007, 2, 1, 9),
+                                      timedelta(hours=3)), 'rain_3h')
+    same(io.get_dict_discharge_series(loc + '.flow', 'csv', datetime(2007, 1, 1, 9), datetime(2007, 3, 1, 9),
+                                      175.46e6, 175.97e6), 'flow')
+    raw, first, last, step = io.read_peva_file(loc + '.peva', 'csv')
+    assert len(raw) == int(g['peva_raw_n']) and (first - epoch).total_seconds() == float(g['peva_raw_first']) and \
+        (last - epoch).total_seconds() == float(g['peva_raw_last']) and step.total_seconds() == float(g['peva_raw_step'])
+    assert len(io.read_flow_file(loc + '.flow', 'csv')) == int(g['flow_raw_n'])
+    with pytest.raises(Exception, match='Rain data not sufficient'):
+        io.get_dict_rain_series_simu(loc + '.rain', 'csv', datetime(2007, 1, 1, 12), datetime(2030, 2, 1, 9),
+                                     timedelta(hours=3))
+    assert io.valid_file_format('CSV') == 'csv' and tf.valid_delta_min('90') == timedelta(minutes=90)
+    assert tf.valid_date('01/02/2007_09:00:00') == datetime(2007, 2, 1, 9)
+    frame = tf.TimeFrame(datetime(2007, 1, 1, 9), datetime(2007, 1, 3, 9), timedelta(hours=6), timedelta(days=1))
+    assert frame._get_list_save_dt_with_initial_conditions() == frame.save_series and \
+        frame._get_list_simu_dt_with_initial_conditions() == frame.simu_series
+
+
+def test_public_surface_has_every_name_of_the_reference():
+    """tests/golden/api_surface.json lists the public functions, classes and methods of the reference's modules with
+    their parameter names (generated by make_golden.py); the package must offer each under the same name with the
+    same parameters, so that a script written against the reference runs after `import smartpy_amd as smartpy`."""
+    import importlib
+    import inspect
+    import json
+    with open(os.path.join(GOLDEN, 'api_surface.json')) as fh:
+        ref = json.load(fh)
+    problems = []
+    for mod_name, names in ref.items():
+        mine = importlib.import_module(mod_name.replace('smartpy', 'smartpy_amd', 1))
+        for name, spec in names.items():
+            obj = getattr(mine, name, None)
+            if obj is None:
+                problems.append('%s.%s missing' % (mod_name, name))
+            elif isinstance(spec, list):
+                if list(inspect.signature(obj).parameters) != spec:
+                    problems.append('%s.%s%s' % (mod_name, name, inspect.signature(obj)))
+            else:
+                for meth, params in spec.items():
+                    fn = getattr(obj, meth, None)
+                    if fn is None:
+                        problems.append('%s.%s.%s missing' % (mod_name, name, meth))
+                    elif params is not None and list(inspect.signature(fn).parameters) != params:
+                        problems.append('%s.%s.%s%s' % (mod_name, name, meth, inspect.signature(fn)))
+    assert not problems, problems
+
+
 # ---- sharding arithmetic -----------------------------------------------------------------------------------------
 def test_shard_bounds_cover_the_rows_exactly():
     from smartpy_amd.distributed import shard_bounds, shard_counts
