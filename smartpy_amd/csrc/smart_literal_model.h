@@ -79,6 +79,7 @@ struct LiteralModel {
     // run_one_step_river, structure.py:461-503, with rk already in seconds: outflow of the step, v updated
     __device__ static double river(double dt, double q_in, double rk, double &v)
     {
+#pragma clang fp contract(off)
         double q = v / rk; // :487
         const double v_old = v;
         const double tmp = v_old + (q_in - q) * dt; // :490
