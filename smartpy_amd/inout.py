@@ -28,6 +28,18 @@ _NO_NETCDF_OUT = "The use of 'netcdf' as the output file format requires the pac
 _DT = "%Y-%m-%d %H:%M:%S"
 
 
+def _stamp(text):
+    """'%Y-%m-%d %H:%M:%S' -> datetime.  datetime.fromisoformat is ten times faster than strptime (a ten-year daily
+    file has 3,653 stamps, three files per catchment); anything that is not exactly of that shape goes through
+    strptime, which accepts or rejects it as the reference does."""
+    if len(text) == 19 and text[10] == ' ':
+        try:
+            return datetime.fromisoformat(text)
+        except ValueError:
+            pass
+    return datetime.strptime(text, _DT)
+
+
 # ----------------------------------------------------------------------------------------------------------
 # forcing
 # ----------------------------------------------------------------------------------------------------------
@@ -53,7 +65,7 @@ def _read_regular_series(file_location, file_format, variable):
                 stamps, values = [], []
                 try:
                     for row in DictReader(f):
-                        stamps.append(datetime.strptime(row['DateTime'], _DT))
+                        stamps.append(_stamp(row['DateTime']))
                         values.append(np.float64(row[variable]))
                 except KeyError:
                     raise Exception('Field {} or {} does not exist in {}.'.format('DateTime', variable,
@@ -115,7 +127,7 @@ def _read_flow_arrays(file_location, file_format):
                         if row['flow'] != '':
                             v = np.float64(row['flow'])
                             if v != -99.0:
-                                stamps.append(datetime.strptime(row['DateTime'], _DT))
+                                stamps.append(_stamp(row['DateTime']))
                                 values.append(v)
                     except ValueError:
                         raise Exception('Field {} in {} cannot be converted to float '
@@ -246,7 +258,7 @@ def read_csv_time_series_with_delta_check(csv_file, key_header, val_header):
             stamps = []
             try:
                 for row in DictReader(f):
-                    stamp = datetime.strptime(row[key_header], _DT)
+                    stamp = _stamp(row[key_header])
                     data[stamp] = np.float64(row[val_header])
                     stamps.append(stamp)
             except KeyError:
@@ -285,7 +297,7 @@ def read_csv_time_series_with_missing_check(csv_file, key_header, val_header):
                 for row in DictReader(f):
                     try:
                         if row[val_header] != '' and np.float64(row[val_header]) != -99.0:
-                            data[datetime.strptime(row[key_header], _DT)] = np.float64(row[val_header])
+                            data[_stamp(row[key_header])] = np.float64(row[val_header])
                     except ValueError:
                         raise Exception('Field {} in {} cannot be converted to float '
                                         'at {}.'.format(val_header, csv_file, row[key_header]))
