@@ -458,10 +458,11 @@ __device__ __forceinline__ void interval_loop_obs(const double2 *__restrict__ f,
 // A block of 64 samples is one wavefront for the whole time axis, so a launch of B blocks on S SIMDs lasts as long as
 // the SIMDs that hold ceil(B / S) of them while the others idle (1e5 samples: 1,563 blocks on 1,024 SIMDs, 539 SIMDs
 // with two).  Here the time axis of every block is cut into n_seg slices and each (block, slice) is its own
-// workgroup, id = slice * seg_blocks + (catchment * n_blocks + block): the hardware hands out workgroups in id order as slots free up, so a
-// SIMD that finishes early simply gets more slices.  Slice s of a block starts from the state slice s - 1 left in
-// `seg_state`; it waits for `seg_flag[block] >= s` (its predecessor has a lower id, so it is already resident or
-// finished -- no deadlock; the wait is bounded anyway).  The arithmetic is that of the unsliced run, bit for bit.
+// workgroup, id = slice * seg_blocks + (catchment * n_blocks + block): the hardware hands out workgroups in id order
+// as slots free up, so a SIMD that finishes early simply gets more slices.  Slice s of a block starts from the state
+// slice s - 1 left in `seg_state`; it waits for `seg_flag[slot] >= s` (its predecessor has a lower id, so it is
+// already resident or finished -- no deadlock; the wait is bounded anyway).  The arithmetic is that of the unsliced
+// run, bit for bit.
 constexpr long kMaxPolls = 20000000; // x ~3 us = a minute; a slice takes ~1 ms and waits for one predecessor
 
 __device__ __forceinline__ void wait_for_slice(const KArgs &a, long slot, int seg)
