@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SMART_AMD_ABI_VERSION 1
+#define SMART_AMD_ABI_VERSION 2
 
 /* report_type, as structure.py:65-70 maps report='summary' / 'raw' */
 #define SMART_REPORT_SUMMARY 1
@@ -105,7 +105,11 @@ typedef struct SmartEnsemble {
     double *objfn;         /* [C][N][8] objective functions (montecarlo.py:193-209); needs obs;       */
                            /* column 7 (GW) is NaN where gw_obs is absent                            */
     double *final_vars;    /* [C][N][19] last row of the storage table        (structure.py:197)     */
-    double *workspace;     /* [C][8 + R] scratch, required when objfn != NULL                        */
+    void *workspace;       /* device scratch of workspace_bytes bytes: observation statistics when    */
+                           /* objfn != NULL ([C][8 + R] doubles, required), and the hand-over buffer   */
+                           /* of a time-sliced launch (optional: without room for it the launch is     */
+                           /* not sliced).  smart_workspace_bytes() tells how much both need.          */
+    int64_t workspace_bytes;
 
     void *stream;          /* hipStream_t; NULL = the default stream                                 */
 } SmartEnsemble;
@@ -119,6 +123,12 @@ int smart_run_ensemble_hip(const SmartEnsemble *e);
 
 /* Validation only (no device needed): the checks smart_run_ensemble_hip performs before launching. */
 int smart_check_ensemble(const SmartEnsemble *e);
+
+/* Bytes of device scratch the call wants in e->workspace for these sizes and outputs (pointers are not read):
+ * the observation statistics if e->objfn is set, plus -- on a machine with a HIP device -- the hand-over buffer of
+ * the time-sliced launch the library would choose.  The library allocates nothing itself: the caller owns every
+ * buffer, which also lets the call be captured into a HIP graph. */
+int64_t smart_workspace_bytes(const SmartEnsemble *e);
 
 /*
  * smartcpp.allsteps -- same arguments and results as run_all_steps (structure.py:149-152,197).

@@ -26,7 +26,7 @@ class SmartEnsemble(ctypes.Structure):
         ('area_m2', _dp), ('forcing', _dp), ('params', _dp), ('params_catchment_stride', ctypes.c_int64),
         ('extra', _dp), ('initial', _dp), ('obs', _dp), ('gw_obs', _dp),
         ('discharge', _dp), ('discharge_ld', ctypes.c_int64), ('gw', _dp), ('objfn', _dp),
-        ('final_vars', _dp), ('workspace', _dp), ('stream', _dp),
+        ('final_vars', _dp), ('workspace', _dp), ('workspace_bytes', ctypes.c_int64), ('stream', _dp),
     ]
 
 
@@ -35,6 +35,7 @@ SYMBOLS = {
     'smart_n_reports': (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64, ctypes.c_int32]),
     'smart_run_ensemble_hip': (ctypes.c_int, [ctypes.POINTER(SmartEnsemble)]),
     'smart_check_ensemble': (ctypes.c_int, [ctypes.POINTER(SmartEnsemble)]),
+    'smart_workspace_bytes': (ctypes.c_int64, [ctypes.POINTER(SmartEnsemble)]),
     'smart_allsteps_hip': (ctypes.c_int, [ctypes.c_double, ctypes.c_double, ctypes.c_int64, _dp, _dp, _dp, _dp,
                                           ctypes.c_int32, ctypes.c_int64, _dp, _dp, _dp]),
     'smart_onestep_hip': (ctypes.c_int, [ctypes.c_int64, _dp, _dp]),
@@ -75,7 +76,7 @@ def lib():
             fn = getattr(L, name)       # AttributeError here = the header and the library disagree
             fn.restype = res
             fn.argtypes = args
-        if L.smart_abi_version() != 1:
+        if L.smart_abi_version() != 2:
             raise ImportError("smartpy_amd: ABI version mismatch between smartpy_amd/_lib.py and %s" % LIB_PATH)
         _lib = L
     return _lib

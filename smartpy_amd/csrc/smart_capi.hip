@@ -177,6 +177,22 @@ __global__ __launch_bounds__(WX *WR *kWave) void smart_objfn_matrix(long N, long
     }
 }
 
+// workspace layout: [C][8 + R] doubles of observation statistics (if objfn), then the time-slice hand-over buffer
+static size_t obs_stats_bytes(const SmartEnsemble *e)
+{
+    if (!e->objfn)
+        return 0;
+    const int64_t R = smart_n_reports(e->n_steps, e->report_gap, e->report_type);
+    return (size_t)e->n_catchments * (size_t)(kWsHead + R) * sizeof(double);
+}
+
+static size_t slice_bytes(int64_t n_samples, int64_t n_catchments)
+{
+    const size_t blocks = (size_t)((n_samples + kWave - 1) / kWave) * (size_t)n_catchments;
+    const size_t padded = (blocks + 7) / 8 * 8;
+    return padded * kSegFields * kWave * sizeof(double) + (padded + (size_t)n_catchments + 1) * sizeof(int);
+}
+
 static int check(const SmartEnsemble *e)
 {
     if (!e)
@@ -209,6 +225,9 @@ static int check(const SmartEnsemble *e)
         return fail(SMART_E_SIZE, "discharge_ld must be >= n_samples");
     if (e->objfn && (!e->obs || !e->workspace))
         return fail(SMART_E_NULL, "objfn needs obs and workspace");
+    if (e->objfn && e->workspace_bytes < (int64_t)obs_stats_bytes(e))
+        return fail(SMART_E_SIZE, "workspace_bytes %lld is less than the %lld the observation statistics need",
+                    (long long)e->workspace_bytes, (long long)obs_stats_bytes(e));
     g_err[0] = 0;
     return SMART_OK;
 }
@@ -284,7 +303,7 @@ static int run(const SmartEnsemble *e)
     a.initial = e->initial;
     a.obs = e->obs;
     a.gw_obs = e->gw_obs;
-    a.ws = e->objfn ? e->workspace : nullptr;
+    a.ws = e->objfn ? (const double *)e->workspace : nullptr;
     a.discharge = e->discharge;
     a.ld = e->discharge_ld;
     a.gw = e->gw;
@@ -293,7 +312,7 @@ static int run(const SmartEnsemble *e)
     a.np_mean = e->math_mode == SMART_MATH_LITERAL && e->report_type == SMART_REPORT_SUMMARY && a.gap >= 8 && a.gap <= 128;
 
     if (e->objfn)
-        hipLaunchKernelGGL(smart_obs_prepare, dim3((unsigned)e->n_catchments), dim3(256), 0, s, e->obs, a.R, e->workspace);
+        hipLaunchKernelGGL(smart_obs_prepare, dim3((unsigned)e->n_catchments), dim3(256), 0, s, e->obs, a.R, (double *)e->workspace);
 
     const dim3 grid((unsigned)((a.N + kWave - 1) / kWave), (unsigned)e->n_catchments);
     if (e->math_mode == SMART_MATH_LITERAL) {
@@ -304,41 +323,59 @@ static int run(const SmartEnsemble *e)
 
     int per_simd = 0;
     double load = 0.0; // blocks of 64 samples per SIMD
-    const int n_seg = plan_time_slices(e, a, &per_simd, &load);
+    int n_seg = plan_time_slices(e, a, &per_simd, &load);
     // early exits in the interval engine pay off once the SIMDs have two or more waves to issue from
     // (FastModel::kExits; measured: off wins by 5 % at 1.53 blocks per SIMD, on wins by 4 % at 2.0, by 7 % at 15)
     {
         const char *env = getenv("SMART_EXITS");
         a.exits = env ? atoi(env) != 0 : load >= 1.75;
     }
+    // the hand-over buffer of a time-sliced launch sits behind the observation statistics in the caller's workspace;
+    // a workspace without room for it means a plain launch
+    const size_t stats = obs_stats_bytes(e);
+    if (n_seg > 1 && (!e->workspace || e->workspace_bytes < (int64_t)(stats + slice_bytes(e->n_samples, e->n_catchments))))
+        n_seg = 1;
     if (n_seg <= 1) {
         launch_fast(a, grid, 0, s);
         HIP_TRY(hipGetLastError());
         return SMART_OK;
     }
-    // time-sliced launch (smart_device.h): hand-over states and completion flags live in a stream-ordered scratch
-    // allocation; dynamic LDS is requested only to cap the resident workgroups at `per_simd` per SIMD
+    // time-sliced launch (smart_device.h); dynamic LDS is requested only to cap the resident workgroups at `per_simd`
+    // per SIMD (working + waiting; beyond 3 the register file is the limit anyway)
     a.n_seg = n_seg;
     a.n_catch = e->n_catchments;
     a.n_blocks = grid.x;
     a.seg_blocks = (a.n_blocks * a.n_catch + 7) / 8 * 8;
-    const size_t state_bytes = (size_t)a.seg_blocks * kSegFields * kWave * sizeof(double);
-    const size_t flag_bytes = (size_t)(a.seg_blocks + a.n_catch + 1) * sizeof(int);
-    char *scratch = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&scratch, state_bytes + flag_bytes, s));
+    char *scratch = (char *)e->workspace + stats;
     a.seg_state = (double *)scratch;
-    a.seg_flag = (int *)(scratch + state_bytes);
-    HIP_TRY(hipMemsetAsync(a.seg_flag, 0, flag_bytes, s));
-    // per_simd working + waiting workgroups per SIMD: beyond 3 the register file is the limit anyway
+    a.seg_flag = (int *)(scratch + (size_t)a.seg_blocks * kSegFields * kWave * sizeof(double));
     const size_t lds_bytes = per_simd <= 3 ? fast_lds_for_residency(4 * per_simd) : 0;
     if (getenv("SMART_DEBUG"))
         fprintf(stderr, "smart_amd: time-sliced launch, %d slices x %ld blocks, %d resident per SIMD (dynamic LDS %zu B)\n",
                 n_seg, (long)(a.n_blocks * a.n_catch), per_simd, lds_bytes);
     launch_fast(a, dim3((unsigned)(a.seg_blocks * n_seg), 1), lds_bytes, s);
-    hipError_t err = hipGetLastError();
-    HIP_TRY(hipFreeAsync(scratch, s));
-    HIP_TRY(err);
+    HIP_TRY(hipGetLastError());
     return SMART_OK;
+}
+
+static int64_t workspace_bytes(const SmartEnsemble *e)
+{
+    if (!e || e->n_catchments < 1 || e->n_samples < 1 || e->n_steps < 0 || e->report_gap < 1)
+        return 0;
+    size_t need = obs_stats_bytes(e);
+    if (e->math_mode == SMART_MATH_FAST) {
+        KArgs a;
+        a.N = e->n_samples;
+        a.W = e->n_warm;
+        a.gap = e->report_gap;
+        a.R = smart_n_reports(e->n_steps, e->report_gap, e->report_type);
+        int per_simd = 0;
+        double load = 0.0;
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) == hipSuccess && n_dev > 0 && plan_time_slices(e, a, &per_simd, &load) > 1)
+            need += slice_bytes(e->n_samples, e->n_catchments);
+    }
+    return (int64_t)need;
 }
 
 } // namespace smart
@@ -355,6 +392,8 @@ int64_t smart_n_reports(int64_t n_steps, int64_t report_gap, int32_t report_type
 }
 
 int smart_check_ensemble(const SmartEnsemble *e) { return check(e); }
+
+int64_t smart_workspace_bytes(const SmartEnsemble *e) { return workspace_bytes(e); }
 
 int smart_run_ensemble_hip(const SmartEnsemble *e) { return run(e); }
 

@@ -630,6 +630,16 @@ __global__ void smart_forcing_scan(const double2 *__restrict__ forcing, long T, 
         __hip_atomic_store(not_pc + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Zeroes the slice counters and the flags of a time-sliced launch.  A kernel rather than hipMemsetAsync: inside a
+// captured HIP graph the memset node of ROCm 7.2 was not ordered before the ensemble kernel (replays started with the
+// counters of the previous replay: no waiting, stale hand-over states; tools/debug/graph_dbg.py), kernel nodes are.
+__global__ void smart_slice_reset(int *flags, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        flags[i] = 0;
+}
+
 // dynamic LDS that lets exactly `per_cu` workgroups of the ensemble kernel be resident on a CU (0: no such size)
 size_t fast_lds_for_residency(int per_cu)
 {
@@ -658,6 +668,11 @@ size_t fast_lds_for_residency(int per_cu)
 
 void launch_fast(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s)
 {
+    if (a.n_seg > 1) {
+        const long n_flags = a.seg_blocks + a.n_catch + 1;
+        hipLaunchKernelGGL(smart_slice_reset, dim3((unsigned)((n_flags + 255) / 256)), dim3(256), 0, s, a.seg_flag,
+                           n_flags);
+    }
     if (a.n_seg > 1)
         hipLaunchKernelGGL(smart_forcing_scan, dim3(64, (unsigned)a.n_catch), dim3(256), 0, s,
                            reinterpret_cast<const double2 *>(a.forcing), a.T, a.gap, a.seg_flag + a.seg_blocks);

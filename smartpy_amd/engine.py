@@ -211,7 +211,6 @@ def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report
     gw = torch.empty((C, N), dtype=torch.float64, device=device)
     objfn = torch.empty((C, N, 8), dtype=torch.float64, device=device) if want_objfn else None
     fin = torch.empty((C, N, 19), dtype=torch.float64, device=device) if want_final else None
-    ws = torch.empty((C, 8 + R), dtype=torch.float64, device=device) if want_objfn else None
 
     def ptr(t):
         return None if t is None else t.data_ptr()
@@ -222,7 +221,11 @@ def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report
     e.area_m2, e.forcing, e.params, e.params_catchment_stride = ptr(area), ptr(forcing), ptr(params), pstride
     e.extra, e.initial, e.obs, e.gw_obs = ptr(extra), ptr(initial), ptr(obs), ptr(gw_obs)
     e.discharge, e.discharge_ld, e.gw, e.objfn = ptr(dis), ld, ptr(gw), ptr(objfn)
-    e.final_vars, e.workspace = ptr(fin), ptr(ws)
+    e.final_vars = ptr(fin)
+    # the caller owns every buffer, the library's scratch included: observation statistics + slice hand-over
+    n_ws = int(L.smart_workspace_bytes(ctypes.byref(e)))
+    ws = torch.empty((n_ws + 7) // 8, dtype=torch.float64, device=device) if n_ws > 0 else None
+    e.workspace, e.workspace_bytes = ptr(ws), n_ws
     with torch.cuda.device(device):
         e.stream = torch.cuda.current_stream(device).cuda_stream
         _lib.check(L.smart_run_ensemble_hip(ctypes.byref(e)))

@@ -672,3 +672,32 @@ def test_randomized_interval_engine(eng, monkeypatch):
             fin = np.isfinite(want[:, :7]).all(axis=1)
             assert rel(got[fin, :7], want[fin, :7], floor=1e-12) <= 1e-7, tag
     assert worst < 1e-10
+
+
+def test_launch_captures_into_a_hip_graph(eng, example):
+    """With every input resident on the device the call is pure stream work -- kernels plus, for a time-sliced launch,
+    a stream-ordered allocation, a memset and a free -- so it captures into a HIP graph and replays to the same bits."""
+    import torch
+    dev = torch.device('cuda:0')
+    T, W = 24 * 200, 24 * 20
+    f = torch.as_tensor(forcing_of(example['rain_hourly'][:T], example['peva_hourly'][:T]), device=dev)
+    obs = torch.as_tensor(example['flow_obs'][:T // 24], device=dev)
+    area = torch.tensor([example['area']], dtype=torch.float64, device=dev)
+    ex = example['extra']
+    extra = torch.tensor([[ex['aar'], ex['r-o_ratio']] + list(ex['r-o_split'])], dtype=torch.float64, device=dev)
+    gwo = torch.tensor([0.12667], dtype=torch.float64, device=dev)
+    for n in (300, 70000):                  # plain launch; time-sliced launch (1,094 blocks > 1,024 SIMDs)
+        params = torch.as_tensor(lhs_oracle.lhs_params(n, seed=3), device=dev)
+        kw = dict(extra=extra, obs=obs, gw_obs=gwo, want_discharge=False)
+        ref = eng.run_ensemble(params, f, area, 3600.0, W, 24, **kw)
+        torch.cuda.synchronize()
+        graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                out = eng.run_ensemble(params, f, area, 3600.0, W, 24, **kw)
+        for _ in range(3):
+            out.objfn.zero_()
+            out.gw.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out.objfn, ref.objfn) and torch.equal(out.gw, ref.gw)

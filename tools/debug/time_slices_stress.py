@@ -1,4 +1,5 @@
-"""Repeat the time-sliced launch and compare every result with the unsliced one bit for bit."""
+"""Repeat the time-sliced launch and compare every result with the unsliced one bit for bit (the output buffers are
+poisoned before every launch: a row that was not written cannot pass for the previous launch's)."""
 import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np
@@ -27,6 +28,8 @@ os.environ.pop('SMART_TIME_SLICES')
 bad = 0
 t0 = time.perf_counter()
 for i in range(reps):
+    poison = torch.full((n * 12,), float('nan'), dtype=torch.float64, device=dev)      # what torch.empty hands out next
+    del poison
     out = engine.run_ensemble(params, ft, 175.46e6, 3600.0, W, 24, extra=extra, obs=obs, gw_obs=0.12667, want_discharge=False)
     if not (torch.equal(out.gw.view(torch.int64), ref[0].view(torch.int64)) and torch.equal(out.objfn.view(torch.int64), ref[1].view(torch.int64))):
         bad += 1
