@@ -78,7 +78,18 @@ def test_validation_and_error_codes_without_a_device(L):
     assert L.smart_check_ensemble(ctypes.byref(e)) == 0 and L.smart_last_error() == b''
     e.objfn = ctypes.addressof(buf)
     assert L.smart_check_ensemble(ctypes.byref(e)) == -1                      # objfn needs obs + workspace
+    # the workspace is the caller's: smart_workspace_bytes says how much, the check refuses less
+    assert L.smart_workspace_bytes(None) == 0
+    R = L.smart_n_reports(e.n_steps, e.report_gap, e.report_type)
+    e.obs = e.workspace = ctypes.addressof(buf)
+    need = L.smart_workspace_bytes(ctypes.byref(e))
+    assert need >= 8 * (8 + R)                 # observation statistics (+ slice hand-over where a device says so)
+    e.workspace_bytes = 8 * (8 + R) - 8
+    assert L.smart_check_ensemble(ctypes.byref(e)) == -2 and b'workspace_bytes' in L.smart_last_error()
+    e.workspace_bytes = need
+    assert L.smart_check_ensemble(ctypes.byref(e)) == 0
     e.objfn = None
+    assert L.smart_workspace_bytes(ctypes.byref(e)) in (0, need - 8 * (8 + R))
     e.discharge, e.discharge_ld = ctypes.addressof(buf), 5
     assert L.smart_check_ensemble(ctypes.byref(e)) == -2
 
