@@ -463,6 +463,9 @@ __device__ __forceinline__ void interval_loop_obs(const double2 *__restrict__ f,
 // slice s - 1 left in `seg_state`; it waits for `seg_flag[slot] >= s` (its predecessor has a lower id, so it is
 // already resident or finished -- no deadlock; the wait is bounded anyway).  The arithmetic is that of the unsliced
 // run, bit for bit.
+#ifndef SMART_POLL_SLEEP
+#define SMART_POLL_SLEEP 100
+#endif
 constexpr long kMaxPolls = 20000000; // x ~3 us = a minute; a slice takes ~1 ms and waits for one predecessor
 
 __device__ __forceinline__ void wait_for_slice(const KArgs &a, long slot, int seg)
@@ -470,7 +473,7 @@ __device__ __forceinline__ void wait_for_slice(const KArgs &a, long slot, int se
     int *flag = a.seg_flag + slot;
     long polls = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
-        __builtin_amdgcn_s_sleep(100);
+        __builtin_amdgcn_s_sleep(SMART_POLL_SLEEP);
         if (++polls > kMaxPolls) { // never seen; leaves a mark instead of a hung GPU
             __hip_atomic_store(a.seg_flag + a.seg_blocks + a.n_catch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
