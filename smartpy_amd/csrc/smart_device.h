@@ -593,7 +593,14 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
 
     if (last) {
         m.balance_sums(q_out_total, num, den);
-        write_results(a, x, m, rep, num / den);
+        double gw = num / den;
+        // a slice that gave up waiting (never seen; wait_for_slice) must not pass for a result: NaN for the whole launch
+        if (a.n_seg > 1 &&
+            __hip_atomic_load(a.seg_flag + a.seg_blocks + a.n_catch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            gw = __builtin_bit_cast(double, 0x7ff8000000000000ull);
+            rep.A = rep.B = rep.C1 = rep.C2 = rep.C3 = gw;
+        }
+        write_results(a, x, m, rep, gw);
     } else {
         m.save_state(hand, kWave);
         hand[14 * kWave] = q_out_total;
