@@ -589,6 +589,15 @@ def test_time_sliced_launch_is_bit_identical(eng, example, monkeypatch, n_slices
         assert bits_equal(cut.discharge.cpu().numpy(), plain.discharge.cpu().numpy())
         assert bits_equal(cut.gw.cpu().numpy(), plain.gw.cpu().numpy())
         assert np.array_equal(cut.objfn.cpu().numpy(), plain.objfn.cpu().numpy(), equal_nan=True)
+    # per-catchment parameter blocks and given initial states, sliced against plain
+    p3 = np.stack([lhs_oracle.lhs_params(130, seed=s) for s in (7, 8, 9)])
+    init = np.abs(rng.normal(1e4, 5e3, (3, 130, 12)))
+    monkeypatch.setenv('SMART_TIME_SLICES', '0')
+    plain3 = eng.run_ensemble(p3, np.stack(fs), [60e6, 175.46e6, 900e6], 3600.0, W, 24, initial=init, obs=obs)
+    monkeypatch.setenv('SMART_TIME_SLICES', str(n_slices))
+    cut3 = eng.run_ensemble(p3, np.stack(fs), [60e6, 175.46e6, 900e6], 3600.0, W, 24, initial=init, obs=obs)
+    assert bits_equal(cut3.discharge.cpu().numpy(), plain3.discharge.cpu().numpy())
+    assert np.array_equal(cut3.objfn.cpu().numpy(), plain3.objfn.cpu().numpy(), equal_nan=True)
     # and against the oracle, for the sliced result itself
     dis, gwo, _ = so.run_batch(60e6, 3600.0, T, W, fs[0][:, 0], fs[0][:, 1], params[:40], example['extra'],
                                so.REPORT_SUMMARY, 24)
