@@ -263,7 +263,7 @@ static int plan_time_slices(const SmartEnsemble *e, const KArgs &a, int *per_sim
     const long cap = (blocks + n_simd - 1) / n_simd;
     *per_simd = (int)(cap < 1 ? 1 : cap); // blocks of 64 samples per SIMD, rounded up
     *load = (double)blocks / (double)n_simd;
-    if (e->report_type != SMART_REPORT_SUMMARY || a.gap < 2 || e->final_vars)
+    if (e->report_type != SMART_REPORT_SUMMARY || a.gap < 2)
         return 1;
     const long n_all = a.W / a.gap + a.R;
     const char *env = getenv("SMART_TIME_SLICES");

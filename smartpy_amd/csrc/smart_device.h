@@ -42,7 +42,7 @@ struct KArgs {
     int *seg_flag = nullptr;     // [seg_blocks] slices completed; then [C] forcing NOT piecewise constant; then [1] error
 };
 
-constexpr int kSegFields = 20;
+constexpr int kSegFields = 22;
 
 #ifndef SMART_NT_STORE
 #define SMART_NT_STORE 0
@@ -539,12 +539,12 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
     if (seg > 0) {
         wait_for_slice(a, slot, seg);
         m.load_state(hand, kWave);
-        q_out_total = hand[14 * kWave];
-        rep.A = hand[15 * kWave];
-        rep.B = hand[16 * kWave];
-        rep.C1 = hand[17 * kWave];
-        rep.C2 = hand[18 * kWave];
-        rep.C3 = hand[19 * kWave];
+        q_out_total = hand[16 * kWave];
+        rep.A = hand[17 * kWave];
+        rep.B = hand[18 * kWave];
+        rep.C1 = hand[19 * kWave];
+        rep.C2 = hand[20 * kWave];
+        rep.C3 = hand[21 * kWave];
     }
 
     // warm-up over the first W steps of the same forcing, only the states survive (structure.py:118-121); then the
@@ -603,12 +603,12 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         write_results(a, x, m, rep, gw);
     } else {
         m.save_state(hand, kWave);
-        hand[14 * kWave] = q_out_total;
-        hand[15 * kWave] = rep.A;
-        hand[16 * kWave] = rep.B;
-        hand[17 * kWave] = rep.C1;
-        hand[18 * kWave] = rep.C2;
-        hand[19 * kWave] = rep.C3;
+        hand[16 * kWave] = q_out_total;
+        hand[17 * kWave] = rep.A;
+        hand[18 * kWave] = rep.B;
+        hand[19 * kWave] = rep.C1;
+        hand[20 * kWave] = rep.C2;
+        hand[21 * kWave] = rep.C3;
         publish_slice(a, slot, seg);
     }
 }

@@ -60,9 +60,12 @@ namespace smart {
 // outflow: (Ua + Ub)' = (Ua + Ub)*dec + (xa + xb)*cq.  Only their sums enter the river inflow (structure.py:254)
 // and the groundwater ratio (:191).  Used when the caller does not ask for the final state vector.
 // EXITS: wave-uniform early exits inside the interval engine's cascades (see kExits below).
-template <bool STIFF, bool GUARD, bool MERGE = false, bool EXITS = true>
+// SPLIT (with MERGE): the drain and the deep-groundwater reservoir are carried next to the two merged totals, for
+// callers that ask for the final state vector; the discharge arithmetic is that of the merged form, bit for bit.
+template <bool STIFF, bool GUARD, bool MERGE = false, bool EXITS = true, bool SPLIT = false>
 struct FastModel {
     static_assert(!(MERGE && STIFF), "the clamps of structure.py:429-450 act on each reservoir separately");
+    static_assert(MERGE || !SPLIT, "SPLIT refines the merged form");
     static constexpr bool kExactDivide = false;
 
     // per-sample constants
@@ -117,7 +120,8 @@ struct FastModel {
             u_ove = (st[0] + st[1]) * m3_to_mm;
             u_int = st[2] * m3_to_mm;
             u_sgw = (st[3] + st[4]) * m3_to_mm;
-            u_dra = u_dgw = 0.0;
+            u_dra = SPLIT ? st[1] * m3_to_mm : 0.0;
+            u_dgw = SPLIT ? st[4] * m3_to_mm : 0.0;
         } else {     // the others as outflows U = V / k
             u_ove = st[0] / k_s;
             u_dra = st[1] / k_s;
@@ -142,11 +146,19 @@ struct FastModel {
 #pragma unroll
         for (int i = 0; i < 7; ++i)
             v[i] = __builtin_nan("");
-        v[7] = MERGE ? u_ove * mm_to_m3 : u_ove * k_s; // (merged: the pair's total; not reachable through the API)
-        v[8] = u_dra * k_s;
-        v[9] = MERGE ? u_int * mm_to_m3 : u_int * k_f;
-        v[10] = MERGE ? u_sgw * mm_to_m3 : u_sgw * k_g;
-        v[11] = u_dgw * k_g;
+        if (MERGE) { // totals and (SPLIT) their drain / deep parts, in mm; without SPLIT the pairs stay merged
+            v[7] = (u_ove - u_dra) * mm_to_m3;
+            v[8] = u_dra * mm_to_m3;
+            v[9] = u_int * mm_to_m3;
+            v[10] = (u_sgw - u_dgw) * mm_to_m3;
+            v[11] = u_dgw * mm_to_m3;
+        } else {
+            v[7] = u_ove * k_s;
+            v[8] = u_dra * k_s;
+            v[9] = u_int * k_f;
+            v[10] = u_sgw * k_g;
+            v[11] = u_dgw * k_g;
+        }
         v[12] = l0 * mm_to_m3;
         v[13] = l1 * mm_to_m3;
         v[14] = l2 * mm_to_m3;
@@ -278,6 +290,7 @@ struct FastModel {
     // instead of 36 + 1 + 5; the differences cost <= 1e-13 relative on a step's flows (levels ~1e2 mm, leaks
     // >= 1e-3 mm), unbiased.  Filling as t = l + ex; l = min(t, z); ex = t - l (3 instead of 4 per layer).
     static constexpr bool kLeakBalance = SMART_FAST_LEAK_BALANCE && MERGE && !GUARD;
+    static_assert(kLeakBalance || !SPLIT, "SPLIT is implemented in wet_balance()");
 
     // Wave-uniform early exits in the filling cascade of a wet step (no lane has excess left after the top layer: 32 %
     // of the wet steps) and in the evaporation cascade of a dry interval.  They trade ~5 vector instructions per step
@@ -321,6 +334,7 @@ struct FastModel {
         l3 = fma(-l3, s1 * 0.25, l3);
         l4 = fma(-l4, s1 * 0.2, l4);
         l5 = fma(-l5, s1 * (1.0 / 6.0), l5);
+        const double after_sgw = SPLIT ? layer_sum() : 0.0; // SPLIT: the deep leak is what the third pass takes
         l0 = fma(-l0, p6, l0);
         l1 = fma(-l1, p5, l1);
         l2 = fma(-l2, p4, l2);
@@ -336,6 +350,10 @@ struct FastModel {
         asm("v_add_f64 %0, %1, %2" : "+v"(tot) : "v"(upper), "v"(lower)); // tot = layer sum after the step, in place
         const double xg = after_int - tot;
         fma_in_place(u_sgw, dec_g, xg);
+        if (SPLIT) {
+            fma_in_place(u_dra, dec_s, pD * rem);
+            fma_in_place(u_dgw, dec_g, after_sgw - tot);
+        }
         if (kBalanceSums)
             xg_sum += xg;
     }
@@ -383,7 +401,7 @@ struct FastModel {
         u_ove = clamp(u_ove * dec_s);
         u_int = clamp(u_int * dec_f);
         u_sgw = clamp(u_sgw * dec_g);
-        if (!MERGE) {
+        if (!MERGE || SPLIT) {
             u_dra = clamp(u_dra * dec_s);
             u_dgw = clamp(u_dgw * dec_g);
         }
@@ -425,23 +443,26 @@ struct FastModel {
     }
 
     // hand-over between two slices of a time-sliced launch (merged variant: 10 states + 3 balance terms)
+    static constexpr int kStateFields = 15;
+
     __device__ void save_state(double *p, int stride) const
     {
-        const double v[13] = {l0, l1, l2, l3, l4, l5, u_ove, u_int, u_sgw, u_riv, g0, r0, xg_sum};
+        const double v[kStateFields] = {l0, l1, l2, l3, l4, l5, u_ove, u_int, u_sgw, u_riv, g0, r0, xg_sum, u_dra, u_dgw};
 #pragma unroll
-        for (int i = 0; i < 13; ++i)
+        for (int i = 0; i < (SPLIT ? 15 : 13); ++i)
             p[i * stride] = v[i];
     }
 
     __device__ void load_state(const double *p, int stride)
     {
-        double v[13];
+        double v[kStateFields] = {};
 #pragma unroll
-        for (int i = 0; i < 13; ++i)
+        for (int i = 0; i < (SPLIT ? 15 : 13); ++i)
             v[i] = p[i * stride];
         l0 = v[0], l1 = v[1], l2 = v[2], l3 = v[3], l4 = v[4], l5 = v[5];
         u_ove = v[6], u_int = v[7], u_sgw = v[8], u_riv = v[9];
         g0 = v[10], r0 = v[11], xg_sum = v[12];
+        u_dra = v[13], u_dgw = v[14];
     }
 
     // ---- groundwater ratio without per-step sums (regular merged variant) -------------------------------------
@@ -546,6 +567,10 @@ struct FastModel {
         u_ove *= P_q;
         u_int *= P_i;
         u_sgw *= P_g;
+        if (SPLIT) {
+            u_dra *= P_q;
+            u_dgw *= P_g;
+        }
     }
 };
 
@@ -588,20 +613,29 @@ __global__ __launch_bounds__(kWave, SMART_FAST_MIN_WAVES) void smart_ensemble_fa
         block = slot % a.n_blocks;
     }
     const int cls = wave_class(a, block, c);
-    if (cls == 0 && a.final_vars == nullptr) {
+    if (cls == 0) {
         using Merged = FastModel<false, false, true>;
+        using MergedSplit = FastModel<false, false, true, true, true>; // final state vector asked for
         if (SMART_FAST_INTERVALS && Merged::kIntervals && a.report_type == 1 && a.gap >= 2) {
             const bool piecewise = a.n_seg > 1 ? a.seg_flag[a.seg_blocks + c] == 0 // answered by smart_forcing_scan
                                                : forcing_is_piecewise_constant(forcing + c * a.T, a.T, a.gap);
-            if (piecewise && a.exits)
+            if (a.final_vars) {
+                if (piecewise)
+                    run_ensemble_merged<MergedSplit, true>(a, forcing, obs, ws, block, c, seg);
+                else
+                    run_ensemble_merged<MergedSplit, false>(a, forcing, obs, ws, block, c, seg);
+            } else if (piecewise && a.exits)
                 run_ensemble_merged<Merged, true>(a, forcing, obs, ws, block, c, seg);
             else if (piecewise)
                 run_ensemble_merged<FastModel<false, false, true, false>, true>(a, forcing, obs, ws, block, c, seg);
             else
                 run_ensemble_merged<Merged, false>(a, forcing, obs, ws, block, c, seg);
-        } else if (seg == 0)
+            return;
+        }
+        if (seg == 0 && a.final_vars == nullptr) {
             run_ensemble<Merged, false>(a, forcing, obs, ws, nullptr, block, c);
-        return;
+            return;
+        }
     }
     if (seg != 0)
         return;

@@ -710,3 +710,39 @@ def test_launch_captures_into_a_hip_graph(eng, example):
             graph.replay()
             torch.cuda.synchronize()
             assert torch.equal(out.objfn, ref.objfn) and torch.equal(out.gw, ref.gw)
+
+
+def test_final_states_do_not_change_the_discharge(eng, example, monkeypatch):
+    """Asking for the final state vector selects the SPLIT refinement of the merged variant (drain and deep
+    groundwater reservoirs carried next to the merged totals): same discharge, bit for bit; states against the
+    oracle; and the same through a time-sliced launch."""
+    params = lhs_oracle.lhs_params(200, seed=41)
+    T, W = 24 * 400, 24 * 60
+    f = forcing_of(example['rain_hourly'][:T], example['peva_hourly'][:T])
+    kw = dict(extra=example['extra'], obs=example['flow_obs'][:T // 24], gw_obs=0.12667)
+    monkeypatch.setenv('SMART_TIME_SLICES', '0')
+    a = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, **kw)
+    b = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, want_final=True, **kw)
+    assert bits_equal(a.discharge.cpu().numpy(), b.discharge.cpu().numpy())
+    assert bits_equal(a.gw.cpu().numpy(), b.gw.cpu().numpy()) and torch_equal(a.objfn, b.objfn)
+    _, _, fin = so.run_batch(example['area'], 3600.0, T, W, example['rain_hourly'], example['peva_hourly'], params,
+                             example['extra'], so.REPORT_SUMMARY, 24, want_final=True)
+    assert rel(b.final_vars.cpu().numpy()[:, 7:], fin[:, 7:], floor=1e-290) <= 1e-9
+    monkeypatch.setenv('SMART_TIME_SLICES', '6')
+    c = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, want_final=True, **kw)
+    assert bits_equal(c.discharge.cpu().numpy(), b.discharge.cpu().numpy())
+    assert bits_equal(c.final_vars.cpu().numpy()[:, 7:], b.final_vars.cpu().numpy()[:, 7:])
+    # forcing that varies inside the day: the step loop of the same variant
+    f2 = f.copy()
+    f2[::7, 0] *= 1.5
+    d = eng.run_ensemble(params, f2, example['area'], 3600.0, W, 24, **kw)
+    e = eng.run_ensemble(params, f2, example['area'], 3600.0, W, 24, want_final=True, **kw)
+    assert bits_equal(d.discharge.cpu().numpy(), e.discharge.cpu().numpy())
+    _, _, fin2 = so.run_batch(example['area'], 3600.0, T, W, f2[:, 0].copy(), f2[:, 1].copy(), params,
+                              example['extra'], so.REPORT_SUMMARY, 24, want_final=True)
+    assert rel(e.final_vars.cpu().numpy()[:, 7:], fin2[:, 7:], floor=1e-290) <= 1e-9
+
+
+def torch_equal(a, b):
+    import torch
+    return torch.equal(a, b)
