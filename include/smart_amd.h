@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SMART_AMD_ABI_VERSION 2
+#define SMART_AMD_ABI_VERSION 3
 
 /* report_type, as structure.py:65-70 maps report='summary' / 'raw' */
 #define SMART_REPORT_SUMMARY 1
@@ -63,6 +63,24 @@ extern "C" {
 #define SMART_E_NO_DEVICE (-6)   /* no HIP device / HIP runtime error (text in smart_last_error)        */
 #define SMART_E_MODE (-7)        /* unknown math mode                                                   */
 #define SMART_E_IO (-8)          /* a database file could not be opened / written                       */
+
+/* plan bits (smart_plan_ensemble, SmartEnsemble.plan): what the rows and the forcing of a call need.  The fast mode
+ * is a family of kernels, one per arithmetic class of a block of 64 parameter rows and per kind of forcing; a plan
+ * lets a launch skip the kernels that would find nothing to do. */
+#define SMART_PLAN_CLASS_REGULAR 0x01    /* rows with every k*3600 >= delta_sec, 0 <= S <= 0.5, C >= 0, Z > 0    */
+#define SMART_PLAN_CLASS_STIFF 0x02      /* some k*3600 < delta_sec: clamps (structure.py:429-450) and the river's */
+                                         /* 95 % rule (:492-496) are reachable                                     */
+#define SMART_PLAN_CLASS_GUARD 0x04      /* S, C or Z outside those ranges: the leak guards (:383,390,397) matter  */
+#define SMART_PLAN_CLASS_ILLCOND 0x08    /* some delta_sec / (k*3600) > 2: run in the literal arithmetic           */
+#define SMART_PLAN_FORCING_PIECEWISE 0x10 /* a catchment whose forcing is constant within every report interval    */
+#define SMART_PLAN_FORCING_VARYING 0x20   /* a catchment whose forcing is not                                      */
+#define SMART_PLAN_VALID 0x100
+
+/* status bits of a finished launch (smart_launch_status) */
+#define SMART_STATUS_SLICE_TIMEOUT 0x1 /* a time slice gave up waiting for its predecessor: the block's outputs are */
+                                       /* NaN from that slice on; repeat the launch with time_slices = 1            */
+#define SMART_STATUS_STALE_PLAN 0x2    /* the plan did not cover a class / kind of forcing met on the device: those  */
+                                       /* rows were NOT computed; repeat the launch with plan = 0                    */
 
 /*
  * One ensemble launch = the whole per-sample loop that spotpy's sampler drives
@@ -112,6 +130,12 @@ typedef struct SmartEnsemble {
     int64_t workspace_bytes;
 
     void *stream;          /* hipStream_t; NULL = the default stream                                 */
+
+    /* ---- launch control (ABI 3; zero = the library decides) ------------------------------------- */
+    int32_t time_slices;   /* 0: the library's choice (slices the time axis of launches with more blocks  */
+                           /* of 64 samples than SIMDs); 1: never slice; n > 1: n slices                   */
+    int32_t plan;          /* SMART_PLAN_* bits from smart_plan_ensemble for these params / forcing /      */
+                           /* sizes, or 0: launch every kernel the call could need                         */
 } SmartEnsemble;
 
 /* Number of report steps R for a run (structure.py:190 / :193): T // g (summary), ceil(T / g) (raw). */
@@ -125,10 +149,20 @@ int smart_run_ensemble_hip(const SmartEnsemble *e);
 int smart_check_ensemble(const SmartEnsemble *e);
 
 /* Bytes of device scratch the call wants in e->workspace for these sizes and outputs (pointers are not read):
- * the observation statistics if e->objfn is set, plus -- on a machine with a HIP device -- the hand-over buffer of
- * the time-sliced launch the library would choose.  The library allocates nothing itself: the caller owns every
- * buffer, which also lets the call be captured into a HIP graph. */
+ * a header (status word, counters, per-catchment forcing flags), the observation statistics if e->objfn is set,
+ * plus -- on a machine with a HIP device -- the hand-over buffer of the time-sliced launch the library would
+ * choose.  The library allocates nothing itself: the caller owns every buffer, which also lets the call be captured
+ * into a HIP graph.  A launch without a workspace runs unsliced and reports no status. */
 int64_t smart_workspace_bytes(const SmartEnsemble *e);
+
+/* Classify the parameter rows and the forcing of a SMART_MATH_FAST call on the device (two small kernels on
+ * e->stream, then SYNCHRONOUS: the answer is copied back): *plan = SMART_PLAN_VALID | the SMART_PLAN_* bits present.
+ * Valid for as long as params, forcing, delta_sec, report_gap and the sizes do not change.  Needs e->workspace. */
+int smart_plan_ensemble(const SmartEnsemble *e, int32_t *plan);
+
+/* Status word of the last launch that used e->workspace (SMART_STATUS_* bits, 0 = clean).  SYNCHRONOUS: waits for
+ * e->stream.  0 without a workspace. */
+int smart_launch_status(const SmartEnsemble *e, int32_t *status);
 
 /*
  * smartcpp.allsteps -- same arguments and results as run_all_steps (structure.py:149-152,197).

@@ -13,6 +13,11 @@ LIB_PATH = os.environ.get('SMART_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libsm
 
 REPORT_SUMMARY, REPORT_RAW = 1, 2
 MATH_LITERAL, MATH_FAST = 0, 1
+ABI_VERSION = 3
+PLAN_VALID = 0x100
+PLAN_CLASS_BITS = {0: 0x01, 1: 0x02, 2: 0x04, 3: 0x08}     # regular, stiff, guard, ill-conditioned
+PLAN_FORCING_PIECEWISE, PLAN_FORCING_VARYING = 0x10, 0x20
+STATUS_SLICE_TIMEOUT, STATUS_STALE_PLAN = 0x1, 0x2
 
 _dp = ctypes.c_void_p   # device or host address, passed as an integer
 
@@ -27,6 +32,7 @@ class SmartEnsemble(ctypes.Structure):
         ('extra', _dp), ('initial', _dp), ('obs', _dp), ('gw_obs', _dp),
         ('discharge', _dp), ('discharge_ld', ctypes.c_int64), ('gw', _dp), ('objfn', _dp),
         ('final_vars', _dp), ('workspace', _dp), ('workspace_bytes', ctypes.c_int64), ('stream', _dp),
+        ('time_slices', ctypes.c_int32), ('plan', ctypes.c_int32),
     ]
 
 
@@ -36,6 +42,8 @@ SYMBOLS = {
     'smart_run_ensemble_hip': (ctypes.c_int, [ctypes.POINTER(SmartEnsemble)]),
     'smart_check_ensemble': (ctypes.c_int, [ctypes.POINTER(SmartEnsemble)]),
     'smart_workspace_bytes': (ctypes.c_int64, [ctypes.POINTER(SmartEnsemble)]),
+    'smart_plan_ensemble': (ctypes.c_int, [ctypes.POINTER(SmartEnsemble), ctypes.POINTER(ctypes.c_int32)]),
+    'smart_launch_status': (ctypes.c_int, [ctypes.POINTER(SmartEnsemble), ctypes.POINTER(ctypes.c_int32)]),
     'smart_allsteps_hip': (ctypes.c_int, [ctypes.c_double, ctypes.c_double, ctypes.c_int64, _dp, _dp, _dp, _dp,
                                           ctypes.c_int32, ctypes.c_int64, _dp, _dp, _dp]),
     'smart_onestep_hip': (ctypes.c_int, [ctypes.c_int64, _dp, _dp]),
@@ -76,7 +84,7 @@ def lib():
             fn = getattr(L, name)       # AttributeError here = the header and the library disagree
             fn.restype = res
             fn.argtypes = args
-        if L.smart_abi_version() != 2:
+        if L.smart_abi_version() != ABI_VERSION:
             raise ImportError("smartpy_amd: ABI version mismatch between smartpy_amd/_lib.py and %s" % LIB_PATH)
         _lib = L
     return _lib

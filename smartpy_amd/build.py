@@ -7,6 +7,7 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
@@ -19,12 +20,14 @@ UNITS = {
     # the literal model inside the fast kernel opts out of contraction per function (pragma); no NaN ever enters the
     # arithmetic (missing observations are tested on their bit pattern), which spares the sNaN-quieting
     # `v_max_f64 x, x, x` hipcc otherwise puts in front of fmin / fmax (-1.2 % kernel time, A/B measured)
-    'smart_fast.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
+    'smart_fast_intervals.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
+    'smart_fast_steps.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
+    'smart_fast_guarded.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
     'smart_capi.hip': [],
     'smart_hostio.cpp': ['-pthread'],      # host only: the sampling-database writer
 }
 COMMON = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-fno-gpu-rdc', '-Wall']
-DEPS = ['smart_device.h', 'smart_literal_model.h', os.path.join('..', '..', 'include', 'smart_amd.h')]
+DEPS = ['smart_device.h', 'smart_literal_model.h', 'smart_fast_model.h', 'smart_fast_entry.h', os.path.join('..', '..', 'include', 'smart_amd.h')]
 
 
 def hipcc():
@@ -44,17 +47,20 @@ def _stale(target, sources):
 def build(force=False, verbose=False, extra_flags=(), lib_path=LIB):
     cc = hipcc()
     deps = [os.path.join(CSRC, d) for d in DEPS] + [os.path.abspath(__file__)]
-    objs = []
+    objs, jobs = [], []
     suffix = '' if lib_path == LIB else '.' + os.path.basename(lib_path)
     for unit, flags in UNITS.items():
         src = os.path.join(CSRC, unit)
         obj = os.path.join(CSRC, os.path.splitext(unit)[0] + suffix + '.o')
         if force or _stale(obj, [src] + deps):
-            cmd = [cc] + COMMON + flags + list(extra_flags) + ['-c', src, '-o', obj]
-            if verbose:
-                print(' '.join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append([cc] + COMMON + flags + list(extra_flags) + ['-c', src, '-o', obj])
         objs.append(obj)
+    if jobs:        # the translation units are independent: compile them side by side
+        if verbose:
+            for cmd in jobs:
+                print(' '.join(cmd))
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(subprocess.check_call, jobs))
     if force or _stale(lib_path, objs):
         cmd = [cc, '-shared', '-fPIC', '-pthread', '--offload-arch=' + ARCH, '-o', lib_path] + objs
         if verbose:

@@ -1,21 +1,23 @@
 // smart_capi.hip -- the C ABI of include/smart_amd.h: validation, launch plumbing, and the two small
 // kernels around the ensemble launch (observation statistics, objective functions of a stored matrix).
 #include "../../include/smart_amd.h"
-#include "smart_device.h"
+#include "smart_fast_entry.h"
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace smart {
 void launch_literal(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s);
 void launch_onestep(long n, const double *in, double *out, hipStream_t s);
 void launch_river(long n, const double *in, double *out, hipStream_t s);
-void launch_fast(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s);
-size_t fast_lds_for_residency(int per_cu);
+
+static_assert(kStatusSliceTimeout == SMART_STATUS_SLICE_TIMEOUT && kStatusStalePlan == SMART_STATUS_STALE_PLAN,
+              "status bits of smart_device.h and include/smart_amd.h");
 
 static thread_local char g_err[512] = "";
 
@@ -177,7 +179,125 @@ __global__ __launch_bounds__(WX *WR *kWave) void smart_objfn_matrix(long N, long
     }
 }
 
-// workspace layout: [C][8 + R] doubles of observation statistics (if objfn), then the time-slice hand-over buffer
+// ---- small kernels around the launch -------------------------------------------------------------------------
+// The piecewise-constant question (interval engine or step loop?) is answered once per catchment, by the whole chip,
+// before the ensemble kernels start.  not_pc[c] is zeroed by smart_workspace_reset; any step that differs from the
+// first step of its report interval sets it.
+__global__ void smart_forcing_scan(const double2 *__restrict__ forcing, long T, long gap, int *not_pc)
+{
+    const double2 *__restrict__ f = forcing + (long)blockIdx.y * T;
+    bool same = true;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (long)gridDim.x * blockDim.x) {
+        const double2 v = f[t], h = f[(t / gap) * gap];
+        same = same && same_bits(v.x, h.x) && same_bits(v.y, h.y);
+    }
+    if (__builtin_amdgcn_ballot_w64(!same) != 0 && (threadIdx.x & (kWave - 1)) == 0)
+        __hip_atomic_store(not_pc + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Zeroes the header (status word, tickets), the forcing flags and the slice counters.  A kernel rather than
+// hipMemsetAsync: inside a captured HIP graph the memset node of ROCm 7.2 was not ordered before the ensemble kernel
+// (replays started with the counters of the previous replay; tools/debug/graph_dbg.py), kernel nodes are.
+__global__ void smart_workspace_reset(int *hdr, long n_hdr, int *flags, long n_flags)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_hdr)
+        hdr[i] = 0;
+    if (i < n_flags)
+        flags[i] = 0;
+}
+
+// smart_plan_ensemble: the arithmetic classes present among the blocks of 64 rows, and the kinds of forcing
+constexpr int kHdrPlan = 8;
+
+__global__ __launch_bounds__(kWave) void smart_classify_rows(KArgs a)
+{
+    const int cls = wave_class(a, (long)blockIdx.x, (long)blockIdx.y);
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_or(a.hdr + kHdrPlan, 1 << cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void smart_classify_forcing(const int *not_pc, long n_catch, int *hdr)
+{
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_catch)
+        __hip_atomic_fetch_or(hdr + kHdrPlan, not_pc[c] ? SMART_PLAN_FORCING_VARYING : SMART_PLAN_FORCING_PIECEWISE,
+                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- per-device context: what the library caches about a device, and the streams a multi-kernel launch forks onto
+constexpr int kMaxDevices = 64, kMaxAux = 4;
+
+struct DeviceCtx {
+    std::once_flag once;
+    int n_simd = 0;
+    std::mutex mu; // guards everything below
+    hipStream_t aux[kMaxAux] = {};
+    hipEvent_t fork = nullptr, join[kMaxAux] = {};
+    size_t lds_size[kNumFastKernels][17] = {};
+    bool lds_known[kNumFastKernels][17] = {};
+};
+
+static DeviceCtx g_dev[kMaxDevices];
+
+static DeviceCtx *device_ctx()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+        return nullptr;
+    DeviceCtx *d = &g_dev[dev];
+    std::call_once(d->once, [d, dev] {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            d->n_simd = cus * 4;
+    });
+    return d->n_simd > 0 ? d : nullptr;
+}
+
+static const void *fast_kernel(FastKernel k)
+{
+    if (const void *f = fast_kernel_intervals(k))
+        return f;
+    if (const void *f = fast_kernel_steps(k))
+        return f;
+    return fast_kernel_guarded(k);
+}
+
+static const char *const kFastKernelNames[kNumFastKernels] = {
+    "smart_fast_intervals_exits", "smart_fast_intervals", "smart_fast_intervals_states", "smart_fast_steps",
+    "smart_fast_steps_states", "smart_fast_plain", "smart_fast_stiff", "smart_fast_guard", "smart_fast_illcond"};
+
+// dynamic LDS that lets exactly `per_cu` workgroups of kernel k be resident on a CU (0: no such size); d->mu held
+static size_t lds_for_residency(DeviceCtx *d, FastKernel k, int per_cu)
+{
+    if (per_cu < 1 || per_cu > 16)
+        return 0;
+    if (!d->lds_known[k][per_cu]) {
+        size_t found = 0;
+        for (size_t x = (size_t)(160 * 1024 / per_cu) / 256 * 256;
+             x >= 1024 && x > (size_t)(160 * 1024 / (per_cu + 1)) - 2048; x -= 256) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fast_kernel(k), kWave, x) != hipSuccess)
+                break;
+            if (nb == per_cu) {
+                found = x;
+                break;
+            }
+            if (nb > per_cu)
+                break;
+        }
+        d->lds_size[k][per_cu] = found;
+        d->lds_known[k][per_cu] = true;
+    }
+    return d->lds_size[k][per_cu];
+}
+
+// ---- workspace layout: header | [C][8 + R] observation statistics (if objfn) | time-slice hand-over | slice flags
+static size_t header_bytes(int64_t n_catchments)
+{
+    return ((size_t)(kHdrInts + n_catchments) * sizeof(int) + 255) / 256 * 256;
+}
+
 static size_t obs_stats_bytes(const SmartEnsemble *e)
 {
     if (!e->objfn)
@@ -189,8 +309,7 @@ static size_t obs_stats_bytes(const SmartEnsemble *e)
 static size_t slice_bytes(int64_t n_samples, int64_t n_catchments)
 {
     const size_t blocks = (size_t)((n_samples + kWave - 1) / kWave) * (size_t)n_catchments;
-    const size_t padded = (blocks + 7) / 8 * 8;
-    return padded * kSegFields * kWave * sizeof(double) + (padded + (size_t)n_catchments + 1) * sizeof(int);
+    return blocks * kSegFields * kWave * sizeof(double) + (blocks + 1) / 2 * 2 * sizeof(int);
 }
 
 static int check(const SmartEnsemble *e)
@@ -225,9 +344,13 @@ static int check(const SmartEnsemble *e)
         return fail(SMART_E_SIZE, "discharge_ld must be >= n_samples");
     if (e->objfn && (!e->obs || !e->workspace))
         return fail(SMART_E_NULL, "objfn needs obs and workspace");
-    if (e->objfn && e->workspace_bytes < (int64_t)obs_stats_bytes(e))
-        return fail(SMART_E_SIZE, "workspace_bytes %lld is less than the %lld the observation statistics need",
-                    (long long)e->workspace_bytes, (long long)obs_stats_bytes(e));
+    if (e->objfn && e->workspace_bytes < (int64_t)(header_bytes(e->n_catchments) + obs_stats_bytes(e)))
+        return fail(SMART_E_SIZE, "workspace_bytes %lld is less than the %lld the header and the observation statistics need",
+                    (long long)e->workspace_bytes, (long long)(header_bytes(e->n_catchments) + obs_stats_bytes(e)));
+    if (e->time_slices < 0)
+        return fail(SMART_E_SIZE, "time_slices must be >= 0");
+    if (e->plan != 0 && !(e->plan & SMART_PLAN_VALID))
+        return fail(SMART_E_SIZE, "plan must be 0 or a value returned by smart_plan_ensemble");
     g_err[0] = 0;
     return SMART_OK;
 }
@@ -248,43 +371,59 @@ static int device_ready()
 // ceil(B / S) block-times -- 1e5 samples: 1,563 on 1,024 -> 2 against the 1.53 of a perfect split -- and above the
 // residency limit the launch ends with a tail of whole blocks; sliced 16 ways the hardware dispatcher evens both out
 // (measured -14 % at 1e5 samples, -33 % at 1.4e5, -17 % at 4e5; tools/debug/time_slices_sweep.py).  At or below one
-// block per SIMD there is nothing to even out and the hand-over costs 10 %.  SMART_TIME_SLICES = 0 / n overrides.
-static int plan_time_slices(const SmartEnsemble *e, const KArgs &a, int *per_simd, double *load)
+// block per SIMD there is nothing to even out and the hand-over costs 10 %.  e->time_slices (or, for the tuning
+// scripts under tools/, SMART_TIME_SLICES when that field is 0) overrides.
+static int plan_time_slices(const SmartEnsemble *e, int n_simd, int *per_simd, double *load)
 {
-    static int n_simd = 0;
-    if (!n_simd) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-            return 1;
-        n_simd = cus * 4;
-    }
-    const long blocks = (a.N + kWave - 1) / kWave * e->n_catchments;
+    const long blocks = (e->n_samples + kWave - 1) / kWave * e->n_catchments;
     const long cap = (blocks + n_simd - 1) / n_simd;
     *per_simd = (int)(cap < 1 ? 1 : cap); // blocks of 64 samples per SIMD, rounded up
     *load = (double)blocks / (double)n_simd;
-    if (e->report_type != SMART_REPORT_SUMMARY || a.gap < 2)
+    if (e->report_type != SMART_REPORT_SUMMARY || e->report_gap < 2)
         return 1;
-    const long n_all = a.W / a.gap + a.R;
-    const char *env = getenv("SMART_TIME_SLICES");
-    const int forced = env ? atoi(env) : -1;
-    if (forced == 0 || n_all < 64)
+    const long n_all = e->n_warm / e->report_gap + e->n_steps / e->report_gap;
+    int forced = e->time_slices;
+    if (forced == 0) {
+        const char *env = getenv("SMART_TIME_SLICES");
+        if (env)
+            forced = atoi(env) <= 0 ? 1 : atoi(env);
+    }
+    if (forced == 1 || n_all < 64)
         return 1;
-    if (forced > 0)
+    if (forced > 1)
         return forced < n_all / 4 ? forced : (int)(n_all / 4);
     if (blocks <= n_simd)
         return 1;
     return (int)(n_all / 64 < 16 ? n_all / 64 : 16);
 }
 
-static int run(const SmartEnsemble *e)
+// the pieces of e->workspace
+struct Workspace {
+    int *hdr = nullptr, *not_pc = nullptr;
+    double *stats = nullptr;
+    char *slices = nullptr;
+    size_t slice_room = 0;
+};
+
+static Workspace carve(const SmartEnsemble *e)
 {
-    int rc = check(e);
-    if (rc)
-        return rc;
-    if ((rc = device_ready()))
-        return rc;
-    hipStream_t s = (hipStream_t)e->stream;
+    Workspace w;
+    const size_t hb = header_bytes(e->n_catchments), sb = obs_stats_bytes(e);
+    if (!e->workspace || e->workspace_bytes < (int64_t)hb)
+        return w;
+    char *base = (char *)e->workspace;
+    w.hdr = (int *)base;
+    w.not_pc = w.hdr + kHdrInts;
+    if ((size_t)e->workspace_bytes >= hb + sb) {
+        w.stats = sb ? (double *)(base + hb) : nullptr;
+        w.slices = base + hb + sb;
+        w.slice_room = (size_t)e->workspace_bytes - hb - sb;
+    }
+    return w;
+}
+
+static KArgs kernel_args(const SmartEnsemble *e, const Workspace &w)
+{
     KArgs a;
     a.N = e->n_samples;
     a.T = e->n_steps;
@@ -303,58 +442,170 @@ static int run(const SmartEnsemble *e)
     a.initial = e->initial;
     a.obs = e->obs;
     a.gw_obs = e->gw_obs;
-    a.ws = e->objfn ? (const double *)e->workspace : nullptr;
+    a.ws = e->objfn ? w.stats : nullptr;
     a.discharge = e->discharge;
     a.ld = e->discharge_ld;
     a.gw = e->gw;
     a.objfn = e->objfn;
     a.final_vars = e->final_vars;
     a.np_mean = e->math_mode == SMART_MATH_LITERAL && e->report_type == SMART_REPORT_SUMMARY && a.gap >= 8 && a.gap <= 128;
+    a.n_catch = e->n_catchments;
+    a.n_blocks = (a.N + kWave - 1) / kWave;
+    a.seg_blocks = a.n_blocks * a.n_catch;
+    a.hdr = w.hdr;
+    a.not_pc = nullptr;
+    return a;
+}
+
+static void reset_workspace(const Workspace &w, long n_catch, int *flags, long n_flags, hipStream_t s)
+{
+    const long n_hdr = kHdrInts + n_catch, n = n_hdr > n_flags ? n_hdr : n_flags;
+    hipLaunchKernelGGL(smart_workspace_reset, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.hdr, n_hdr, flags,
+                       n_flags);
+}
+
+static void scan_forcing(const SmartEnsemble *e, const Workspace &w, hipStream_t s)
+{
+    hipLaunchKernelGGL(smart_forcing_scan, dim3(64, (unsigned)e->n_catchments), dim3(256), 0, s,
+                       reinterpret_cast<const double2 *>(e->forcing), (long)e->n_steps, (long)e->report_gap, w.not_pc);
+}
+
+struct Launch {
+    FastKernel k;
+    bool sliced;
+};
+
+static hipError_t launch_kernel(FastKernel k, KArgs a, dim3 grid, size_t lds, hipStream_t s)
+{
+    const double2 *forcing = reinterpret_cast<const double2 *>(a.forcing);
+    const double *obs = a.obs, *ws = a.ws;
+    void *args[] = {&a, &forcing, &obs, &ws};
+    return hipLaunchKernel(fast_kernel(k), grid, dim3(kWave), args, lds, s);
+}
+
+static int run(const SmartEnsemble *e)
+{
+    int rc = check(e);
+    if (rc)
+        return rc;
+    if ((rc = device_ready()))
+        return rc;
+    hipStream_t s = (hipStream_t)e->stream;
+    const Workspace w = carve(e);
+    KArgs a = kernel_args(e, w);
 
     if (e->objfn)
-        hipLaunchKernelGGL(smart_obs_prepare, dim3((unsigned)e->n_catchments), dim3(256), 0, s, e->obs, a.R, (double *)e->workspace);
+        hipLaunchKernelGGL(smart_obs_prepare, dim3((unsigned)e->n_catchments), dim3(256), 0, s, e->obs, a.R, w.stats);
 
-    const dim3 grid((unsigned)((a.N + kWave - 1) / kWave), (unsigned)e->n_catchments);
+    const dim3 grid((unsigned)a.n_blocks, (unsigned)e->n_catchments);
     if (e->math_mode == SMART_MATH_LITERAL) {
+        a.hdr = nullptr;
         launch_literal(a, grid, a.np_mean ? (size_t)a.gap * kWave * sizeof(double) : 0, s);
         HIP_TRY(hipGetLastError());
         return SMART_OK;
     }
 
+    DeviceCtx *d = device_ctx();
+    if (!d)
+        return fail(SMART_E_NO_DEVICE, "cannot query the current HIP device");
+
+    // ---- which kernels does this call need? (smart_fast_entry.h)
+    const bool intervals = e->report_type == SMART_REPORT_SUMMARY && a.gap >= 2; // the merged summary kernels apply
+    const int plan = (e->plan & SMART_PLAN_VALID) ? e->plan : 0x3f;
     int per_simd = 0;
     double load = 0.0; // blocks of 64 samples per SIMD
-    int n_seg = plan_time_slices(e, a, &per_simd, &load);
+    int n_seg = plan_time_slices(e, d->n_simd, &per_simd, &load);
+    // the hand-over buffer of a time-sliced launch sits behind the observation statistics in the caller's workspace;
+    // a workspace without room for it means a plain launch
+    if (n_seg > 1 && (!w.slices || w.slice_room < slice_bytes(e->n_samples, e->n_catchments)))
+        n_seg = 1;
     // early exits in the interval engine pay off once the SIMDs have two or more waves to issue from
     // (FastModel::kExits; measured: off wins by 5 % at 1.53 blocks per SIMD, on wins by 4 % at 2.0, by 7 % at 15)
     {
         const char *env = getenv("SMART_EXITS");
         a.exits = env ? atoi(env) != 0 : load >= 1.75;
     }
-    // the hand-over buffer of a time-sliced launch sits behind the observation statistics in the caller's workspace;
-    // a workspace without room for it means a plain launch
-    const size_t stats = obs_stats_bytes(e);
-    if (n_seg > 1 && (!e->workspace || e->workspace_bytes < (int64_t)(stats + slice_bytes(e->n_samples, e->n_catchments))))
-        n_seg = 1;
-    if (n_seg <= 1) {
-        launch_fast(a, grid, 0, s);
-        HIP_TRY(hipGetLastError());
+    Launch todo[kMaxAux + 1];
+    int n_todo = 0;
+    a.class_mask = plan & 0xf;
+    a.pc_mask = 0;
+    if (plan & SMART_PLAN_CLASS_REGULAR) {
+        if (intervals) {
+            if (plan & SMART_PLAN_FORCING_PIECEWISE) {
+                todo[n_todo++] = {e->final_vars ? kIntervalsStates : (a.exits ? kIntervalsExits : kIntervals), true};
+                a.pc_mask |= 1;
+            }
+            if (plan & SMART_PLAN_FORCING_VARYING) {
+                todo[n_todo++] = {e->final_vars ? kStepsStates : kSteps, true};
+                a.pc_mask |= 2;
+            }
+        } else {
+            todo[n_todo++] = {kPlain, false};
+        }
+    }
+    if (plan & SMART_PLAN_CLASS_STIFF)
+        todo[n_todo++] = {kStiff, false};
+    if (plan & SMART_PLAN_CLASS_GUARD)
+        todo[n_todo++] = {kGuard, false};
+    if (plan & SMART_PLAN_CLASS_ILLCOND)
+        todo[n_todo++] = {kIllCond, false};
+    if (n_todo == 0)
+        return fail(SMART_E_SIZE, "the plan names no class of rows");
+
+    // ---- workspace header, forcing flags, slice counters
+    KArgs a_sliced = a;
+    if (n_seg > 1) {
+        a_sliced.n_seg = n_seg;
+        a_sliced.seg_state = (double *)w.slices;
+        a_sliced.seg_flag = (int *)(w.slices + (size_t)a.seg_blocks * kSegFields * kWave * sizeof(double));
+        const char *mp = getenv("SMART_DEBUG_MAX_POLLS"), *dd = getenv("SMART_DEBUG_DROP_SLICE"); // tests only
+        a_sliced.max_polls = mp && atol(mp) > 0 ? atol(mp) : kDefaultMaxPolls;
+        a_sliced.debug_drop = dd ? atoi(dd) : 0;
+    }
+    if (w.hdr) {
+        reset_workspace(w, e->n_catchments, a_sliced.seg_flag, n_seg > 1 ? a.seg_blocks : 0, s);
+        if (intervals && (plan & SMART_PLAN_CLASS_REGULAR)) {
+            scan_forcing(e, w, s);
+            a.not_pc = a_sliced.not_pc = w.not_pc;
+        }
+    }
+
+    // ---- launch: one kernel on the caller's stream; several fork onto the device's auxiliary streams and join
+    std::lock_guard<std::mutex> lock(d->mu);
+    auto launch = [&](const Launch &l, hipStream_t st) -> hipError_t {
+        if (l.sliced && n_seg > 1) {
+            // dynamic LDS is requested only to cap the resident workgroups at `per_simd` per SIMD (working + waiting;
+            // beyond 3 the register file is the limit anyway)
+            const size_t lds = per_simd <= 3 ? lds_for_residency(d, l.k, 4 * per_simd) : 0;
+            if (getenv("SMART_DEBUG"))
+                fprintf(stderr, "smart_amd: %s, %d slices x %ld blocks, %d resident per SIMD (dynamic LDS %zu B)\n",
+                        kFastKernelNames[l.k], n_seg, (long)a.seg_blocks, per_simd, lds);
+            return launch_kernel(l.k, a_sliced, dim3((unsigned)(a.seg_blocks * n_seg), 1), lds, st);
+        }
+        if (getenv("SMART_DEBUG"))
+            fprintf(stderr, "smart_amd: %s, %ld blocks\n", kFastKernelNames[l.k], (long)a.seg_blocks);
+        return launch_kernel(l.k, a, grid, 0, st);
+    };
+    if (n_todo == 1) {
+        HIP_TRY(launch(todo[0], s));
         return SMART_OK;
     }
-    // time-sliced launch (smart_device.h); dynamic LDS is requested only to cap the resident workgroups at `per_simd`
-    // per SIMD (working + waiting; beyond 3 the register file is the limit anyway)
-    a.n_seg = n_seg;
-    a.n_catch = e->n_catchments;
-    a.n_blocks = grid.x;
-    a.seg_blocks = (a.n_blocks * a.n_catch + 7) / 8 * 8;
-    char *scratch = (char *)e->workspace + stats;
-    a.seg_state = (double *)scratch;
-    a.seg_flag = (int *)(scratch + (size_t)a.seg_blocks * kSegFields * kWave * sizeof(double));
-    const size_t lds_bytes = per_simd <= 3 ? fast_lds_for_residency(4 * per_simd) : 0;
-    if (getenv("SMART_DEBUG"))
-        fprintf(stderr, "smart_amd: time-sliced launch, %d slices x %ld blocks, %d resident per SIMD (dynamic LDS %zu B)\n",
-                n_seg, (long)(a.n_blocks * a.n_catch), per_simd, lds_bytes);
-    launch_fast(a, dim3((unsigned)(a.seg_blocks * n_seg), 1), lds_bytes, s);
-    HIP_TRY(hipGetLastError());
+    if (!d->fork) {
+        HIP_TRY(hipEventCreateWithFlags(&d->fork, hipEventDisableTiming));
+        for (int i = 0; i < kMaxAux; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&d->aux[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&d->join[i], hipEventDisableTiming));
+        }
+    }
+    HIP_TRY(hipEventRecord(d->fork, s));
+    for (int i = 1; i < n_todo; ++i) {
+        HIP_TRY(hipStreamWaitEvent(d->aux[i - 1], d->fork, 0));
+        HIP_TRY(launch(todo[i], d->aux[i - 1]));
+        HIP_TRY(hipEventRecord(d->join[i - 1], d->aux[i - 1]));
+    }
+    HIP_TRY(launch(todo[0], s));
+    for (int i = 1; i < n_todo; ++i)
+        HIP_TRY(hipStreamWaitEvent(s, d->join[i - 1], 0));
     return SMART_OK;
 }
 
@@ -362,20 +613,64 @@ static int64_t workspace_bytes(const SmartEnsemble *e)
 {
     if (!e || e->n_catchments < 1 || e->n_samples < 1 || e->n_steps < 0 || e->report_gap < 1)
         return 0;
-    size_t need = obs_stats_bytes(e);
+    size_t need = header_bytes(e->n_catchments) + obs_stats_bytes(e);
     if (e->math_mode == SMART_MATH_FAST) {
-        KArgs a;
-        a.N = e->n_samples;
-        a.W = e->n_warm;
-        a.gap = e->report_gap;
-        a.R = smart_n_reports(e->n_steps, e->report_gap, e->report_type);
         int per_simd = 0;
         double load = 0.0;
         int n_dev = 0;
-        if (hipGetDeviceCount(&n_dev) == hipSuccess && n_dev > 0 && plan_time_slices(e, a, &per_simd, &load) > 1)
+        DeviceCtx *d = hipGetDeviceCount(&n_dev) == hipSuccess && n_dev > 0 ? device_ctx() : nullptr;
+        if (d && plan_time_slices(e, d->n_simd, &per_simd, &load) > 1)
             need += slice_bytes(e->n_samples, e->n_catchments);
     }
     return (int64_t)need;
+}
+
+static int make_plan(const SmartEnsemble *e, int32_t *plan)
+{
+    if (!plan)
+        return fail(SMART_E_NULL, "smart_plan_ensemble: plan is NULL");
+    *plan = 0;
+    int rc = check(e);
+    if (rc)
+        return rc;
+    if ((rc = device_ready()))
+        return rc;
+    const Workspace w = carve(e);
+    if (!w.hdr)
+        return fail(SMART_E_NULL, "smart_plan_ensemble needs a workspace of smart_workspace_bytes() bytes");
+    hipStream_t s = (hipStream_t)e->stream;
+    KArgs a = kernel_args(e, w);
+    reset_workspace(w, e->n_catchments, nullptr, 0, s);
+    hipLaunchKernelGGL(smart_classify_rows, dim3((unsigned)a.n_blocks, (unsigned)e->n_catchments), dim3(kWave), 0, s, a);
+    if (e->report_type == SMART_REPORT_SUMMARY && e->report_gap >= 2) {
+        scan_forcing(e, w, s);
+        hipLaunchKernelGGL(smart_classify_forcing, dim3((unsigned)((e->n_catchments + 255) / 256)), dim3(256), 0, s,
+                           w.not_pc, (long)e->n_catchments, w.hdr);
+    }
+    HIP_TRY(hipGetLastError());
+    int bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, w.hdr + kHdrPlan, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *plan = SMART_PLAN_VALID | (bits & 0x3f);
+    return SMART_OK;
+}
+
+static int launch_status(const SmartEnsemble *e, int32_t *status)
+{
+    if (!e || !status)
+        return fail(SMART_E_NULL, "smart_launch_status: NULL argument");
+    *status = 0;
+    if (!e->workspace || e->workspace_bytes < (int64_t)header_bytes(e->n_catchments < 1 ? 1 : e->n_catchments))
+        return SMART_OK;
+    int rc = device_ready();
+    if (rc)
+        return rc;
+    int word = 0;
+    HIP_TRY(hipMemcpyAsync(&word, (const int *)e->workspace + kHdrStatus, sizeof(int), hipMemcpyDeviceToHost,
+                           (hipStream_t)e->stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)e->stream));
+    *status = word;
+    return SMART_OK;
 }
 
 } // namespace smart
@@ -396,6 +691,10 @@ int smart_check_ensemble(const SmartEnsemble *e) { return check(e); }
 int64_t smart_workspace_bytes(const SmartEnsemble *e) { return workspace_bytes(e); }
 
 int smart_run_ensemble_hip(const SmartEnsemble *e) { return run(e); }
+
+int smart_plan_ensemble(const SmartEnsemble *e, int32_t *plan) { return make_plan(e, plan); }
+
+int smart_launch_status(const SmartEnsemble *e, int32_t *status) { return launch_status(e, status); }
 
 int smart_allsteps_hip(double area_m2, double delta_sec, int64_t length_simu, const double *nd_rain,
                        const double *nd_peva, const double *nd_parameters, const double *nd_initial,

@@ -33,16 +33,35 @@ struct KArgs {
     double *objfn;      // [C][N][8] | null
     double *final_vars; // [C][N][19] | null
     int exits = 1;            // interval engine with (1) or without (0) wave-uniform early exits, FastModel::kExits
+    // which kernels this call launches (include/smart_amd.h, SMART_PLAN_*): a workgroup that meets a block nobody will
+    // run (a stale plan) leaves SMART_STATUS_STALE_PLAN in the status word instead of a silent hole in the outputs
+    int class_mask = 0xf;     // bit c: the kernel of arithmetic class c (wave_class) has been launched
+    int pc_mask = 0x3;        // bit 0: the interval engine (piecewise-constant forcing), bit 1: the step loop
+    // workspace header (null without a workspace: no status word, no time slices, every wavefront scans the forcing)
+    int *hdr = nullptr;       // [kHdrInts]: status word, ticket counters of the sliced kernels
+    int *not_pc = nullptr;    // [C]: forcing of catchment c is NOT piecewise constant over the report interval
     // time-sliced launch (n_seg > 1): see "time-sliced launch" below
     int n_seg = 1;            // workgroups per block of 64 samples, each advancing one slice of the time axis
     long n_catch = 1;         // C
     long n_blocks = 0;        // ceil(N / 64), blocks per catchment
-    long seg_blocks = 0;      // C * n_blocks padded to a multiple of 8 (a block's slices stay on one XCD)
+    long seg_blocks = 0;      // C * n_blocks
     double *seg_state = nullptr; // [seg_blocks][kSegFields][64] hand-over between a block's consecutive slices
-    int *seg_flag = nullptr;     // [seg_blocks] slices completed; then [C] forcing NOT piecewise constant; then [1] error
+    int *seg_flag = nullptr;     // [seg_blocks] slices completed (negative: the chain is poisoned, see wait_for_slice)
+    long max_polls = 0;          // bound of a slice's wait for its predecessor, in polls of ~3 us
+    int debug_drop = 0;          // test knob: slice 0 of block 0 never publishes (its successors must time out)
 };
 
 constexpr int kSegFields = 22;
+constexpr int kHdrInts = 64;      // workspace header: [0] status word, [1 + k] ticket counter of sliced kernel k
+constexpr int kHdrStatus = 0, kHdrTicket = 1;
+constexpr int kStatusSliceTimeout = 1, kStatusStalePlan = 2; // = SMART_STATUS_* of include/smart_amd.h
+
+__device__ __forceinline__ void raise_status(const KArgs &a, int bit)
+{
+    if (a.hdr && threadIdx.x == 0)
+        __hip_atomic_fetch_or(a.hdr + kHdrStatus, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 
 #ifndef SMART_NT_STORE
 #define SMART_NT_STORE 0
@@ -57,6 +76,9 @@ __device__ __forceinline__ bool is_nan_bits(double x)
     return (__builtin_bit_cast(unsigned long long, x) & 0x7fffffffffffffffull) > 0x7ff0000000000000ull;
 }
 constexpr int kWsHead = 8;
+
+// a quiet NaN that does not trip -fno-honor-nans diagnostics (the fast kernels never do arithmetic on one)
+__host__ __device__ __forceinline__ double quiet_nan() { return __builtin_bit_cast(double, 0x7ff8000000000000ull); }
 
 // objective functions from the one-pass moments (montecarlo.py:193-209; formulas of spotpy's nashsutcliffe,
 // kge(return_all=True), pbias, rmse).  Moments are taken about the observation mean, known before the run:
@@ -84,7 +106,7 @@ __device__ inline void finish_objectives(const double *st, double A, double B, d
     if (!is_nan_bits(gw_obs)) // objfunctions.py:20-24
         o[7] = (gw_obs - 0.1 <= gw_sim && gw_sim <= gw_obs + 0.1) ? 1.0 : 0.0;
     else
-        o[7] = __builtin_nan("");
+        o[7] = quiet_nan();
 }
 
 // numpy's pairwise sum of n (< 8, or 8..128) values held in LDS column `lane` (stride 64 doubles):
@@ -298,7 +320,7 @@ __device__ __forceinline__ void write_results(const KArgs &a, const LaneCtx &x, 
         a.gw[x.c * a.N + x.n] = gw;
     if (rep.want_obj && x.live) {
         double o[8];
-        finish_objectives(rep.ws, rep.A, rep.B, rep.C1, rep.C2, rep.C3, gw, a.gw_obs ? a.gw_obs[x.c] : __builtin_nan(""),
+        finish_objectives(rep.ws, rep.A, rep.B, rep.C1, rep.C2, rep.C3, gw, a.gw_obs ? a.gw_obs[x.c] : quiet_nan(),
                           o);
         double *op = a.objfn + (x.c * a.N + x.n) * 8;
 #pragma unroll
@@ -458,35 +480,72 @@ __device__ __forceinline__ void interval_loop_obs(const double2 *__restrict__ f,
 // A block of 64 samples is one wavefront for the whole time axis, so a launch of B blocks on S SIMDs lasts as long as
 // the SIMDs that hold ceil(B / S) of them while the others idle (1e5 samples: 1,563 blocks on 1,024 SIMDs, 539 SIMDs
 // with two).  Here the time axis of every block is cut into n_seg slices and each (block, slice) is its own
-// workgroup, id = slice * seg_blocks + (catchment * n_blocks + block): the hardware hands out workgroups in id order
-// as slots free up, so a SIMD that finishes early simply gets more slices.  Slice s of a block starts from the state
-// slice s - 1 left in `seg_state`; it waits for `seg_flag[slot] >= s` (its predecessor has a lower id, so it is
-// already resident or finished -- no deadlock; the wait is bounded anyway).  The arithmetic is that of the unsliced
-// run, bit for bit.
+// workgroup, handed out as slots free up, so a SIMD that finishes early simply gets more slices.  Slice s of a block
+// starts from the state slice s - 1 left in `seg_state` and waits for `seg_flag[slot] >= s`.
+//
+// Which (block, slice) a workgroup runs comes from a TICKET it draws when it starts (one atomic add on a counter in
+// the workspace header), not from its workgroup id: ticket t is slice t / seg_blocks of block t % seg_blocks, so the
+// slice a workgroup waits for (ticket t - seg_blocks) was drawn by a workgroup that is already running or done,
+// whatever order the hardware dispatches workgroups in and however the ids map to XCDs -- forward progress needs
+// nothing beyond "resident wavefronts keep executing".  The wait is bounded all the same (a preempted queue on a
+// shared GPU): a slice that gives up raises kStatusSliceTimeout in the status word, writes NaN for its report rows
+// and poisons its chain (negative flag), so that no number computed from a missing hand-over can pass for a result;
+// the host reads the status word and repeats the launch unsliced (engine.py).  The arithmetic is that of the
+// unsliced run, bit for bit.
 #ifndef SMART_POLL_SLEEP
 #define SMART_POLL_SLEEP 100
 #endif
-constexpr long kMaxPolls = 20000000; // x ~3 us = a minute; a slice takes ~1 ms and waits for one predecessor
+constexpr long kDefaultMaxPolls = 1000000; // x ~3 us = three seconds; a slice takes ~1 ms and waits for one predecessor
 
-__device__ __forceinline__ void wait_for_slice(const KArgs &a, long slot, int seg)
+// the piece of work of this workgroup: block of 64 samples, catchment, time slice
+struct Work {
+    long block, c;
+    int seg;
+};
+
+__device__ __forceinline__ Work claim_work(const KArgs &a, int sliced_kernel)
+{
+    Work w;
+    if (a.n_seg > 1) {
+        unsigned t = 0;
+        if (threadIdx.x == 0)
+            t = __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(a.hdr) + kHdrTicket + sliced_kernel, 1u,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        const long slot = (long)(t % (unsigned long)a.seg_blocks);
+        w.seg = (int)(t / (unsigned long)a.seg_blocks);
+        w.c = slot / a.n_blocks;
+        w.block = slot % a.n_blocks;
+    } else {
+        w.block = blockIdx.x;
+        w.c = blockIdx.y;
+        w.seg = 0;
+    }
+    return w;
+}
+
+// true: the predecessor's hand-over is there; false: gave up, or the chain is already poisoned
+__device__ __forceinline__ bool wait_for_slice(const KArgs &a, long slot, int seg)
 {
     int *flag = a.seg_flag + slot;
     long polls = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seg) {
+    int v;
+    while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > -seg && v < seg) {
         __builtin_amdgcn_s_sleep(SMART_POLL_SLEEP);
-        if (++polls > kMaxPolls) { // never seen; leaves a mark instead of a hung GPU
-            __hip_atomic_store(a.seg_flag + a.seg_blocks + a.n_catch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
+        if (++polls > a.max_polls) {
+            raise_status(a, kStatusSliceTimeout);
+            return false;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return v >= seg;
 }
 
-__device__ __forceinline__ void publish_slice(const KArgs &a, long slot, int seg)
+__device__ __forceinline__ void publish_slice(const KArgs &a, long slot, int seg, bool good)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (threadIdx.x == 0)
-        __hip_atomic_store(a.seg_flag + slot, seg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.seg_flag + slot, good ? seg + 1 : -(seg + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Launch body of the merged regular variant for summary reports (Model::kIntervals), whole or time-sliced.
@@ -537,7 +596,22 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
     double num = 0.0, den = 0.0, q_out_total = 0.0;
     double *hand = a.seg_state + (slot * kSegFields) * kWave + x.lane;
     if (seg > 0) {
-        wait_for_slice(a, slot, seg);
+        if (!wait_for_slice(a, slot, seg)) {
+            // the hand-over never came (or the chain is poisoned already): NaN for everything this slice owes, and
+            // the same for its successors -- nothing computed from a missing state may pass for a result
+            const double nan = quiet_nan();
+            if (a.discharge && x.live)
+                for (long r = ra; r < rb; ++r)
+                    a.discharge[(x.c * a.R + r) * a.ld + x.n] = nan;
+            if (last) {
+                rep.A = rep.B = rep.C1 = rep.C2 = rep.C3 = nan;
+                m.poison(nan);
+                write_results(a, x, m, rep, nan);
+            } else {
+                publish_slice(a, slot, seg, false);
+            }
+            return;
+        }
         m.load_state(hand, kWave);
         q_out_total = hand[16 * kWave];
         rep.A = hand[17 * kWave];
@@ -594,12 +668,6 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
     if (last) {
         m.balance_sums(q_out_total, num, den);
         double gw = num / den;
-        // a slice that gave up waiting (never seen; wait_for_slice) must not pass for a result: NaN for the whole launch
-        if (a.n_seg > 1 &&
-            __hip_atomic_load(a.seg_flag + a.seg_blocks + a.n_catch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            gw = __builtin_bit_cast(double, 0x7ff8000000000000ull);
-            rep.A = rep.B = rep.C1 = rep.C2 = rep.C3 = gw;
-        }
         write_results(a, x, m, rep, gw);
     } else {
         m.save_state(hand, kWave);
@@ -609,7 +677,8 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         hand[19 * kWave] = rep.C1;
         hand[20 * kWave] = rep.C2;
         hand[21 * kWave] = rep.C3;
-        publish_slice(a, slot, seg);
+        if (!(a.debug_drop && slot == 0 && seg == 0)) // test knob: a hand-over that never arrives
+            publish_slice(a, slot, seg, true);
     }
 }
 

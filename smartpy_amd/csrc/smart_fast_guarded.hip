@@ -1,0 +1,40 @@
+// smart_fast_guarded.hip -- the rows outside the regular class: reachable clamps and 95 % rule (STIFF), leak guards
+// that can matter (GUARD), and the ill-conditioned rows that only the reference's own operation order reproduces
+// (literal model).  Daily steps with the default parameter ranges put a third of the rows here; hourly steps none.
+// See smart_fast_entry.h for the family.
+#include "smart_fast_entry.h"
+#include "smart_literal_model.h"
+
+namespace smart {
+
+template <int CLS, class Model>
+__device__ __forceinline__ void guarded_kernel(const KArgs &a, const double2 *__restrict__ forcing,
+                                               const double *__restrict__ obs, const double *__restrict__ ws)
+{
+    const Work w = claim_work(a, 0);
+    if (!block_is_mine<CLS>(a, w))
+        return;
+    run_ensemble<Model, false>(a, forcing, obs, ws, nullptr, w.block, w.c);
+}
+
+SMART_FAST_KERNEL(smart_fast_stiff) { guarded_kernel<1, FastModel<true, false>>(a, forcing, obs, ws); }
+
+SMART_FAST_KERNEL(smart_fast_guard) { guarded_kernel<2, FastModel<true, true>>(a, forcing, obs, ws); }
+
+SMART_FAST_KERNEL(smart_fast_illcond) { guarded_kernel<3, LiteralModel>(a, forcing, obs, ws); }
+
+const void *fast_kernel_guarded(FastKernel k)
+{
+    switch (k) {
+    case kStiff:
+        return reinterpret_cast<const void *>(&smart_fast_stiff);
+    case kGuard:
+        return reinterpret_cast<const void *>(&smart_fast_guard);
+    case kIllCond:
+        return reinterpret_cast<const void *>(&smart_fast_illcond);
+    default:
+        return nullptr;
+    }
+}
+
+} // namespace smart

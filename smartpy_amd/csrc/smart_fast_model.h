@@ -1,4 +1,4 @@
-// smart_fast.hip -- SMART_MATH_FAST: the same recurrence (structure.py:267-503) re-expressed for the
+// smart_fast_model.h -- SMART_MATH_FAST: the same recurrence (structure.py:267-503) re-expressed for the
 // fp64 vector ALU of gfx950.  There is no contraction in this model (a strict, branchy recurrence per
 // sample), so no MFMA; the binding roof is fp64 VALU issue, and the per-step instruction count is what
 // this file minimises:
@@ -34,8 +34,9 @@
 //
 // Tuning knobs (macros) are kept so that tools/ab_variants.sh can A/B them on one box; the defaults are the
 // measured winners.  Tried and not kept: see DESIGN.md section 4.1.
+#pragma once
+
 #include "smart_device.h"
-#include "smart_literal_model.h"
 
 #ifndef SMART_FAST_EARLY_EXIT
 #define SMART_FAST_EARLY_EXIT 1
@@ -145,7 +146,7 @@ struct FastModel {
     {
 #pragma unroll
         for (int i = 0; i < 7; ++i)
-            v[i] = __builtin_nan("");
+            v[i] = quiet_nan();
         if (MERGE) { // totals and (SPLIT) their drain / deep parts, in mm; without SPLIT the pairs stay merged
             v[7] = (u_ove - u_dra) * mm_to_m3;
             v[8] = u_dra * mm_to_m3;
@@ -166,6 +167,13 @@ struct FastModel {
         v[16] = l4 * mm_to_m3;
         v[17] = l5 * mm_to_m3;
         v[18] = u_riv * k_r;
+    }
+
+    // every state = v (the NaN a poisoned time slice reports, smart_device.h)
+    __device__ void poison(double v)
+    {
+        l0 = l1 = l2 = l3 = l4 = l5 = v;
+        u_ove = u_dra = u_int = u_sgw = u_dgw = u_riv = v;
     }
 
     // top-down filling of one layer (structure.py:367-374): a = min(ex, space)
@@ -591,127 +599,6 @@ __device__ inline int wave_class(const KArgs &a, long block, long catchment)
     const bool any_guard = __builtin_amdgcn_ballot_w64(guard) != 0;
     const bool any_unstable = __builtin_amdgcn_ballot_w64(unstable) != 0;
     return any_unstable ? 3 : (any_guard ? 2 : (any_stiff ? 1 : 0));
-}
-
-#ifndef SMART_FAST_MIN_WAVES
-#define SMART_FAST_MIN_WAVES 1
-#endif
-__global__ __launch_bounds__(kWave, SMART_FAST_MIN_WAVES) void smart_ensemble_fast(KArgs a, const double2 *__restrict__ forcing,
-                                                             const double *__restrict__ obs,
-                                                             const double *__restrict__ ws)
-{
-    // time-sliced launch: workgroup id = slice * seg_blocks + catchment * n_blocks + block; only the interval engine
-    // is sliced, every other path runs a block's whole time axis in its slice-0 workgroup
-    long block = blockIdx.x, c = blockIdx.y;
-    int seg = 0;
-    if (a.n_seg > 1) {
-        const long slot = blockIdx.x % a.seg_blocks;
-        seg = (int)(blockIdx.x / a.seg_blocks);
-        if (slot >= a.n_catch * a.n_blocks)
-            return;
-        c = slot / a.n_blocks;
-        block = slot % a.n_blocks;
-    }
-    const int cls = wave_class(a, block, c);
-    if (cls == 0) {
-        using Merged = FastModel<false, false, true>;
-        using MergedSplit = FastModel<false, false, true, true, true>; // final state vector asked for
-        if (SMART_FAST_INTERVALS && Merged::kIntervals && a.report_type == 1 && a.gap >= 2) {
-            const bool piecewise = a.n_seg > 1 ? a.seg_flag[a.seg_blocks + c] == 0 // answered by smart_forcing_scan
-                                               : forcing_is_piecewise_constant(forcing + c * a.T, a.T, a.gap);
-            if (a.final_vars) {
-                if (piecewise)
-                    run_ensemble_merged<MergedSplit, true>(a, forcing, obs, ws, block, c, seg);
-                else
-                    run_ensemble_merged<MergedSplit, false>(a, forcing, obs, ws, block, c, seg);
-            } else if (piecewise && a.exits)
-                run_ensemble_merged<Merged, true>(a, forcing, obs, ws, block, c, seg);
-            else if (piecewise)
-                run_ensemble_merged<FastModel<false, false, true, false>, true>(a, forcing, obs, ws, block, c, seg);
-            else
-                run_ensemble_merged<Merged, false>(a, forcing, obs, ws, block, c, seg);
-            return;
-        }
-        if (seg == 0 && a.final_vars == nullptr) {
-            run_ensemble<Merged, false>(a, forcing, obs, ws, nullptr, block, c);
-            return;
-        }
-    }
-    if (seg != 0)
-        return;
-    if (cls == 0)
-        run_ensemble<FastModel<false, false>, false>(a, forcing, obs, ws, nullptr, block, c);
-    else if (cls == 1)
-        run_ensemble<FastModel<true, false>, false>(a, forcing, obs, ws, nullptr, block, c);
-    else if (cls == 2)
-        run_ensemble<FastModel<true, true>, false>(a, forcing, obs, ws, nullptr, block, c);
-    else
-        run_ensemble<LiteralModel, false>(a, forcing, obs, ws, nullptr, block, c);
-}
-
-// time-sliced launches: the piecewise-constant question is answered once per catchment, by the whole chip (the
-// slices of a block must agree on it).  not_pc[c] is zeroed by the host; any step that differs from the first step
-// of its report interval sets it.
-__global__ void smart_forcing_scan(const double2 *__restrict__ forcing, long T, long gap, int *not_pc)
-{
-    const double2 *__restrict__ f = forcing + (long)blockIdx.y * T;
-    bool same = true;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (long)gridDim.x * blockDim.x) {
-        const double2 v = f[t], h = f[(t / gap) * gap];
-        same = same && same_bits(v.x, h.x) && same_bits(v.y, h.y);
-    }
-    if (__builtin_amdgcn_ballot_w64(!same) != 0 && (threadIdx.x & (kWave - 1)) == 0)
-        __hip_atomic_store(not_pc + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Zeroes the slice counters and the flags of a time-sliced launch.  A kernel rather than hipMemsetAsync: inside a
-// captured HIP graph the memset node of ROCm 7.2 was not ordered before the ensemble kernel (replays started with the
-// counters of the previous replay: no waiting, stale hand-over states; tools/debug/graph_dbg.py), kernel nodes are.
-__global__ void smart_slice_reset(int *flags, long n)
-{
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        flags[i] = 0;
-}
-
-// dynamic LDS that lets exactly `per_cu` workgroups of the ensemble kernel be resident on a CU (0: no such size)
-size_t fast_lds_for_residency(int per_cu)
-{
-    static size_t cache[17] = {};
-    static bool known[17] = {};
-    if (per_cu < 1 || per_cu > 16)
-        return 0;
-    if (!known[per_cu]) {
-        size_t found = 0;
-        for (size_t x = (size_t)(160 * 1024 / per_cu) / 256 * 256; x >= 1024 && x > (size_t)(160 * 1024 / (per_cu + 1)) - 2048; x -= 256) {
-            int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, smart_ensemble_fast, kWave, x) != hipSuccess)
-                break;
-            if (nb == per_cu) {
-                found = x;
-                break;
-            }
-            if (nb > per_cu)
-                break;
-        }
-        cache[per_cu] = found;
-        known[per_cu] = true;
-    }
-    return cache[per_cu];
-}
-
-void launch_fast(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s)
-{
-    if (a.n_seg > 1) {
-        const long n_flags = a.seg_blocks + a.n_catch + 1;
-        hipLaunchKernelGGL(smart_slice_reset, dim3((unsigned)((n_flags + 255) / 256)), dim3(256), 0, s, a.seg_flag,
-                           n_flags);
-    }
-    if (a.n_seg > 1)
-        hipLaunchKernelGGL(smart_forcing_scan, dim3(64, (unsigned)a.n_catch), dim3(256), 0, s,
-                           reinterpret_cast<const double2 *>(a.forcing), a.T, a.gap, a.seg_flag + a.seg_blocks);
-    hipLaunchKernelGGL(smart_ensemble_fast, grid, dim3(kWave), lds_bytes, s, a,
-                       reinterpret_cast<const double2 *>(a.forcing), a.obs, a.ws);
 }
 
 } // namespace smart

@@ -6,6 +6,8 @@ and nothing imports the test oracle.
 """
 import ctypes
 import math
+import warnings
+import weakref
 
 import numpy as np
 import torch
@@ -86,12 +88,9 @@ def n_reports(n_steps, gap, report_type):
     return int(_lib.lib().smart_n_reports(n_steps, gap, report_type))
 
 
-_GROUP_CACHE = {}     # (data_ptr, version, N, dt) -> (gather, inverse) | None   (one entry: the last matrix seen)
-
-
 def variant_classes(params, delta_sec):
-    """Which arithmetic variant of the fast kernel a parameter row needs -- the rules of wave_class() in
-    csrc/smart_fast.hip: 0 regular, 1 stiff (some k*3600 < dt: clamps / river rule reachable), 2 guarded
+    """Which arithmetic variant of the fast kernels a parameter row needs -- the rules of wave_class() in
+    csrc/smart_fast_model.h: 0 regular, 1 stiff (some k*3600 < dt: clamps / river rule reachable), 2 guarded
     (S outside [0, 0.5], C < 0 or Z <= 0), 3 ill-conditioned (some dt / (k*3600) > 2: literal arithmetic)."""
     k = params[:, 6:10] * 3600.0
     cls = torch.zeros(params.shape[0], dtype=torch.int64, device=params.device)
@@ -106,40 +105,128 @@ def _variant_grouping(params, delta_sec):
     arithmetic (and cost) independent of its neighbours, rows are grouped by variant before the launch, each group
     padded to whole wavefronts with copies of its last row.  Returns (gather [N_run], inverse [N]) or None when the
     matrix needs no regrouping (one variant only -- always the case for hourly steps with the default ranges)."""
-    key = (params.data_ptr(), params._version, params.shape[0], float(delta_sec))
-    if key in _GROUP_CACHE:
-        return _GROUP_CACHE[key]
     cls = variant_classes(params, delta_sec)
-    result = None
-    if int(cls.min()) != int(cls.max()):
-        pieces = []
-        for c in range(4):
-            idx = torch.nonzero(cls == c)[:, 0]
-            if idx.numel():
-                pad = (-idx.numel()) % 64
-                pieces.append(torch.cat([idx, idx[-1:].expand(pad)]) if pad else idx)
-        gather = torch.cat(pieces)
-        inverse = torch.empty(params.shape[0], dtype=torch.int64, device=params.device)
-        inverse[gather] = torch.arange(gather.numel(), device=params.device)    # duplicates hold identical results
-        result = (gather, inverse)
-    _GROUP_CACHE.clear()
-    _GROUP_CACHE[key] = result
-    return result
+    if int(cls.min()) == int(cls.max()):
+        return None
+    pieces = []
+    for c in range(4):
+        idx = torch.nonzero(cls == c)[:, 0]
+        if idx.numel():
+            pad = (-idx.numel()) % 64
+            pieces.append(torch.cat([idx, idx[-1:].expand(pad)]) if pad else idx)
+    gather = torch.cat(pieces)
+    inverse = torch.empty(params.shape[0], dtype=torch.int64, device=params.device)
+    inverse[gather] = torch.arange(gather.numel(), device=params.device)    # duplicates hold identical results
+    return gather, inverse
 
 
-def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report='summary', extra=None,
-                 initial=None, obs=None, gw_obs=None, math_mode='fast', want_discharge=True, want_objfn=None,
-                 want_final=False, device=None, discharge_out=None, group_variants=True):
-    """One launch of the whole ensemble: the batched form of the spotpy loop over MonteCarlo.simulation /
-    objectivefunction (montecarlo.py:153-154,179-209).
+class _Memo(object):
+    """What has been worked out about a (params, forcing) pair: the variant grouping of the rows and the launch plan
+    (which kernels the rows and the forcing need, smart_plan_ensemble).  Entries are tied to the tensor OBJECTS the
+    caller passed (weak references) and their in-place version counters, never to addresses: a fresh tensor that
+    happens to reuse a freed address starts from nothing."""
+    _entries = []
+    SIZE = 8
 
-    params   [N, 10] or [C, N, 10]    forcing [T, 2] or [C, T, 2] (rain, peva per step)
-    area_m2  scalar or [C]            extra   dict / 7-vector / [C, 7] / None
-    initial  [N, 12] / [C, N, 12]     obs     [R] or [C, R], NaN = missing    gw_obs scalar / [C] / None
-    """
+    @classmethod
+    def lookup(cls, kind, tensors, key):
+        alive = []
+        hit = None
+        for ent in cls._entries:
+            refs = [r() for r in ent[1]]
+            if any(t is None for t in refs):
+                continue
+            alive.append(ent)
+            if (ent[0] == kind and ent[3] == key and len(refs) == len(tensors)
+                    and all(r is t for r, t in zip(refs, tensors))
+                    and ent[2] == tuple(t._version for t in tensors)):
+                hit = ent
+        cls._entries[:] = alive
+        return None if hit is None else hit[4]
+
+    @classmethod
+    def store(cls, kind, tensors, key, value):
+        cls._entries.append((kind, [weakref.ref(t) for t in tensors], tuple(t._version for t in tensors), key,
+                             (value,)))
+        del cls._entries[:-cls.SIZE]
+
+
+class PreparedEnsemble(object):
+    """One ensemble call, made ready: inputs on the device, output buffers, the workspace and the launch plan, all
+    owned here -- launch() only enqueues the kernels (no allocation, no synchronisation), so a caller that repeats the
+    call (a benchmark, a HIP-graph capture, a calibration loop over observation sets) pays for the set-up once.
+    Build one with prepare_ensemble()."""
+
+    def launch(self):
+        """Enqueue on torch's current stream of the device.  Returns the EnsembleResult (views of this object's
+        buffers: the next launch() overwrites them)."""
+        with torch.cuda.device(self.device):
+            self._e.stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(_lib.lib().smart_run_ensemble_hip(ctypes.byref(self._e)))
+        return self._result()
+
+    def status(self):
+        """SMART_STATUS_* bits of the last launch (synchronises with the stream)."""
+        word = ctypes.c_int32(0)
+        with torch.cuda.device(self.device):
+            self._e.stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(_lib.lib().smart_launch_status(ctypes.byref(self._e), ctypes.byref(word)))
+        return int(word.value)
+
+    def verify(self):
+        """Read the status word of the last launch and repair what it reports: a time slice that gave up waiting for
+        its predecessor (never seen on an idle GPU; possible when the queue is preempted) -> the launch is repeated
+        unsliced; a plan that no longer matches the inputs -> re-planned and repeated.  Raises if the second launch
+        is not clean either.  Returns the result to use."""
+        word = self.status()
+        if word == 0:
+            return self._result()
+        warnings.warn("smartpy_amd: launch status %#x (%s); repeating the launch %s" % (
+            word, ' + '.join(n for b, n in ((_lib.STATUS_SLICE_TIMEOUT, 'a time slice timed out'),
+                                            (_lib.STATUS_STALE_PLAN, 'stale plan')) if word & b),
+            'without time slices' if word & _lib.STATUS_SLICE_TIMEOUT else 'with a fresh plan'))
+        if word & _lib.STATUS_SLICE_TIMEOUT:
+            self._e.time_slices = 1
+        if word & _lib.STATUS_STALE_PLAN:
+            self._e.plan = 0
+            self._e.plan = self._make_plan()
+        self.launch()
+        word = self.status()
+        if word != 0:
+            raise SmartEngineError(-6, "smartpy_amd: the repeated launch reports status %#x as well" % word)
+        return self._result()
+
+    def _make_plan(self):
+        plan = ctypes.c_int32(0)
+        with torch.cuda.device(self.device):
+            self._e.stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(_lib.lib().smart_plan_ensemble(ctypes.byref(self._e), ctypes.byref(plan)))
+        return int(plan.value)
+
+    def _result(self):
+        dis, gw, objfn, fin = self._dis, self._gw, self._objfn, self._fin
+        if self._grouping is not None:        # back to the caller's row order
+            inverse = self._grouping[1]
+            gw = gw[:, inverse]
+            objfn = None if objfn is None else objfn[:, inverse]
+            fin = None if fin is None else fin[:, inverse]
+            if dis is not None:
+                if self._caller_out is not None:
+                    self._caller_out[:, :, :self.n_samples].copy_(torch.index_select(dis, 2, inverse))
+                    dis = self._caller_out
+                else:
+                    dis = torch.index_select(dis, 2, inverse)
+        return EnsembleResult(dis, gw, objfn, fin, self.n_samples, self._squeeze)
+
+
+def prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report='summary', extra=None,
+                     initial=None, obs=None, gw_obs=None, math_mode='fast', want_discharge=True, want_objfn=None,
+                     want_final=False, device=None, discharge_out=None, group_variants=True, time_slices=0):
+    """Everything of run_ensemble() short of the launch: see PreparedEnsemble.  Arguments as run_ensemble()."""
     L = _lib.lib()
     device = torch.device(device) if device is not None else (
         params.device if isinstance(params, torch.Tensor) and params.is_cuda else default_device())
+    params_in, forcing_in = params, forcing
     params = as_device(params, device)
     forcing = as_device(forcing, device)
     squeeze = forcing.dim() == 2
@@ -185,20 +272,26 @@ def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report
     if gw_obs is not None:
         gw_obs = as_device(np.full(C, gw_obs, dtype=np.float64) if np.ndim(gw_obs) == 0 else gw_obs, device, (C,))
 
+    # what is already known about these very tensors (only when the caller handed over device tensors: anything
+    # converted above is a fresh object, and a fresh object is classified afresh)
+    memo_on = [t for t in (params_in, forcing_in) if isinstance(t, torch.Tensor) and t.is_cuda]
+    memo_key = (float(delta_sec), int(report_gap), rtype, C, N, T, bool(group_variants))
+    memo = _Memo.lookup('fast', memo_on, memo_key) if len(memo_on) == 2 and mmode == MATH_FAST else None
+
     # rows grouped by arithmetic variant (fast mode, one shared [N, 10] matrix spanning more than one wavefront)
-    grouping = None
-    n_rows = N
+    p = PreparedEnsemble()
+    p.device, p.n_samples, p._squeeze = device, N, squeeze
+    p._grouping, p._caller_out = None, None
     if group_variants and mmode == MATH_FAST and pstride == 0 and N > 64:
-        grouping = _variant_grouping(params, float(delta_sec))
-        if grouping is not None:
-            gather, inverse = grouping
+        p._grouping = memo[0][0] if memo else _variant_grouping(params, float(delta_sec))
+        if p._grouping is not None:
+            gather = p._grouping[0]
             params = params[gather].contiguous()
             if initial is not None:
                 initial = initial[:, gather].contiguous()
             N = gather.numel()
-    caller_out = None
-    if grouping is not None and discharge_out is not None:
-        caller_out, discharge_out, want_discharge = discharge_out, None, True
+    if p._grouping is not None and discharge_out is not None:
+        p._caller_out, discharge_out, want_discharge = discharge_out, None, True
 
     ld = N
     dis = None
@@ -208,40 +301,63 @@ def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report
         ld = dis.shape[2]
     elif want_discharge:
         dis = torch.empty((C, R, ld), dtype=torch.float64, device=device)
-    gw = torch.empty((C, N), dtype=torch.float64, device=device)
-    objfn = torch.empty((C, N, 8), dtype=torch.float64, device=device) if want_objfn else None
-    fin = torch.empty((C, N, 19), dtype=torch.float64, device=device) if want_final else None
+    p._dis = dis
+    p._gw = torch.empty((C, N), dtype=torch.float64, device=device)
+    p._objfn = torch.empty((C, N, 8), dtype=torch.float64, device=device) if want_objfn else None
+    p._fin = torch.empty((C, N, 19), dtype=torch.float64, device=device) if want_final else None
 
     def ptr(t):
         return None if t is None else t.data_ptr()
 
-    e = _lib.SmartEnsemble()
+    e = p._e = _lib.SmartEnsemble()
     e.n_catchments, e.n_samples, e.n_steps, e.n_warm, e.report_gap = C, N, T, int(n_warm), int(report_gap)
     e.report_type, e.math_mode, e.delta_sec = rtype, mmode, float(delta_sec)
     e.area_m2, e.forcing, e.params, e.params_catchment_stride = ptr(area), ptr(forcing), ptr(params), pstride
     e.extra, e.initial, e.obs, e.gw_obs = ptr(extra), ptr(initial), ptr(obs), ptr(gw_obs)
-    e.discharge, e.discharge_ld, e.gw, e.objfn = ptr(dis), ld, ptr(gw), ptr(objfn)
-    e.final_vars = ptr(fin)
-    # the caller owns every buffer, the library's scratch included: observation statistics + slice hand-over
-    n_ws = int(L.smart_workspace_bytes(ctypes.byref(e)))
-    ws = torch.empty((n_ws + 7) // 8, dtype=torch.float64, device=device) if n_ws > 0 else None
-    e.workspace, e.workspace_bytes = ptr(ws), n_ws
+    e.discharge, e.discharge_ld, e.gw, e.objfn = ptr(dis), ld, ptr(p._gw), ptr(p._objfn)
+    e.final_vars = ptr(p._fin)
+    e.time_slices = int(time_slices)
+    # the caller of the C ABI owns every buffer, the library's scratch included: header, observation statistics,
+    # slice hand-over
     with torch.cuda.device(device):
-        e.stream = torch.cuda.current_stream(device).cuda_stream
-        _lib.check(L.smart_run_ensemble_hip(ctypes.byref(e)))
-    # keep the inputs alive until the launch has been enqueued on the torch stream (it has: the call returned)
-    if grouping is not None:        # back to the caller's row order
-        gw = gw[:, inverse]
-        objfn = None if objfn is None else objfn[:, inverse]
-        fin = None if fin is None else fin[:, inverse]
-        if dis is not None:
-            if caller_out is not None:
-                caller_out[:, :, :n_rows].copy_(torch.index_select(dis, 2, inverse))
-                dis = caller_out
-            else:
-                dis = torch.index_select(dis, 2, inverse)
-        N = n_rows
-    return EnsembleResult(dis, gw, objfn, fin, N, squeeze)
+        n_ws = int(L.smart_workspace_bytes(ctypes.byref(e)))
+    p._ws = torch.empty((n_ws + 7) // 8, dtype=torch.float64, device=device) if n_ws > 0 else None
+    e.workspace, e.workspace_bytes = ptr(p._ws), n_ws
+    _lib.check(L.smart_check_ensemble(ctypes.byref(e)))
+    if mmode == MATH_FAST and p._ws is not None:
+        if memo:
+            e.plan = memo[0][1]
+        else:
+            e.plan = p._make_plan()
+            if len(memo_on) == 2:
+                _Memo.store('fast', memo_on, memo_key, (p._grouping, int(e.plan)))
+    p._keep = (area, forcing, params, extra, initial, obs, gw_obs)     # alive for as long as the struct points at them
+    return p
+
+
+def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report='summary', extra=None,
+                 initial=None, obs=None, gw_obs=None, math_mode='fast', want_discharge=True, want_objfn=None,
+                 want_final=False, device=None, discharge_out=None, group_variants=True, time_slices=0, verify=True):
+    """One launch of the whole ensemble: the batched form of the spotpy loop over MonteCarlo.simulation /
+    objectivefunction (montecarlo.py:153-154,179-209).
+
+    params   [N, 10] or [C, N, 10]    forcing [T, 2] or [C, T, 2] (rain, peva per step)
+    area_m2  scalar or [C]            extra   dict / 7-vector / [C, 7] / None
+    initial  [N, 12] / [C, N, 12]     obs     [R] or [C, R], NaN = missing    gw_obs scalar / [C] / None
+
+    verify: read the launch's status word afterwards (synchronises with the stream) and repeat the launch if a time
+    slice timed out; skipped while the stream is being captured into a HIP graph.  Callers that pipeline launches
+    use prepare_ensemble() / launch() and call verify() when they synchronise anyway.
+    """
+    p = prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report=report, extra=extra,
+                         initial=initial, obs=obs, gw_obs=gw_obs, math_mode=math_mode,
+                         want_discharge=want_discharge, want_objfn=want_objfn, want_final=want_final, device=device,
+                         discharge_out=discharge_out, group_variants=group_variants, time_slices=time_slices)
+    out = p.launch()
+    if verify and p._ws is not None and p._e.math_mode == MATH_FAST and not torch.cuda.is_current_stream_capturing():
+        out = p.verify()
+    out._prepared = p       # the result's tensors live in the prepared call's buffers
+    return out
 
 
 def objective_functions(discharge_report_major, obs, gw_sim=None, gw_obs=None):
