@@ -2,14 +2,22 @@
 """Headline benchmark: Monte-Carlo sample-timesteps per second of the SMART time loop on MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1: launched by torch.distributed.run, one rank per
-GPU, RCCL).  One "step" = one pass of the hot path over one batch = one ensemble launch that advances every
-sample of this rank's shard through warm-up + simulation (BASELINE config 3: 1e5 LHS samples x hourly 10-year
-synthetic forcing per GPU, summary report, objective functions fused, discharge matrix written) followed, for
-N > 1, by the one RCCL all-gather of the objective / groundwater arrays.  Weak scaling: 1e5 samples per GPU.
+GPU, RCCL).  One "step" = one pass of the hot path over one batch = the ensemble launch that advances every run of
+this rank's shard through warm-up + simulation, followed, for N > 1, by the one RCCL all-gather of the objective /
+groundwater arrays.  `--config` picks the BASELINE.json configuration (default 3, the one the metric is quoted on):
 
-Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for every field.
+  2  1e4 LHS samples x daily 10 yr, per GPU (replicas for N > 1)                                   weak
+  3  1e5 LHS samples x hourly 10 yr per GPU, sample-sharded                       (headline)       weak
+  4  1e6 LHS samples x hourly 10 yr in total, sample-sharded over the N GPUs, gather of [N, 9]     strong
+  5  64 synthetic catchments x 1e4 samples x hourly 10 yr in total, catchment-sharded              strong
+
+Rank 0 prints ONE JSON line; DESIGN.md section 5 explains every field.  At N = 1 the line also carries, measured in
+the same run: `parity` (GPU against the CPU oracle on the rows the cpu_baseline leg simulates anyway),
+`flat_forcing` (the same workload with forcing that varies inside the day: the step loop instead of the interval
+engine) and `cpu_baseline`.
 """
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -36,6 +44,9 @@ FP64_VALU_PEAK_TFLOPS = 78.6    # 1/2 of the 157.3 TF fp32 vector peak (MI355X_M
 HBM_PEAK_GBS = 8000.0           # same table
 N_SIMD = 256 * 4                # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9                # peak engine clock, same table
+VALU_ISSUE_CYCLES = 4           # a wave64 fp64 (or any vector) instruction occupies its SIMD for 4 cycles
+PARITY_GATE = 1e-6              # BASELINE.json: discharge <= 1e-6 relative against the CPU reference path
+GW_OBS = 0.12667
 
 
 def synthetic_forcing(catchment=0, hourly=True):
@@ -50,6 +61,22 @@ def synthetic_forcing(catchment=0, hourly=True):
     return np.stack([np.repeat(rain_d / 24, 24), np.repeat(pe_d / 24, 24)], axis=1), rng
 
 
+def hourly_varying_forcing(base, seed=3):
+    """The same daily totals spread UNEVENLY over the hours of each day (rain in ~6 random hours, PE on a daytime
+    sine): genuinely sub-daily forcing, which the interval engine does not apply to."""
+    rng = np.random.default_rng(seed)
+    days = base.shape[0] // 24
+    wts = rng.random((days, 24)) * (rng.random((days, 24)) < 0.25)
+    wts[wts.sum(1) == 0, 0] = 1.0
+    wts /= wts.sum(1, keepdims=True)
+    out = base.copy()
+    out[:, 0] = (base[::24, 0][:, None] * 24 * wts).ravel()
+    day = np.maximum(0.0, np.sin(np.pi * (np.arange(24) - 5) / 14))
+    day /= day.sum()
+    out[:, 1] = (base[::24, 1][:, None] * 24 * day[None, :]).ravel()
+    return out
+
+
 def wet_fraction(forcing, n_warm, t_lo=0.9, t_hi=1.1):
     """Realised fraction of executed sample-steps on the wet branch (rain * T - peva >= 0, T ~ U[t_lo, t_hi])."""
     f = np.concatenate([forcing[:n_warm], forcing])
@@ -59,9 +86,22 @@ def wet_fraction(forcing, n_warm, t_lo=0.9, t_hi=1.1):
     return float(np.mean(np.clip((t_hi - thr) / (t_hi - t_lo), 0.0, 1.0)))
 
 
-def cpu_baseline(forcing, n_warm, gap, budget_s=12.0):
-    """The oracle's OpenMP batch runner (a C port of the reference loop) on the host cores, on a bounded sample of
-    the same workload.  Reported next to the GPU number; never part of the timed GPU region."""
+def kernel_source_hash():
+    """sha256 over the kernel sources: a PMC summary is only quoted for the code it was measured on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'smartpy_amd', 'csrc')
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(('.hip', '.h', '.cpp')):
+            with open(os.path.join(csrc, name), 'rb') as fh:
+                h.update(name.encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline_and_parity(forcing, n_warm, gap, dt, device, budget_s=12.0):
+    """(1) The oracle's OpenMP batch runner (a C port of the reference loop) on the host cores, on a bounded sample of
+    the same workload: reported next to the GPU number, never part of the timed GPU region.  (2) The same rows through
+    the engine: the largest relative difference of the discharge and of the groundwater ratio -- parity measured in
+    the run that reports the throughput."""
     from oracle import smart_oracle as so
     cores = so.max_threads()
     rain, pe = np.ascontiguousarray(forcing[:, 0]), np.ascontiguousarray(forcing[:, 1])
@@ -71,20 +111,49 @@ def cpu_baseline(forcing, n_warm, gap, budget_s=12.0):
     def run(n):
         p = latin_hypercube(n, ranges, seed=99)
         t0 = time.perf_counter()
-        so.run_batch(AREA, 3600.0, T, n_warm, rain, pe, p, EXTRA, so.REPORT_SUMMARY, gap, want_discharge=True,
-                     n_threads=cores)
-        return time.perf_counter() - t0
+        dis, gw, _ = so.run_batch(AREA, dt, T, n_warm, rain, pe, p, EXTRA, so.REPORT_SUMMARY, gap,
+                                  want_discharge=True, n_threads=cores)
+        return time.perf_counter() - t0, p, dis, gw
 
     run(2 * cores)                      # first touch of the per-thread tables, thread start-up
     probe_n = 8 * cores
-    probe = run(probe_n)
+    probe = run(probe_n)[0]
     n = int(max(probe_n, min(4096, probe_n * budget_s / max(probe, 1e-3))))
     n -= n % cores
-    dt = run(n)
-    return {'value': n * (T + n_warm) / dt, 'unit': 'sample-timesteps/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d LHS samples x %d steps (hourly 10 yr + 365 d warm-up), oracle/smart_oracle.c with OpenMP, '
-                      '%.1f s' % (n, T + n_warm, dt),
-            'reference_python_1core': 6.9e4}
+    secs, p, want, want_gw = run(n)
+    cpu = {'value': n * (T + n_warm) / secs, 'unit': 'sample-timesteps/s', 'cores': cores, 'kind': 'port',
+           'sample': '%d LHS samples x %d steps (%d + warm-up %d), oracle/smart_oracle.c with OpenMP, %.1f s'
+                     % (n, T + n_warm, T, n_warm, secs),
+           'reference_python_1core': 6.9e4}
+    got = engine.run_ensemble(p, forcing, AREA, dt, n_warm, gap, extra=EXTRA, device=device)
+    dis = got.discharge.cpu().numpy()
+    gw = got.gw.cpu().numpy()
+    rel = float(np.max(np.abs(dis - want) / np.maximum(np.abs(want), 1e-300)))
+    gw_abs = float(np.max(np.abs(gw - want_gw)))
+    parity = {'max_rel_discharge': rel, 'max_abs_gw_ratio': gw_abs, 'gate': PARITY_GATE,
+              'ok': bool(rel <= PARITY_GATE and gw_abs <= PARITY_GATE),
+              'against': 'oracle/smart_oracle.c (reference operation order, libm pow, numpy summation order)',
+              'rows': n, 'values': int(dis.size)}
+    return cpu, parity
+
+
+def timed_steps(step, n_steps, n_warmup, device):
+    """W untimed steps, then K steps between barrier + synchronize on both sides.  Returns (wall seconds, max over
+    ranks; mean HIP-event milliseconds of a step on the stream the kernels are launched on)."""
+    for _ in range(n_warmup):
+        step()
+    sdist.barrier()
+    torch.cuda.synchronize(device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)]
+    t0 = time.perf_counter()
+    for k in range(n_steps):
+        ev[k][0].record()
+        res = step()
+        ev[k][1].record()
+    torch.cuda.synchronize(device)
+    sdist.barrier()
+    elapsed = sdist.max_over_ranks(time.perf_counter() - t0, device)
+    return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev])), res
 
 
 def main():
@@ -92,11 +161,12 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--samples', type=int, default=100000, help='samples per GPU')
+    ap.add_argument('--config', type=int, default=3, choices=[2, 3, 4, 5], help='BASELINE.json configuration')
+    ap.add_argument('--samples', type=int, default=None, help='override the sample count of the configuration')
     ap.add_argument('--math', default='fast', choices=['fast', 'literal'])
     ap.add_argument('--no-discharge', action='store_true', help='do not write the [R, N] discharge matrix')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--sort-col', type=int, default=-1, help='experiment: sort the sample rows by this parameter column')
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip cpu_baseline and the in-run parity check')
+    ap.add_argument('--no-flat', action='store_true', help='skip the flat_forcing leg')
     args = ap.parse_args()
 
     rank, world, device = sdist.init()
@@ -106,108 +176,157 @@ def main():
     if device.type != 'cuda':
         raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
 
-    forcing, rng = synthetic_forcing(0, hourly=True)
-    T, W, gap = forcing.shape[0], WARM_DAYS * 24, 24
-    n_local = args.samples
+    cfg = args.config
+    hourly = cfg != 2
+    dt, gap = (3600.0, 24) if hourly else (86400.0, 1)
+    W = WARM_DAYS * (24 if hourly else 1)
+    forcing, rng = synthetic_forcing(0, hourly=hourly)
+    T = forcing.shape[0]
+    R = T // gap
     ranges = Parameters().ranges
-    params = latin_hypercube(n_local, ranges, seed=2718 + rank)       # this rank's shard of the ensemble
-    if args.sort_col >= 0:
-        params = params[np.argsort(params[:, args.sort_col], kind='stable')]
     d_forcing = torch.from_numpy(forcing).to(device)
-    d_params = torch.from_numpy(params).to(device)
 
     # observations: discharge of the "truth" parameter set (computed by the engine itself) x lognormal noise, 12 % NaN
-    truth = engine.run_ensemble(np.array([TRUTH]), d_forcing, AREA, 3600.0, W, gap, extra=EXTRA, device=device)
-    obs = truth.discharge[0].cpu().numpy() * np.exp(rng.normal(0.0, 0.2, T // gap))
-    obs[rng.random(T // gap) < 0.12] = np.nan
-    d_obs = torch.from_numpy(obs).to(device)
-    R = T // gap
-    d_dis = None if args.no_discharge else torch.empty((1, R, n_local), dtype=torch.float64, device=device)
+    truth = engine.run_ensemble(np.array([TRUTH]), d_forcing, AREA, dt, W, gap, extra=EXTRA, device=device)
+    obs = truth.discharge[0].cpu().numpy() * np.exp(rng.normal(0.0, 0.2, R))
+    obs[rng.random(R) < 0.12] = np.nan
 
-    def one_step():
-        out = engine.run_ensemble(d_params, d_forcing, AREA, 3600.0, W, gap, extra=EXTRA, obs=d_obs, gw_obs=0.12667,
-                                  math_mode=args.math, want_discharge=False, discharge_out=d_dis, device=device)
-        if world > 1:   # the path's only exchange: objective functions + gw of every shard, one all-gather
-            res = torch.cat([out.objfn, out.gw.unsqueeze(1)], dim=1)
-            return sdist.gather_rows(res, n_local * world)
-        return out.objfn
+    store = not args.no_discharge and cfg in (2, 3)     # configs 4 and 5 gather objective functions only
+    kw = dict(extra=EXTRA, math_mode=args.math, want_discharge=store, device=device)
+    if cfg in (2, 3):
+        n_local = args.samples or (100000 if cfg == 3 else 10000)
+        n_runs_total = n_local * world
+        params = latin_hypercube(n_local, ranges, seed=2718 + rank)       # this rank's own block of the ensemble
+        d_params = torch.from_numpy(params).to(device)
+        job = sdist.ShardedEnsemble(d_params, d_forcing, AREA, dt, W, gap, axis='samples', local_block=True,
+                                    obs=obs, gw_obs=GW_OBS, **kw)
+        scaling, shard = 'weak', 'sample-shard x%d' % world
+        what = '%d-sample LHS ensemble per GPU x %s 10-yr synthetic forcing' % (n_local, 'hourly' if hourly else 'daily')
+        blocks_local = math.ceil(n_local / 64)
+    elif cfg == 4:
+        n_total = args.samples or 1000000
+        params = latin_hypercube(n_total, ranges, seed=2718)              # the same matrix on every rank, cut by rows
+        lo, hi = sdist.shard_bounds(n_total, world, rank)
+        d_params = torch.from_numpy(params[lo:hi]).to(device)
+        job = sdist.ShardedEnsemble(torch.from_numpy(params).to(device), d_forcing, AREA, dt, W, gap, axis='samples',
+                                    obs=obs, gw_obs=GW_OBS, **kw)
+        n_runs_total, n_local = n_total, hi - lo
+        scaling, shard = 'strong', 'sample-shard x%d' % world
+        what = '%d-sample LHS ensemble in total (%d per GPU) x hourly 10-yr synthetic forcing' % (n_total, n_local)
+        blocks_local = math.ceil(n_local / 64)
+    else:
+        C, n_per = 64, args.samples or 10000
+        params = latin_hypercube(n_per, ranges, seed=2718)
+        d_params = torch.from_numpy(params).to(device)
+        areas = np.exp(np.random.default_rng(12345).uniform(np.log(20e6), np.log(2000e6), C))
+        obs_c = np.tile(obs, (C, 1))
+        job = sdist.ShardedEnsemble(torch.from_numpy(params).to(device), lambda c: synthetic_forcing(c, True)[0],
+                                    areas, dt, W, gap, axis='catchments', n_catchments=C, obs=obs_c, gw_obs=GW_OBS,
+                                    **kw)
+        n_runs_total, n_local = C * n_per, job.n_local * n_per
+        scaling, shard = 'strong', 'catchment-shard x%d' % world
+        what = '%d synthetic catchments x %d samples each in total (%d catchments per GPU) x hourly 10-yr forcing' \
+               % (C, n_per, job.n_local)
+        blocks_local = math.ceil(n_per / 64) * job.n_local
 
-    for _ in range(args.warmup):
-        one_step()
-    sdist.barrier()
-    torch.cuda.synchronize(device)
-    # HIP events on the stream the kernels are launched on (the engine launches on torch's current stream)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        res = one_step()
-        ev[k][1].record()
-    torch.cuda.synchronize(device)
-    sdist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = sdist.max_over_ranks(elapsed, device)
-    launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    assert bool(torch.isfinite(res[:, :7]).all())
+    elapsed, launch_ms, res = timed_steps(job.step, args.steps, args.warmup, device)
+    job.verify()                                         # status word of the last launch: no slice timed out
+    assert bool(torch.isfinite(res[..., :7]).all())
 
     if rank == 0:
-        steps_per_launch = n_local * (W + T)                      # executed sample-timesteps per rank per step
-        value = world * steps_per_launch * args.steps / elapsed
+        steps_per_run = W + T
+        units_per_step = n_runs_total * steps_per_run            # executed sample-timesteps, all ranks, per step
+        units_per_launch = n_local * steps_per_run               # ... of rank 0's launch
+        value = units_per_step * args.steps / elapsed
         w = wet_fraction(forcing, W)
-        flops_per_step = 105.0 + 121.0 * w                         # literal operation count
-        bytes_per_step = (0.0 if args.no_discharge else 8.0 / gap * T / (W + T)) \
-            + 16.0 / n_local + (80.0 + 64.0 + 8.0) / (W + T)
+        flops_per_step = 105.0 + 121.0 * w                        # literal operation count
+        bytes_per_step = (8.0 / gap * T / (W + T) if store else 0.0) + 16.0 / max(n_local, 1) \
+            + (80.0 + 64.0 + 8.0) / (W + T)
         kern_s = launch_ms * 1e-3
-        traffic = executed = None
+        kernels = job.prepared.describe()
+        pmc_key = 'config%d:runs_per_gpu=%d:discharge=%d:math=%s' % (cfg, n_local, int(store), args.math)
+
+        # ---- roofline of the dominant kernel.  The binding roof is fp64 vector-ALU issue:
+        # frac = vector instructions the kernel executes x 4 issue cycles / the issue cycles 1,024 SIMDs have in one
+        # launch.  The instruction count is a property of (kernel build, workload): it comes from the committed PMC
+        # summary of this same command and is only quoted while the kernel sources hash to what was profiled.
+        traffic = insts = held_clock = None
+        pmc_note = 'no PMC summary for this workload'
         tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
         if os.path.exists(tpath):
             with open(tpath) as fh:
-                pmc = json.load(fh)
-            traffic = pmc.get('hbm_bytes_per_launch')
-            if pmc.get('valu_insts_per_launch') and n_local == 100000 and not args.no_discharge and args.math == 'fast':
-                # executed view: vector-ALU wave-instructions (PMC SQ_INSTS_VALU of the committed profile of this
-                # same command) x 4 issue cycles, over the issue cycles the chip's 1,024 SIMDs have in one launch
-                insts = float(pmc['valu_insts_per_launch'])
-                executed = {'valu_insts_per_launch': insts,
-                            'valu_insts_per_wave_step': insts / (math.ceil(n_local / 64) * (W + T)),
-                            'issue_frac': insts * 4.0 / (N_SIMD * kern_s * CLOCK_HZ),
-                            'source': 'profiles/traffic_latest.json'}
+                pmc_all = json.load(fh)
+            pmc = pmc_all.get('workloads', {}).get(pmc_key)
+            if pmc is None:
+                pmc_note = 'profiles/traffic_latest.json holds no PMC summary for workload %s' % pmc_key
+            elif pmc.get('source_hash') == kernel_source_hash():
+                traffic = pmc.get('hbm_bytes_per_launch')
+                insts = pmc.get('valu_insts_per_launch')
+                held_clock = pmc.get('held_clock_hz')
+                pmc_note = pmc.get('source', 'profiles/traffic_latest.json')
+            else:
+                pmc_note = 'profiles/traffic_latest.json was measured on other kernel sources (hash %s, now %s): ' \
+                           'not quoted' % (pmc.get('source_hash'), kernel_source_hash())
+        issue = None if insts is None else insts * VALU_ISSUE_CYCLES / (N_SIMD * kern_s * CLOCK_HZ)
+        roofline = {
+            'bound': 'valu-fp64-issue',
+            'achieved': None if insts is None else insts / kern_s / 1e12,
+            'peak': N_SIMD * CLOCK_HZ / VALU_ISSUE_CYCLES / 1e12,
+            'unit': 'T wave-instructions/s',
+            'frac': issue,
+            'clock_basis_hz': CLOCK_HZ,
+            'frac_at_held_clock': None if insts is None or not held_clock else
+            insts * VALU_ISSUE_CYCLES / (N_SIMD * kern_s * held_clock),
+            'held_clock_hz': held_clock,
+            'valu_insts_per_launch': insts,
+            'valu_insts_per_wave_step': None if insts is None else insts / (blocks_local * steps_per_run),
+            'kernel': kernels, 'launch_ms': launch_ms, 'traffic': traffic, 'pmc_key': pmc_key, 'pmc_source': pmc_note,
+            # the reference's literal operation count against the fp64 vector peak: NOT a bound (the kernel executes
+            # fewer operations than the reference writes down), kept as the algorithmic ratio
+            'algorithmic_ratio': {'flops_per_sample_step': flops_per_step,
+                                  'tflops': units_per_launch * flops_per_step / kern_s / 1e12,
+                                  'peak_tflops': FP64_VALU_PEAK_TFLOPS,
+                                  'ratio': units_per_launch * flops_per_step / kern_s / 1e12 / FP64_VALU_PEAK_TFLOPS},
+            'hbm': {'bound': 'hbm', 'achieved': units_per_launch * bytes_per_step / kern_s / 1e9,
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': units_per_launch * bytes_per_step / kern_s / 1e9 / HBM_PEAK_GBS,
+                    'bytes_per_sample_step': bytes_per_step},
+        }
         line = {
             'metric': 'MC sample-timesteps/sec/GPU; 1e5 LHS x hourly 10-yr forcing',
             'value': value, 'unit': 'sample-timesteps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'configs[2]: %d-sample LHS ensemble per GPU x hourly 10-yr synthetic forcing '
-                                   '(T=%d + warm-up %d steps), summary report gap %d, objective functions fused, '
-                                   'discharge %s' % (n_local, T, W, gap, 'not stored' if args.no_discharge
-                                                     else 'stored [R,N]'),
-                       'samples_per_gpu': n_local, 'n_steps': T, 'n_warm': W, 'math_mode': args.math,
-                       'wet_fraction': w, 'parallelism': 'sample-shard x%d' % world},
+            'scaling': scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'configs[%d]: %s (T=%d + warm-up %d steps), summary report gap %d, objective '
+                                   'functions fused, discharge %s; forcing constant within each report interval '
+                                   '(daily values spread over the steps of the day, the reference\'s own input format)'
+                                   % (cfg - 1, what, T, W, gap, 'stored [R,N]' if store else 'not stored'),
+                       'runs_total': n_runs_total, 'runs_per_gpu': n_local, 'n_steps': T, 'n_warm': W,
+                       'math_mode': args.math, 'wet_fraction': w, 'parallelism': shard},
             'per_gpu': value / world,
             # the same rate counting the simulated steps only (the warm-up replays W of them)
-            'value_without_warmup': world * n_local * T * args.steps / elapsed,
-            'roofline': {
-                'bound': 'valu-fp64', 'achieved': steps_per_launch * flops_per_step / kern_s / 1e12,
-                'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': steps_per_launch * flops_per_step / kern_s / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                'flops_per_sample_step': flops_per_step, 'kernel': 'smart_ensemble_' + args.math,
-                'launch_ms': launch_ms,
-                'traffic': traffic,
-                'executed': executed,
-                'note': 'achieved = the reference\'s literal operation count F(w) = 105 + 121 w per sample-step '
-                        '(SURVEY.md 8d) x sample-steps / launch time; the kernel executes fewer operations than '
-                        'that count (DESIGN.md 4.1), so frac can exceed 1 -- `executed` is the instruction-issue view',
-                'hbm': {'bound': 'hbm', 'achieved': steps_per_launch * bytes_per_step / kern_s / 1e9,
-                        'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': steps_per_launch * bytes_per_step / kern_s / 1e9 / HBM_PEAK_GBS,
-                        'bytes_per_sample_step': bytes_per_step},
-            },
+            'value_without_warmup': n_runs_total * T * args.steps / elapsed,
+            'roofline': roofline,
         }
+        if world == 1 and cfg in (3, 4) and not args.no_flat and args.math == 'fast':
+            # the same workload with forcing that varies inside the report interval: the step loop (smart_fast_steps)
+            vary = hourly_varying_forcing(forcing)
+            flat = engine.prepare_ensemble(d_params, vary, AREA, dt, W, gap, obs=obs, gw_obs=GW_OBS, **kw)
+            f_elapsed, f_ms, _ = timed_steps(flat.launch, max(2, args.steps // 2), 1, device)
+            flat.verify()
+            line['flat_forcing'] = {
+                'what': 'same runs, daily totals spread unevenly over the hours (rain in ~6 random hours, PE on a '
+                        'daytime sine): forcing varies inside the report interval, the interval engine does not apply',
+                'kernel': flat.describe(), 'launch_ms': f_ms, 'value': units_per_launch / (f_ms * 1e-3),
+                'unit': 'sample-timesteps/s', 'wet_fraction': wet_fraction(vary, W)}
+            del flat
         if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline(forcing, W, gap)
+            line['cpu_baseline'], line['parity'] = cpu_baseline_and_parity(forcing, W, gap, dt, device)
         elif not args.no_cpu_baseline:
-            line['cpu_baseline'] = None
+            line['cpu_baseline'] = line['parity'] = None
         print(json.dumps(line), flush=True)
+        if line.get('parity') and not line['parity']['ok']:
+            raise SystemExit('bench.py: in-run parity check failed: %r' % (line['parity'],))
     sdist.barrier()
     if sdist.is_distributed():
         torch.distributed.destroy_process_group()

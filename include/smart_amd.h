@@ -164,6 +164,10 @@ int smart_plan_ensemble(const SmartEnsemble *e, int32_t *plan);
  * e->stream.  0 without a workspace. */
 int smart_launch_status(const SmartEnsemble *e, int32_t *status);
 
+/* Which kernels smart_run_ensemble_hip would launch for *e on the current device, as text for logs and benchmark
+ * lines: e.g. "smart_fast_intervals[16 slices x 1563 blocks, 2 resident per SIMD]".  Launches nothing. */
+int smart_describe_launch(const SmartEnsemble *e, char *text, int64_t len);
+
 /*
  * smartcpp.allsteps -- same arguments and results as run_all_steps (structure.py:149-152,197).
  * HOST pointers; synchronous (copies in, runs one sample on the GPU in SMART_MATH_LITERAL, copies out).

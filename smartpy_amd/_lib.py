@@ -44,6 +44,7 @@ SYMBOLS = {
     'smart_workspace_bytes': (ctypes.c_int64, [ctypes.POINTER(SmartEnsemble)]),
     'smart_plan_ensemble': (ctypes.c_int, [ctypes.POINTER(SmartEnsemble), ctypes.POINTER(ctypes.c_int32)]),
     'smart_launch_status': (ctypes.c_int, [ctypes.POINTER(SmartEnsemble), ctypes.POINTER(ctypes.c_int32)]),
+    'smart_describe_launch': (ctypes.c_int, [ctypes.POINTER(SmartEnsemble), ctypes.c_char_p, ctypes.c_int64]),
     'smart_allsteps_hip': (ctypes.c_int, [ctypes.c_double, ctypes.c_double, ctypes.c_int64, _dp, _dp, _dp, _dp,
                                           ctypes.c_int32, ctypes.c_int64, _dp, _dp, _dp]),
     'smart_onestep_hip': (ctypes.c_int, [ctypes.c_int64, _dp, _dp]),

@@ -483,6 +483,57 @@ static hipError_t launch_kernel(FastKernel k, KArgs a, dim3 grid, size_t lds, hi
     return hipLaunchKernel(fast_kernel(k), grid, dim3(kWave), args, lds, s);
 }
 
+// What a SMART_MATH_FAST call launches: the kernels (smart_fast_entry.h), sliced or not, and the load figures behind
+// the choices.  Shared by the launch itself and by smart_describe_launch.
+struct Decision {
+    Launch todo[kMaxAux + 1];
+    int n_todo = 0;
+    int n_seg = 1, per_simd = 0, exits = 0;
+    int class_mask = 0, pc_mask = 0;
+    bool intervals = false;
+    double load = 0.0; // blocks of 64 samples per SIMD
+};
+
+static int decide(const SmartEnsemble *e, const DeviceCtx *d, const Workspace &w, Decision *out)
+{
+    Decision &x = *out;
+    x.intervals = e->report_type == SMART_REPORT_SUMMARY && e->report_gap >= 2; // the merged summary kernels apply
+    const int plan = (e->plan & SMART_PLAN_VALID) ? e->plan : 0x3f;
+    x.n_seg = plan_time_slices(e, d->n_simd, &x.per_simd, &x.load);
+    // the hand-over buffer of a time-sliced launch sits behind the observation statistics in the caller's workspace;
+    // a workspace without room for it means a plain launch
+    if (x.n_seg > 1 && (!w.slices || w.slice_room < slice_bytes(e->n_samples, e->n_catchments)))
+        x.n_seg = 1;
+    // early exits in the interval engine pay off once the SIMDs have two or more waves to issue from
+    // (FastModel::kExits; measured: off wins by 5 % at 1.53 blocks per SIMD, on wins by 4 % at 2.0, by 7 % at 15)
+    const char *env = getenv("SMART_EXITS");
+    x.exits = env ? atoi(env) != 0 : x.load >= 1.75;
+    x.class_mask = plan & 0xf;
+    if (plan & SMART_PLAN_CLASS_REGULAR) {
+        if (x.intervals) {
+            if (plan & SMART_PLAN_FORCING_PIECEWISE) {
+                x.todo[x.n_todo++] = {e->final_vars ? kIntervalsStates : (x.exits ? kIntervalsExits : kIntervals), true};
+                x.pc_mask |= 1;
+            }
+            if (plan & SMART_PLAN_FORCING_VARYING) {
+                x.todo[x.n_todo++] = {e->final_vars ? kStepsStates : kSteps, true};
+                x.pc_mask |= 2;
+            }
+        } else {
+            x.todo[x.n_todo++] = {kPlain, false};
+        }
+    }
+    if (plan & SMART_PLAN_CLASS_STIFF)
+        x.todo[x.n_todo++] = {kStiff, false};
+    if (plan & SMART_PLAN_CLASS_GUARD)
+        x.todo[x.n_todo++] = {kGuard, false};
+    if (plan & SMART_PLAN_CLASS_ILLCOND)
+        x.todo[x.n_todo++] = {kIllCond, false};
+    if (x.n_todo == 0)
+        return fail(SMART_E_SIZE, "the plan names no class of rows");
+    return SMART_OK;
+}
+
 static int run(const SmartEnsemble *e)
 {
     int rc = check(e);
@@ -508,49 +559,13 @@ static int run(const SmartEnsemble *e)
     DeviceCtx *d = device_ctx();
     if (!d)
         return fail(SMART_E_NO_DEVICE, "cannot query the current HIP device");
-
-    // ---- which kernels does this call need? (smart_fast_entry.h)
-    const bool intervals = e->report_type == SMART_REPORT_SUMMARY && a.gap >= 2; // the merged summary kernels apply
-    const int plan = (e->plan & SMART_PLAN_VALID) ? e->plan : 0x3f;
-    int per_simd = 0;
-    double load = 0.0; // blocks of 64 samples per SIMD
-    int n_seg = plan_time_slices(e, d->n_simd, &per_simd, &load);
-    // the hand-over buffer of a time-sliced launch sits behind the observation statistics in the caller's workspace;
-    // a workspace without room for it means a plain launch
-    if (n_seg > 1 && (!w.slices || w.slice_room < slice_bytes(e->n_samples, e->n_catchments)))
-        n_seg = 1;
-    // early exits in the interval engine pay off once the SIMDs have two or more waves to issue from
-    // (FastModel::kExits; measured: off wins by 5 % at 1.53 blocks per SIMD, on wins by 4 % at 2.0, by 7 % at 15)
-    {
-        const char *env = getenv("SMART_EXITS");
-        a.exits = env ? atoi(env) != 0 : load >= 1.75;
-    }
-    Launch todo[kMaxAux + 1];
-    int n_todo = 0;
-    a.class_mask = plan & 0xf;
-    a.pc_mask = 0;
-    if (plan & SMART_PLAN_CLASS_REGULAR) {
-        if (intervals) {
-            if (plan & SMART_PLAN_FORCING_PIECEWISE) {
-                todo[n_todo++] = {e->final_vars ? kIntervalsStates : (a.exits ? kIntervalsExits : kIntervals), true};
-                a.pc_mask |= 1;
-            }
-            if (plan & SMART_PLAN_FORCING_VARYING) {
-                todo[n_todo++] = {e->final_vars ? kStepsStates : kSteps, true};
-                a.pc_mask |= 2;
-            }
-        } else {
-            todo[n_todo++] = {kPlain, false};
-        }
-    }
-    if (plan & SMART_PLAN_CLASS_STIFF)
-        todo[n_todo++] = {kStiff, false};
-    if (plan & SMART_PLAN_CLASS_GUARD)
-        todo[n_todo++] = {kGuard, false};
-    if (plan & SMART_PLAN_CLASS_ILLCOND)
-        todo[n_todo++] = {kIllCond, false};
-    if (n_todo == 0)
-        return fail(SMART_E_SIZE, "the plan names no class of rows");
+    Decision x;
+    if ((rc = decide(e, d, w, &x)))
+        return rc;
+    const int n_seg = x.n_seg, n_todo = x.n_todo;
+    a.exits = x.exits;
+    a.class_mask = x.class_mask;
+    a.pc_mask = x.pc_mask;
 
     // ---- workspace header, forcing flags, slice counters
     KArgs a_sliced = a;
@@ -564,7 +579,7 @@ static int run(const SmartEnsemble *e)
     }
     if (w.hdr) {
         reset_workspace(w, e->n_catchments, a_sliced.seg_flag, n_seg > 1 ? a.seg_blocks : 0, s);
-        if (intervals && (plan & SMART_PLAN_CLASS_REGULAR)) {
+        if (x.intervals && (x.class_mask & SMART_PLAN_CLASS_REGULAR)) {
             scan_forcing(e, w, s);
             a.not_pc = a_sliced.not_pc = w.not_pc;
         }
@@ -576,18 +591,13 @@ static int run(const SmartEnsemble *e)
         if (l.sliced && n_seg > 1) {
             // dynamic LDS is requested only to cap the resident workgroups at `per_simd` per SIMD (working + waiting;
             // beyond 3 the register file is the limit anyway)
-            const size_t lds = per_simd <= 3 ? lds_for_residency(d, l.k, 4 * per_simd) : 0;
-            if (getenv("SMART_DEBUG"))
-                fprintf(stderr, "smart_amd: %s, %d slices x %ld blocks, %d resident per SIMD (dynamic LDS %zu B)\n",
-                        kFastKernelNames[l.k], n_seg, (long)a.seg_blocks, per_simd, lds);
+            const size_t lds = x.per_simd <= 3 ? lds_for_residency(d, l.k, 4 * x.per_simd) : 0;
             return launch_kernel(l.k, a_sliced, dim3((unsigned)(a.seg_blocks * n_seg), 1), lds, st);
         }
-        if (getenv("SMART_DEBUG"))
-            fprintf(stderr, "smart_amd: %s, %ld blocks\n", kFastKernelNames[l.k], (long)a.seg_blocks);
         return launch_kernel(l.k, a, grid, 0, st);
     };
     if (n_todo == 1) {
-        HIP_TRY(launch(todo[0], s));
+        HIP_TRY(launch(x.todo[0], s));
         return SMART_OK;
     }
     if (!d->fork) {
@@ -600,12 +610,49 @@ static int run(const SmartEnsemble *e)
     HIP_TRY(hipEventRecord(d->fork, s));
     for (int i = 1; i < n_todo; ++i) {
         HIP_TRY(hipStreamWaitEvent(d->aux[i - 1], d->fork, 0));
-        HIP_TRY(launch(todo[i], d->aux[i - 1]));
+        HIP_TRY(launch(x.todo[i], d->aux[i - 1]));
         HIP_TRY(hipEventRecord(d->join[i - 1], d->aux[i - 1]));
     }
-    HIP_TRY(launch(todo[0], s));
+    HIP_TRY(launch(x.todo[0], s));
     for (int i = 1; i < n_todo; ++i)
         HIP_TRY(hipStreamWaitEvent(s, d->join[i - 1], 0));
+    return SMART_OK;
+}
+
+static int describe(const SmartEnsemble *e, char *text, int64_t len)
+{
+    if (!text || len < 1)
+        return fail(SMART_E_NULL, "smart_describe_launch: no room for the text");
+    text[0] = 0;
+    int rc = check(e);
+    if (rc)
+        return rc;
+    if (e->math_mode == SMART_MATH_LITERAL) {
+        snprintf(text, (size_t)len, "smart_ensemble_literal");
+        return SMART_OK;
+    }
+    if ((rc = device_ready()))
+        return rc;
+    DeviceCtx *d = device_ctx();
+    if (!d)
+        return fail(SMART_E_NO_DEVICE, "cannot query the current HIP device");
+    Decision x;
+    if ((rc = decide(e, d, carve(e), &x)))
+        return rc;
+    const long blocks = (e->n_samples + kWave - 1) / kWave * e->n_catchments;
+    size_t used = 0;
+    for (int i = 0; i < x.n_todo && used + 1 < (size_t)len; ++i) {
+        int n;
+        if (x.todo[i].sliced && x.n_seg > 1)
+            n = snprintf(text + used, (size_t)len - used, "%s%s[%d slices x %ld blocks, %d resident per SIMD]",
+                         i ? " + " : "", kFastKernelNames[x.todo[i].k], x.n_seg, blocks, x.per_simd);
+        else
+            n = snprintf(text + used, (size_t)len - used, "%s%s[%ld blocks]", i ? " + " : "",
+                         kFastKernelNames[x.todo[i].k], blocks);
+        if (n < 0)
+            break;
+        used += (size_t)n;
+    }
     return SMART_OK;
 }
 
@@ -695,6 +742,8 @@ int smart_run_ensemble_hip(const SmartEnsemble *e) { return run(e); }
 int smart_plan_ensemble(const SmartEnsemble *e, int32_t *plan) { return make_plan(e, plan); }
 
 int smart_launch_status(const SmartEnsemble *e, int32_t *status) { return launch_status(e, status); }
+
+int smart_describe_launch(const SmartEnsemble *e, char *text, int64_t len) { return describe(e, text, len); }
 
 int smart_allsteps_hip(double area_m2, double delta_sec, int64_t length_simu, const double *nd_rain,
                        const double *nd_peva, const double *nd_parameters, const double *nd_initial,

@@ -1,4 +1,5 @@
-"""Sharding of the sample axis over the GPUs of a node, one process per GPU.
+"""Sharding of an ensemble over the GPUs of a node, one process per GPU: along the sample axis, or -- for a
+catchment x sample batch -- along the catchment axis.
 
 The reference parallelises the same axis through spotpy's MPI job farm (lhs.py:75-89, montecarlo.py:153):
 rank 0 hands one parameter vector to a worker and gets (discharge, [gw]) back, pickled, one sample at a
@@ -6,6 +7,11 @@ time.  Here every rank runs a contiguous block of ceil(N / world) rows of the sa
 and the only exchange is a single all-gather of the per-sample results ([N_local, 8] objective functions and
 [N_local] groundwater ratios: 72 bytes per sample) over RCCL (torch.distributed backend "nccl" on ROCm).
 Discharge series are never gathered (29 GB at N = 1e6): each rank keeps / writes its own shard.
+
+A catchment x sample batch (BASELINE config 5: 64 catchments x 1e4 samples) is cut along the CATCHMENT axis instead:
+rank r holds the forcing, areas and observations of its own block of catchments only (the forcing is the one large
+per-catchment input: 1.4 MB each), runs them as one launch with the catchment index on grid.y, and the same single
+all-gather returns [C, N, 9].  ShardedEnsemble below does either.
 
 The helpers work on CPU tensors with the gloo backend too, which is how tests/test_dist_gloo.py covers them.
 """
@@ -74,9 +80,11 @@ def barrier():
             dist.barrier()
 
 
-def gather_rows(local, n_rows_total):
+def gather_rows(local, n_rows_total, out=None):
     """All-gather row blocks produced under shard_bounds(): local [n_local, ...] -> [n_rows_total, ...] on every
-    rank.  One collective: blocks are padded to ceil(N / world) rows so that all_gather_into_tensor applies."""
+    rank.  One collective: blocks are padded to ceil(N / world) rows so that all_gather_into_tensor applies.
+    `out`: a [world * ceil(N / world), ...] buffer to gather into (repeated calls then allocate nothing when the
+    local block already has ceil(N / world) rows)."""
     if not is_distributed():
         return local
     world = dist.get_world_size()
@@ -89,9 +97,113 @@ def gather_rows(local, n_rows_total):
     device = local.device
     if device.type != 'cpu' and _host_staged():
         local = local.cpu()
-    out = torch.empty((world * per,) + tail, dtype=local.dtype, device=local.device)
+        out = None
+    if out is None:
+        out = torch.empty((world * per,) + tail, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out[:n_rows_total].to(device)
+
+
+def broadcast_matrix(matrix, src=0):
+    """Every rank gets rank `src`'s copy of a numpy matrix (shape and dtype included).  The Monte-Carlo classes call
+    this on their sample before sharding it: the reference's sampler draws from NumPy's unseeded global stream
+    (lhs.py:149,154), so processes started side by side would otherwise each hold a different matrix -- in the
+    reference's MPI mode only the master draws (spotpy's mpi sampler), which is what this restores."""
+    import numpy as np
+    if not is_distributed():
+        return matrix
+    device = torch.device('cpu') if _host_staged() else torch.device('cuda', torch.cuda.current_device())
+    head = [matrix.shape, str(matrix.dtype)] if dist.get_rank() == src else [None, None]
+    dist.broadcast_object_list(head, src=src)
+    if dist.get_rank() == src:
+        t = torch.from_numpy(np.ascontiguousarray(matrix)).to(device)
+    else:
+        t = torch.empty(tuple(head[0]), dtype=getattr(torch, head[1]), device=device)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+class ShardedEnsemble(object):
+    """This rank's part of an ensemble cut over the process group, prepared once (engine.prepare_ensemble) so that
+    step() = one launch + the one all-gather, nothing else.
+
+    axis='samples'     params [N, 10] is cut into contiguous row blocks; forcing / area / obs are shared.
+                       local_block=True: params already IS this rank's block (every rank drew its own rows, all
+                       blocks equally long): nothing is cut, the gathered matrix is the blocks in rank order.
+    axis='catchments'  the catchments are cut into contiguous blocks; `forcing` is either the full [C, T, 2] array or
+                       a callable c -> [T, 2] that is only asked for this rank's catchments; area_m2, obs, gw_obs,
+                       extra may be scalars / per-catchment arrays of the FULL batch (they are sliced here).
+    step() returns [N, 9] (samples) or [C, N, 9] (catchments) on every rank: the 8 objective functions and the
+    groundwater ratio of every run.  Without observations the objective columns are NaN."""
+
+    def __init__(self, params, forcing, area_m2, delta_sec, n_warm, report_gap, axis='samples', n_catchments=None,
+                 obs=None, gw_obs=None, extra=None, device=None, local_block=False, **kw):
+        import numpy as np
+        from . import engine
+        rank, world = rank_world()
+        self.axis = axis
+        self.device = torch.device(device) if device is not None else engine.default_device()
+        if axis == 'samples':
+            self.n_total = params.shape[0] * (world if local_block else 1)
+            lo, hi = (0, params.shape[0]) if local_block else shard_bounds(self.n_total, world, rank)
+            self.n_local = hi - lo
+            local_params = params[lo:hi] if hi > lo else params[:1]       # an empty shard still joins the collective
+            self._prep = engine.prepare_ensemble(local_params, forcing, area_m2, delta_sec, n_warm, report_gap,
+                                                 obs=obs, gw_obs=gw_obs, extra=extra, device=self.device, **kw)
+            n_run = local_params.shape[0]
+            tail = (9,)
+        elif axis == 'catchments':
+            C = int(n_catchments if n_catchments is not None else forcing.shape[0])
+            self.n_total = C
+            lo, hi = shard_bounds(C, world, rank)
+            self.n_local = hi - lo
+            cs = list(range(lo, hi)) if hi > lo else [0]
+
+            def per_catchment(x, shared_ndim):
+                """a scalar / shared array stays; an array with a leading catchment axis is cut to this rank's block"""
+                if x is None or isinstance(x, dict) or np.ndim(x) <= shared_ndim:
+                    return x
+                return x[cs]
+            f_local = np.stack([np.asarray(forcing(c), dtype=np.float64) for c in cs]) if callable(forcing) \
+                else forcing[cs]
+            self._prep = engine.prepare_ensemble(
+                per_catchment(params, 2), f_local, per_catchment(area_m2, 0), delta_sec, n_warm, report_gap,
+                obs=per_catchment(obs, 1), gw_obs=per_catchment(gw_obs, 0), extra=per_catchment(extra, 1),
+                device=self.device, **kw)
+            n_run = len(cs)
+            tail = (params.shape[-2], 9)
+        else:
+            raise Exception("axis must be 'samples' or 'catchments'")
+        per = -(-self.n_total // world)
+        self._packed = torch.full((max(per, n_run),) + tail, float('nan'), dtype=torch.float64, device=self.device)
+        self._n_run = n_run
+        self._gathered = torch.empty((world * per,) + tail, dtype=torch.float64, device=self.device) \
+            if is_distributed() and not _host_staged() else None
+
+    def step(self):
+        out = self._prep.launch()
+        k = self.n_local
+        if k:
+            if self.axis == 'samples':
+                if out.objfn is not None:
+                    self._packed[:k, :8].copy_(out.objfn[:k])
+                self._packed[:k, 8].copy_(out.gw[:k])
+            else:
+                objfn = out.objfn if out.objfn is None or out.objfn.dim() == 3 else out.objfn.unsqueeze(0)
+                gw = out.gw if out.gw.dim() == 2 else out.gw.unsqueeze(0)
+                if objfn is not None:
+                    self._packed[:k, :, :8].copy_(objfn[:k])
+                self._packed[:k, :, 8].copy_(gw[:k])
+        per = -(-self.n_total // rank_world()[1])
+        return gather_rows(self._packed[:per], self.n_total, out=self._gathered)
+
+    def verify(self):
+        """Status word of this rank's last launch (engine.PreparedEnsemble.verify)."""
+        return self._prep.verify()
+
+    @property
+    def prepared(self):
+        return self._prep
 
 
 def max_over_ranks(value, device):

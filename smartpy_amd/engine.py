@@ -173,6 +173,13 @@ class PreparedEnsemble(object):
             _lib.check(_lib.lib().smart_launch_status(ctypes.byref(self._e), ctypes.byref(word)))
         return int(word.value)
 
+    def describe(self):
+        """The kernels launch() enqueues on this device, as text (smart_describe_launch)."""
+        buf = ctypes.create_string_buffer(512)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().smart_describe_launch(ctypes.byref(self._e), buf, len(buf)))
+        return buf.value.decode()
+
     def verify(self):
         """Read the status word of the last launch and repair what it reports: a time slice that gave up waiting for
         its predecessor (never seen on an idle GPU; possible when the queue is preempted) -> the launch is repeated

@@ -47,7 +47,15 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['data'] == 'synthetic'
     assert 'workload' in d['config'] and 'model' not in d['config']
     r = d['roofline']
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['unit'] == 'TFLOP/s' and r['hbm']['unit'] == 'GB/s'
+    # the issue-slot fraction needs the PMC instruction count of this very workload and kernel build: absent for the
+    # reduced sample count used here, and then it is null rather than a number measured on something else
+    assert r['bound'] == 'valu-fp64-issue' and r['frac'] is None and 'no PMC summary' in r['pmc_source']
+    assert r['hbm']['unit'] == 'GB/s' and 0 < r['hbm']['frac'] < 1 and r['algorithmic_ratio']['ratio'] > 0
+    assert 'smart_fast_intervals' in r['kernel'] and r['launch_ms'] > 0
+    p = d['parity']
+    assert p['ok'] is True and p['max_rel_discharge'] <= 1e-9 and p['gate'] == 1e-6 and p['rows'] >= 64
+    f = d['flat_forcing']
+    assert 'smart_fast_steps' in f['kernel'] and 0 < f['value'] < d['value'] * 1.05
     assert abs(d['value'] - 20000 * 96432 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 1e6 and 'sample' in c

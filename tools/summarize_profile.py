@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 CSVs written by tools/profile.sh into a small markdown + json summary.
-usage: python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<name>"""
+usage: python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<name> [workload-key]
+With a workload key (bench.py prints it as roofline.pmc_key) the per-launch figures bench.py quotes -- HBM bytes,
+vector-instruction count, held clock -- are also entered into profiles/traffic_latest.json under that key."""
 import csv
 import glob
 import json
@@ -9,6 +11,13 @@ import sys
 from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else None
+
+
+def is_main(name):
+    """the time-loop kernels: smart_fast_* (one per variant) and smart_ensemble_literal"""
+    return 'smart_fast_' in name or 'smart_ensemble' in name
+
 out = {'source': src}
 lines = ['# rocprofv3 summary (%s)' % os.path.basename(src), '']
 
@@ -31,7 +40,7 @@ if stats:
 trace = glob.glob(os.path.join(src, 'trace', '**', '*kernel_trace.csv'), recursive=True)
 if trace:
     with open(trace[0]) as f:
-        rows = [r for r in csv.DictReader(f) if 'smart_ensemble' in r['Kernel_Name']]
+        rows = [r for r in csv.DictReader(f) if is_main(r['Kernel_Name'])]
     if rows:
         gmax = max(int(r['Grid_Size_X']) for r in rows)
         full = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows if int(r['Grid_Size_X']) == gmax]
@@ -53,11 +62,11 @@ for path in glob.glob(os.path.join(src, 'pmc_*', '**', '*counter_collection.csv'
         allrows += list(csv.DictReader(f))
 # the bench also launches the time-loop kernel once with N = 1 (the synthetic "truth" run): keep only the
 # full-size dispatches of the dominant kernel, and drop torch's / the runtime's helper kernels
-big = max([int(r['Grid_Size']) for r in allrows if 'smart_ensemble' in r['Kernel_Name']] or [0])
+big = max([int(r['Grid_Size']) for r in allrows if is_main(r['Kernel_Name'])] or [0])
 for row in allrows:
     if 'smart' not in row['Kernel_Name']:
         continue
-    if 'smart_ensemble' in row['Kernel_Name'] and int(row['Grid_Size']) != big:
+    if is_main(row['Kernel_Name']) and int(row['Grid_Size']) != big:
         continue
     pmc[row['Kernel_Name'].split('(')[0]][row['Counter_Name']].append(float(row['Counter_Value']))
 if pmc:
@@ -70,7 +79,7 @@ if pmc:
             out['pmc'][k][c] = sum(v) / len(v)
             lines.append('| `%s` | %s | %.6g | %d |' % (k[:60], c, sum(v) / len(v), len(v)))
     lines.append('')
-    main = [k for k in pmc if 'smart_ensemble' in k]
+    main = [k for k in pmc if is_main(k)]
     if main:
         c = out['pmc'][main[0]]
         if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
@@ -86,6 +95,44 @@ if pmc:
                       '- FETCH_SIZE = %.4g KiB -> %.4g MB raw, %.4g MB with the gfx950 x2 correction' % (c['FETCH_SIZE'], rd / 1e6, 2 * rd / 1e6),
                       '- WRITE_SIZE = %.4g KiB -> %.4g MB' % (c['WRITE_SIZE'], wr / 1e6),
                       '- traffic (corrected) = %.4g MB per launch' % ((2 * rd + wr) / 1e6), '']
+hash_file = os.path.join(src, 'source_hash.txt')
+if os.path.exists(hash_file):
+    out['source_hash'] = open(hash_file).read().strip()
+    lines += ['kernel sources at profile time: sha256[:16] = `%s` (bench.kernel_source_hash)' % out['source_hash'], '']
+main = [k for k in out.get('pmc', {}) if is_main(k)]
+if main and 'GRBM_GUI_ACTIVE' in out['pmc'][main[0]] and 'full_size_dispatch_ms' in out:
+    # GRBM_GUI_ACTIVE counts busy cycles of every XCD (8); over the kernel's duration in its own PMC pass that is the
+    # engine clock the chip actually held under this load
+    durs = []
+    for path in glob.glob(os.path.join(src, 'pmc_SQ_WAIT_ANY', '**', '*kernel_trace.csv'), recursive=True):
+        with open(path) as f:
+            rows = [r for r in csv.DictReader(f) if is_main(r['Kernel_Name'])]
+        gmax = max(int(r['Grid_Size_X']) for r in rows)
+        durs += [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e9 for r in rows if int(r['Grid_Size_X']) == gmax]
+    if durs:
+        out['held_clock_hz'] = out['pmc'][main[0]]['GRBM_GUI_ACTIVE'] / 8 / (sum(durs) / len(durs))
+        lines += ['## clock held during the kernel', '',
+                  '- GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same pass (%.4f ms) = %.3f GHz' % (
+                      sum(durs) / len(durs) * 1e3, out['held_clock_hz'] / 1e9), '']
+if workload and main and 'hbm_bytes_per_launch' in out:
+    tpath = os.path.join(os.path.dirname(dst) or '.', 'traffic_latest.json')
+    table = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    if 'workloads' not in table:
+        table = {'workloads': {}}
+    c = out['pmc'][main[0]]
+    table['workloads'][workload] = {
+        'kernel': main[0], 'source_hash': out.get('source_hash'),
+        'hbm_bytes_per_launch': out['hbm_bytes_per_launch'],
+        'hbm_bytes_per_launch_uncorrected': out['hbm_bytes_per_launch_uncorrected'],
+        'fetch_bytes_raw': out['hbm_read_bytes_raw'], 'write_bytes': out['hbm_write_bytes'],
+        'valu_insts_per_launch': c.get('SQ_INSTS_VALU'), 'salu_insts_per_launch': c.get('SQ_INSTS_SALU'),
+        'held_clock_hz': out.get('held_clock_hz'),
+        'avg_ms_kernel_trace': out.get('full_size_dispatch_ms', {}).get('avg'),
+        'source': dst + '.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU / GRBM_GUI_ACTIVE (separate '
+                  'passes, tools/profile.sh) on the bench command of this workload; FETCH_SIZE doubled per '
+                  'MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B), an upper bound here since the reads '
+                  'are scalar loads and 8-B/lane rows'}
+    json.dump(table, open(tpath, 'w'), indent=1)
 with open(dst + '.md', 'w') as f:
     f.write('\n'.join(lines) + '\n')
 with open(dst + '.json', 'w') as f:
