@@ -603,10 +603,16 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
             if (a.discharge && x.live)
                 for (long r = ra; r < rb; ++r)
                     a.discharge[(x.c * a.R + r) * a.ld + x.n] = nan;
-            if (last) {
-                rep.A = rep.B = rep.C1 = rep.C2 = rep.C3 = nan;
-                m.poison(nan);
-                write_results(a, x, m, rep, nan);
+            if (last) { // the per-sample results, written as NaN bit patterns (no arithmetic: -fno-honor-nans)
+                if (x.live) {
+                    a.gw[x.c * a.N + x.n] = nan;
+                    if (a.objfn)
+                        for (int i = 0; i < 8; ++i)
+                            a.objfn[(x.c * a.N + x.n) * 8 + i] = nan;
+                    if (a.final_vars)
+                        for (int i = 0; i < 19; ++i)
+                            a.final_vars[(x.c * a.N + x.n) * 19 + i] = nan;
+                }
             } else {
                 publish_slice(a, slot, seg, false);
             }

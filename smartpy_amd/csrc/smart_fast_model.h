@@ -169,13 +169,6 @@ struct FastModel {
         v[18] = u_riv * k_r;
     }
 
-    // every state = v (the NaN a poisoned time slice reports, smart_device.h)
-    __device__ void poison(double v)
-    {
-        l0 = l1 = l2 = l3 = l4 = l5 = v;
-        u_ove = u_dra = u_int = u_sgw = u_dgw = u_riv = v;
-    }
-
     // top-down filling of one layer (structure.py:367-374): a = min(ex, space)
     __device__ static void fill(double &l, double &ex, double z)
     {

@@ -334,6 +334,8 @@ def prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, re
     if mmode == MATH_FAST and p._ws is not None:
         if memo:
             e.plan = memo[0][1]
+        elif torch.cuda.is_current_stream_capturing():
+            e.plan = 0      # planning synchronises: inside a graph capture every kernel the call could need is launched
         else:
             e.plan = p._make_plan()
             if len(memo_on) == 2:

@@ -1,31 +1,34 @@
 """GLUE conditioning run (counterpart of smartpy/montecarlo/glue.py): keep the behavioural sets of a previous
 LHS sampling, re-simulate them (typically on another period)."""
 from .montecarlo import MonteCarlo
-from .selection import condition_mask, check_shapes
+from .selection import condition_mask, check_shapes, SecondStage
 
 
-class GLUE(MonteCarlo):
+class GLUE(SecondStage, MonteCarlo):
+    """Constructor of the reference (glue.py:34-37) plus `sampling=`: a finished sampling run of this process (an LHS
+    object after run()) whose objective functions are still on the GPU -- the behavioural mask is then evaluated
+    there and only the selected parameter rows travel, instead of re-reading and parsing the database file."""
+
     def __init__(self, catchment, root_f, in_format, out_format,
                  conditioning,
                  parallel='seq', save_sim=False, settings_filename=None,
-                 decompression_csv=False):
+                 decompression_csv=False, sampling=None):
         MonteCarlo.__init__(self, catchment, root_f, in_format, out_format,
                             parallel=parallel, save_sim=save_sim, func='glue', settings_filename=settings_filename)
-        self.sampling_run_file = \
-            ''.join([self.model.out_f, catchment, '.SMART.lhs.nc']) if self.out_format == 'netcdf' else \
-            ''.join([self.model.out_f, catchment, '.SMART.lhs'])
-        self.sampled_params, self.sampled_obj_fns = self._get_sampled_sets_from_file(
-            self.sampling_run_file, self.param_names, self.obj_fn_names, decompression_csv)
-        try:
-            self.objective_fn_indices = [self.obj_fn_names.index(fn) for fn in conditioning]
-        except ValueError:
-            raise Exception("One of the names of objective functions for conditioning in GLUE is not recognised."
-                            "Please check for typos and case sensitive issues.")
+        self.objective_fn_indices = self._columns_of(
+            conditioning, "One of the names of objective functions for conditioning in GLUE is not recognised."
+                          "Please check for typos and case sensitive issues.")
         self.conditions_types = [conditioning[fn][0] for fn in conditioning]
         self.conditions_values = [conditioning[fn][1] for fn in conditioning]
-        self.behavioural_params = self._get_behavioural_sets(self.sampled_params,
-                                                             self.sampled_obj_fns[:, self.objective_fn_indices],
-                                                             self.conditions_values, self.conditions_types)
+        self._load_sampling(catchment, decompression_csv, sampling)
+        if sampling is not None:
+            keep = condition_mask(self._device_obj_fns[:, self.objective_fn_indices], self.conditions_values,
+                                  self.conditions_types)
+            self.behavioural_params = self._rows_as_stored(keep)
+        else:
+            self.behavioural_params = self._get_behavioural_sets(
+                self.sampled_params, self.sampled_obj_fns[:, self.objective_fn_indices],
+                self.conditions_values, self.conditions_types)
         self._set_sample(self.behavioural_params)
 
     @staticmethod

@@ -4,30 +4,26 @@ The reference hands this object to spotpy's `mc` sampler, which calls parameters
 objectivefunction() / save() once per sample (montecarlo.py:153-154), optionally farmed out over MPI.  Here
 `run()` evaluates the whole sample in one launch per GPU -- time loop and objective functions fused
 (SMART.simulate_ensemble) -- shards the rows over the ranks of torch.distributed when the script was started with
-one process per GPU, gathers the [N, 8] objective matrix with one RCCL all-gather and lets rank 0 write the
-sampling database in the reference's format (float32 values printed '%.6e'; NetCDF schema of :91-118).
-The per-sample protocol methods are kept, with the reference's signatures, for code written against them.
+one process per GPU, gathers the [N, 9] result block with one RCCL all-gather and lets rank 0 write the sampling
+database (database.py) in the reference's format.  The per-sample protocol methods are kept, with the reference's
+signatures, for code written against them.
+
+After run() the results also stay where they were computed: `device_obj_fns` / `device_gw` / `device_sample` are
+the gathered matrices as device tensors, which GLUE / Best take directly (`sampling=<this object>`) instead of
+re-reading the database file.
 """
-import gzip
-import shutil
-from io import open
-from os import sep, remove, rename
+from os import sep
 
 import numpy as np
-
-try:
-    from netCDF4 import Dataset
-except ImportError:
-    Dataset = None
 
 from ..smart import SMART
 from ..inout import get_dict_simulation_settings
 from ..objfunctions import groundwater_constraint
-from ..version import __version__
 from .. import distributed as sdist
+from .database import database_for
 
-_NO_NETCDF = "The use of 'netcdf' as the output file format requires the package 'netCDF4', " \
-             "please install it and retry, or choose another file format."
+OBJ_FN_NAMES = ['NSE', 'KGE', 'KGEc', 'KGEa', 'KGEb', 'PBias', 'RMSE']      # montecarlo.py:71-74; 'GW' is appended
+                                                                             # when the settings hold a gw_constraint
 
 
 class ParameterList(object):
@@ -48,46 +44,54 @@ class ParameterList(object):
 class MonteCarlo(object):
     def __init__(self, catchment, root_f, in_format, out_format,
                  parallel, save_sim, func, settings_filename):
-        in_f = sep.join([root_f, 'in', catchment, sep])
-        settings = ''.join([in_f, settings_filename]) if settings_filename else \
-            ''.join([in_f, catchment, '.sttngs'])
-        c_area, g_area, start, end, delta_simu, delta_report, warm_up, gw_constraint = \
-            get_dict_simulation_settings(settings)
+        # the settings file names the period, the time steps, the areas and (optionally) the groundwater constraint
+        folder = sep.join([root_f, 'in', catchment, sep])
+        settings = get_dict_simulation_settings(folder + (settings_filename or catchment + '.sttngs'))
+        area, gauged_area, start, end, delta_simu, delta_report, warm_up_days, gw_constraint = settings
+        self.model = SMART(catchment, area, start, end, delta_simu, delta_report, warm_up_days,
+                           in_format, out_format, root_f, gauged_area)
 
-        self.model = SMART(catchment, c_area, start, end, delta_simu, delta_report, warm_up,
-                           in_format, out_format, root_f, g_area)
-
-        self.parallel = parallel            # 'seq' | 'mpi' in the reference; here any value shards over the
-        self.p = parallel == 'mpi'          # ranks of torch.distributed when it is initialised
+        # 'seq' | 'mpi' in the reference; here the rows are sharded over the ranks of torch.distributed whenever it is
+        # initialised, and `p` only keeps its meaning for the NetCDF files (opened in parallel mode, :93)
+        self.parallel, self.p = parallel, parallel == 'mpi'
         self.save_sim = save_sim
         self.constraints = {'gw': gw_constraint}
         self.param_names = self.model.parameters.names
-        self.obj_fn_names = \
-            ['NSE', 'KGE', 'KGEc', 'KGEa', 'KGEb', 'PBias', 'RMSE', 'GW'] \
-            if self.constraints['gw'] else \
-            ['NSE', 'KGE', 'KGEc', 'KGEa', 'KGEb', 'PBias', 'RMSE']
-
-        self._sample = None                 # [N, 10] float64: the rows to simulate, set by the subclasses
-        self._p_map = None
-        self.params = None
-
+        self.obj_fn_names = OBJ_FN_NAMES + (['GW'] if gw_constraint else [])
         self.out_format = out_format
-        self.db_file = \
-            self.model.out_f + '{}.SMART.{}.nc'.format(catchment, func) if self.out_format == 'netcdf' else \
-            self.model.out_f + '{}.SMART.{}'.format(catchment, func)
+        self.db_file = '{}{}.SMART.{}{}'.format(self.model.out_f, catchment, func,
+                                                '.nc' if out_format == 'netcdf' else '')
         self.database = None
         self.math_mode = 'fast'
-        #: results of the last run(): objective functions [N, 7|8] and groundwater ratios [N] (float64, host)
+
+        self._sample = None         # [N, 10] float64 on the host: the rows to simulate, set by the subclasses
+        self._device_sample = None  # the same matrix when it was drawn / selected on the device
+        self._p_map = None
+        self.params = None
+        #: results of the last run(): objective functions [N, 7|8] and groundwater ratios [N] (float64, host) ...
         self.obj_fns = None
         self.gw_contributions = None
+        #: ... and the same on the device, next to the parameter rows they belong to (second stages take these)
+        self.device_obj_fns = None
+        self.device_gw = None
 
         self.model.write_output_files(which='observed', parallel=self.p)
 
     # ---- the sample ------------------------------------------------------------------------------------
     def _set_sample(self, matrix):
+        """matrix: [N, 10] numpy array, or a device tensor (sampled / selected on the GPU: it stays there for the
+        launch; the host copy is what the database and the per-sample protocol read)."""
+        self._device_sample = None
+        if type(matrix).__module__.startswith('torch'):
+            self._device_sample = matrix.to(dtype=_f64()).contiguous()
+            matrix = self._device_sample.cpu().numpy()
         self._sample = np.ascontiguousarray(matrix, dtype=np.float64)
         self._p_map = None
         self.params = [ParameterList(name, self._sample[:, j]) for j, name in enumerate(self.param_names)]
+
+    @property
+    def device_sample(self):
+        return self._device_sample
 
     @property
     def p_map(self):
@@ -96,118 +100,56 @@ class MonteCarlo(object):
             self._p_map = {tuple(self._sample[r, :].tolist()): r for r in range(self._sample.shape[0])}
         return self._p_map
 
-    # ---- database --------------------------------------------------------------------------------------
-    def _simu_stamps(self):
-        return self.model.timeseries_report[1:]
-
-    def _init_db(self):
-        """montecarlo.py:90-127."""
-        n = self._sample.shape[0]
-        if self.out_format == 'netcdf':
-            if not Dataset:
-                raise Exception(_NO_NETCDF)
-            self.database = Dataset(self.db_file, 'w', format='NETCDF4', parallel=self.p)
-            self.database.description = "Monte Carlo Simulation outputs with SMARTpy v{}.".format(__version__)
-            self.database.createDimension('NbSamples', n)
-            self.database.createDimension('NbParameters', len(self.param_names))
-            self.database.createDimension('NbObjFunctions', len(self.obj_fn_names))
-            params = self.database.createVariable('Parameters', np.float32, ('NbSamples', 'NbParameters'))
-            params.units = ', '.join(self.param_names)
-            objfns = self.database.createVariable('ObjFunctions', np.float32, ('NbSamples', 'NbObjFunctions'))
-            objfns.units = ', '.join(self.obj_fn_names)
-            if self.save_sim:
-                stamps = self._simu_stamps()
-                self.database.createDimension('DateTime', len(stamps))
-                times = self.database.createVariable('DateTime', np.float64, ('DateTime',))
-                times.units = "seconds since 1970-01-01 00:00:00.0"
-                simu = self.database.createVariable('Simulations', np.float32, ('NbSamples', 'DateTime'))
-                simu.units = "Discharge in m3/s"
-                self.database.variables['DateTime'][0:len(stamps)] = \
-                    (np.asarray(stamps, dtype='datetime64[us]') - np.datetime64('1970-01-01T00:00:00')) / \
-                    np.timedelta64(1, 's')
-        else:
-            self.database = open(self.db_file, 'w', newline='', encoding='utf8')
-            simu_steps = [dt.strftime('%Y-%m-%d %H:%M:%S') for dt in self._simu_stamps()] if self.save_sim else []
-            self.database.write(','.join(self.obj_fn_names + self.param_names + simu_steps) + '\n')
-
-    def _write_rows(self, obj_fns, params, sims):
-        """Bulk form of save() (montecarlo.py:211-231): everything cast to float32, CSV values as '%.6e'."""
-        if self.out_format == 'netcdf':
-            self.database.variables['Parameters'][:, 0:len(self.param_names)] = params
-            self.database.variables['ObjFunctions'][:, 0:len(self.obj_fn_names)] = obj_fns
-            if self.save_sim:
-                self.database.variables['Simulations'][:, 0:sims.shape[1]] = sims
-        else:
-            cols = [obj_fns, params] + ([sims] if self.save_sim else [])
-            table = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.float32) for c in cols], axis=1))
-            # the rows are formatted by the library (smart_db_append_rows: same characters as '%.6e' % float32,
-            # ~15x faster than numpy.savetxt, which took 30x the GPU run at 1e5 samples)
-            import ctypes
-            from .. import _lib
-            self.database.flush()
-            _lib.check(_lib.lib().smart_db_append_rows(
-                self.db_file.encode('utf8'), table.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
-                table.shape[0], table.shape[1], 0))
-            self.database.seek(0, 2)
-
     # ---- run -------------------------------------------------------------------------------------------
+    def _open_database(self):
+        db = database_for(self.out_format, self.db_file, self.obj_fn_names, self.param_names)
+        self.database = db.create(self._sample.shape[0],
+                                  self.model.timeseries_report[1:] if self.save_sim else None, parallel=self.p)
+        return db
+
+    def _finish_database(self, db, compression):
+        db.close()
+        self.database = None
+        if self.out_format in ('netcdf', 'csv'):
+            db.compress(compression)
+
     def run(self, compression=None):
         """Simulate every row of the sample and write the sampling database (montecarlo.py:132-177)."""
-        n = self._sample.shape[0]
+        import torch
         rank, world = sdist.rank_world()
+        if world > 1:
+            # the sampler draws from NumPy's unseeded global stream (lhs.py:149,154): every process holds another
+            # matrix unless the caller seeded them alike.  Rank 0's is THE sample, as in the reference's MPI mode,
+            # where only the master draws.
+            theirs = sdist.broadcast_matrix(self._sample, src=0)
+            if theirs.shape != self._sample.shape or not np.array_equal(theirs, self._sample):
+                self._set_sample(theirs)
+        n = self._sample.shape[0]
         n_obj = len(self.obj_fn_names)
         if n == 0:      # e.g. GLUE with no behavioural set: the reference's sampler loops zero times, header only
             self.obj_fns, self.gw_contributions = np.empty((0, n_obj)), np.empty(0)
+            self.device_obj_fns = self.device_gw = None
             if rank == 0:
-                self._init_db()
-                self.database.close()
-                self._compress(compression)
+                self._finish_database(self._open_database(), compression)
             sdist.barrier()
             return
         lo, hi = sdist.shard_bounds(n, world, rank)
-        out = self.model.simulate_ensemble(self._sample[lo:hi] if hi > lo else self._sample[:1],
+        rows = self._device_sample if self._device_sample is not None else self._sample
+        out = self.model.simulate_ensemble(rows[lo:hi] if hi > lo else rows[:1],
                                            objective_functions=True, gw_constraint=self.constraints['gw'],
                                            save_discharge=self.save_sim, math_mode=self.math_mode)
-        local = out.objfn[:hi - lo, :n_obj]
-        import torch
-        packed = torch.cat([local, out.gw[:hi - lo].unsqueeze(1)], dim=1)
+        block = [out.objfn[:hi - lo, :n_obj], out.gw[:hi - lo].unsqueeze(1)]
         if self.save_sim:       # float32 is all the database keeps (montecarlo.py:225)
-            packed = torch.cat([packed, out.discharge[:hi - lo].to(torch.float64)], dim=1)
-        packed = sdist.gather_rows(packed, n)
-        host = packed.cpu().numpy()
-        self.obj_fns = host[:, :n_obj]
-        self.gw_contributions = host[:, n_obj]
-        sims = host[:, n_obj + 1:] if self.save_sim else None
+            block.append(out.discharge[:hi - lo].to(torch.float64))
+        gathered = sdist.gather_rows(torch.cat(block, dim=1), n)
+        self.device_obj_fns, self.device_gw = gathered[:, :n_obj], gathered[:, n_obj]
+        host = gathered.cpu().numpy()
+        self.obj_fns, self.gw_contributions = host[:, :n_obj], host[:, n_obj]
         if rank == 0:
-            self._init_db()
-            self._write_rows(self.obj_fns, self._sample, sims)
-            self.database.close()
-            self._compress(compression)
+            db = self._open_database()
+            db.write_table(self.obj_fns, self._sample, host[:, n_obj + 1:] if self.save_sim else None)
+            self._finish_database(db, compression)
         sdist.barrier()
-
-    def _compress(self, compression):
-        """montecarlo.py:157-177."""
-        if self.out_format == 'netcdf':
-            if compression is True:
-                compression = 6
-            if not isinstance(compression, bool) and isinstance(compression, (int, float)):
-                with Dataset(self.db_file, 'r') as src, Dataset(self.db_file.replace('.nc', '_.nc'), 'w') as dst:
-                    dst.description = src.description
-                    for name, dimension in src.dimensions.items():
-                        dst.createDimension(name, len(dimension))
-                    for name, variable in src.variables.items():
-                        v = dst.createVariable(name, variable.datatype, variable.dimensions,
-                                               zlib=True, complevel=compression)
-                        v.units = src.variables[name].units
-                        dst.variables[name][:] = src.variables[name][:]
-                remove(self.db_file)
-                rename(self.db_file.replace('.nc', '_.nc'), self.db_file)
-        elif self.out_format == 'csv':
-            if compression is True:
-                with open(self.db_file, 'rb') as f_in:
-                    with gzip.open(self.db_file + '.gz', 'wb') as f_out:
-                        shutil.copyfileobj(f_in, f_out)
-                remove(self.db_file)
 
     # ---- the per-sample protocol of the reference (spotpy setup class) ------------------------------------
     def parameters(self):
@@ -230,47 +172,21 @@ class MonteCarlo(object):
             o.append(groundwater_constraint(evaluation=evaluation[1], simulation=simulation[1]))
         return o
 
+    def _init_db(self):
+        """Open the database for the per-sample protocol (save() below); run() does this itself."""
+        self._open_database()
+
     def save(self, obj_fns, parameters, simulations, *args, **kwargs):
-        """One row into an open database (montecarlo.py:211-231)."""
+        """One row into the open database (montecarlo.py:211-231); NetCDF rows land at the sample's own index."""
         params = np.asarray(parameters).tolist()
-        if self.out_format == 'netcdf':
-            index = self.p_map[tuple(params)]
-            self.database.variables['Parameters'][index, 0:len(self.param_names)] = params
-            self.database.variables['ObjFunctions'][index, 0:len(self.obj_fn_names)] = obj_fns
-            if self.save_sim:
-                self.database.variables['Simulations'][index, 0:len(simulations[0])] = simulations[0]
-        else:
-            row = list(obj_fns) + params + (np.asarray(simulations[0]).tolist() if self.save_sim else [])
-            self.database.write(','.join('%.6e' % np.float32(x) for x in row) + '\n')
+        index = self.p_map[tuple(params)] if self.out_format == 'netcdf' else None
+        self.database.write_sample(index, obj_fns, params, np.asarray(simulations[0]) if self.save_sim else None)
 
     def _get_sampled_sets_from_file(self, file_location, param_names, obj_fn_names, decompression_csv):
-        """-> (params float32 [N, 10], obj_fns float32 [N, k]) (montecarlo.py:233-262)."""
-        if self.out_format == 'netcdf':
-            if not Dataset:
-                raise Exception(_NO_NETCDF)
-            with Dataset(file_location, 'r') as f:
-                return (np.array(f.variables['Parameters'][:, :], dtype=np.float32),
-                        np.array(f.variables['ObjFunctions'][:, :], dtype=np.float32))
-        opener = (lambda: gzip.open(file_location + '.gz', 'rb')) if decompression_csv else \
-            (lambda: open(file_location, 'rb'))
-        # columns are looked up by header name like the reference's DictReader; the table itself is parsed in bulk by
-        # the library (smart_db_parse_rows: text -> float64 -> float32, as np.array(str) does; a 1e6-row database
-        # takes a fraction of a second instead of minutes)
-        import ctypes
-        from .. import _lib
-        with opener() as f:
-            header = f.readline().decode('utf8').rstrip('\r\n').split(',')
-            try:
-                cols = [header.index(name) for name in list(param_names) + list(obj_fn_names)]
-            except ValueError as e:
-                raise KeyError(str(e))
-            body = f.read()
-        max_rows = body.count(b'\n') + 1
-        table = np.empty((max_rows, len(cols)), dtype=np.float32)
-        idx = np.asarray(cols, dtype=np.int32)
-        n = _lib.lib().smart_db_parse_rows(body, len(body), len(header), idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-                                           len(cols), table.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), max_rows, 0)
-        if n < 0:
-            _lib.check(int(n))
-        table = table[:n]
-        return np.ascontiguousarray(table[:, :len(param_names)]), np.ascontiguousarray(table[:, len(param_names):])
+        """-> (params float32 [N, 10], obj_fns float32 [N, k]) of a previous run's database (montecarlo.py:233-262)."""
+        return database_for(self.out_format, file_location, obj_fn_names, param_names).read(decompression_csv)
+
+
+def _f64():
+    import torch
+    return torch.float64

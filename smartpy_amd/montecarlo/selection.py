@@ -4,6 +4,10 @@
 as well as torch tensors on any device: on an `[N, 8]` objective matrix that is still on the GPU the behavioural
 mask, its count and the top-k rows are computed there and only the selected rows travel.
 """
+import ctypes
+import os
+import tempfile
+
 import numpy as np
 
 
@@ -71,3 +75,69 @@ def best_rows(sort_fn, constrained, nb_best):
         return idx[order][-nb_best:]
     idx = np.nonzero(constrained)[0]
     return idx[np.argsort(sort_fn[idx])][-nb_best:]
+
+
+def as_stored(matrix):
+    """What a float64 matrix becomes on its way through a sampling database: cast to float32, printed '%.6e', parsed
+    back to float32 (montecarlo.py:225-231, :262) -- 7 significant digits, not a float32 round trip.  Done with the
+    library's own writer and reader on a scratch file, so a selection made on the device hands the second stage
+    exactly the rows the file-based path would have read."""
+    from .. import _lib
+    table = np.ascontiguousarray(matrix, dtype=np.float32)
+    if table.size == 0:
+        return table
+    fd, path = tempfile.mkstemp(prefix='smart_rows_')
+    os.close(fd)
+    try:
+        L = _lib.lib()
+        _lib.check(L.smart_db_append_rows(path.encode('utf8'), table.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                          table.shape[0], table.shape[1], 0))
+        with open(path, 'rb') as f:
+            text = f.read()
+    finally:
+        os.remove(path)
+    out = np.empty_like(table)
+    cols = np.arange(table.shape[1], dtype=np.int32)
+    n = L.smart_db_parse_rows(text, len(text), table.shape[1], cols.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                              table.shape[1], out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), table.shape[0], 0)
+    if n != table.shape[0]:
+        raise Exception("as_stored: %d of %d rows came back" % (n, table.shape[0]))
+    return out
+
+
+class SecondStage(object):
+    """What GLUE, Best and Total share: where the sample of a previous run comes from.  Either its database file,
+    `<out>/<catchment>.SMART.lhs[.nc]` (glue.py:182-188, best.py:172-178, total.py:122-128), or -- `sampling=` -- the
+    finished run itself, whose parameter rows and objective functions are still on the GPU."""
+
+    def _load_sampling(self, catchment, decompression_csv, sampling):
+        self.sampling_run_file = '{}{}.SMART.lhs{}'.format(self.model.out_f, catchment,
+                                                           '.nc' if self.out_format == 'netcdf' else '')
+        self._device_obj_fns = self._device_rows = None
+        if sampling is None:
+            self.sampled_params, self.sampled_obj_fns = self._get_sampled_sets_from_file(
+                self.sampling_run_file, self.param_names, self.obj_fn_names, decompression_csv)
+            return
+        if sampling.device_obj_fns is None:
+            raise Exception("The sampling run handed to {} has not been run yet.".format(type(self).__name__))
+        if list(sampling.obj_fn_names) != list(self.obj_fn_names):
+            raise Exception("The sampling run handed to {} does not hold the same objective "
+                            "functions.".format(type(self).__name__))
+        import torch
+        self._device_obj_fns = sampling.device_obj_fns.to(torch.float32)     # the precision the database keeps
+        self._device_rows = sampling.device_sample if sampling.device_sample is not None \
+            else torch.from_numpy(sampling._sample).to(self._device_obj_fns.device)
+        # the host views the file-based path fills: read lazily, most callers never look at them
+        self.sampled_params = as_stored(sampling._sample)
+        self.sampled_obj_fns = as_stored(sampling.obj_fns)
+
+    def _rows_as_stored(self, which):
+        """Parameter rows picked on the device (boolean mask or index tensor) -> float32 host matrix with the
+        rounding of the database."""
+        return as_stored(self._device_rows[which].cpu().numpy()).reshape(-1, len(self.param_names))
+
+    def _columns_of(self, names, problem):
+        try:
+            return [self.obj_fn_names.index(name) for name in names]
+        except ValueError:
+            raise Exception(problem)

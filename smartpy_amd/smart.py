@@ -54,26 +54,21 @@ class SMART(object):
 
     def _init_common(self, catchment, catchment_area_m2, start, end, time_delta_simu, time_delta_save,
                      warm_up_days, in_format, out_format, root):
-        self.catchment = catchment
-        self.area = catchment_area_m2
-        self.in_fmt = in_format
-        self.out_fmt = out_format
-        self.root_f = root
-        self.in_f = sep.join([self.root_f, 'in', self.catchment, sep])
-        self.out_f = sep.join([self.root_f, 'out', self.catchment, sep])
-        self.start = start
-        self.end = end
-        self.delta_simu = time_delta_simu
-        self.delta_save = time_delta_save
-        self.timeframe = TimeFrame(self.start, self.end, self.delta_simu, self.delta_save)
+        """Everything of the constructor that does not read files: identity, folders, the two time axes, and the
+        empty result slots (attribute names as in smart.py:109-152, which user scripts read)."""
+        self.catchment, self.area = catchment, catchment_area_m2
+        self.in_fmt, self.out_fmt, self.root_f = in_format, out_format, root
+        self.in_f, self.out_f = (sep.join([root, side, catchment, sep]) for side in ('in', 'out'))
+        # simulation axis (T + 1 stamps, one leading initial-condition stamp) and report axis (R + 1)
+        self.start, self.end = start, end
+        self.delta_simu, self.delta_save = time_delta_simu, time_delta_save
+        self.timeframe = TimeFrame(start, end, time_delta_simu, time_delta_save)
         self.timeseries = self.timeframe.get_series_simu()
         self.timeseries_report = self.timeframe.get_series_save()
         self.warm_up = warm_up_days
-        self.extra = None                    # smart.py:145
         self.parameters = Parameters()
-        self.outputs = None
-        self.nd_discharge = None
-        self.gw_contribution = None
+        self.extra = None                    # educated guess of the initial reservoirs, set by the user (smart.py:145)
+        self.outputs = self.nd_discharge = self.gw_contribution = None
         self._device_cache = None
 
     # ------------------------------------------------------------------------------------------------------
@@ -113,33 +108,42 @@ class SMART(object):
                                    device=device)
 
     # ------------------------------------------------------------------------------------------------------
+    # the two flow series a model can write / hand out: attribute holding it, file suffix, and what to tell the
+    # user when it is not there yet (the reference's messages, smart.py:212-277)
+    _SERIES = {
+        'modelled': ('nd_discharge', '.mod.flow',
+                     "The modelled flow output file cannot be written. Please make sure to call the "
+                     "simulate method of your SMART instance before writing this output file."),
+        'observed': ('nd_flow', '.obs.flow',
+                     "The observed flow output file cannot be written. Please make sure that a value is "
+                     "assigned to the gauged_area_m2 attribute of the SMART class instance."),
+    }
+
     def write_output_files(self, which='both', parallel=False):
-        """smart.py:212-255."""
-        if (which == 'both') or (which == 'modelled'):
-            if self.nd_discharge is not None:
-                write_flow_file_from_nds(self.timeseries_report[1:], self.nd_discharge,
-                                         ''.join([self.out_f, self.catchment, '.mod.flow']),
-                                         out_file_format=self.out_fmt, parallel=parallel)
-            else:
-                raise Exception("The modelled flow output file cannot be written. Please make sure to call the "
-                                "simulate method of your SMART instance before writing this output file.")
-        if (which == 'both') or (which == 'observed'):
-            if self.nd_flow is not None:
-                write_flow_file_from_nds(self.timeseries_report[1:], self.nd_flow,
-                                         ''.join([self.out_f, self.catchment, '.obs.flow']),
-                                         out_file_format=self.out_fmt, parallel=parallel)
-            else:
-                raise Exception("The observed flow output file cannot be written. Please make sure that a value is "
-                                "assigned to the gauged_area_m2 attribute of the SMART class instance.")
+        """Write `<out>/<catchment>.mod.flow` and / or `.obs.flow` on the report time axis (smart.py:212-255);
+        which = 'modelled' | 'observed' | 'both' (modelled first)."""
+        for kind in (('modelled', 'observed') if which == 'both' else (which,)):
+            if kind not in self._SERIES:
+                continue
+            attribute, suffix, problem = self._SERIES[kind]
+            series = getattr(self, attribute)
+            if series is None:
+                raise Exception(problem)
+            write_flow_file_from_nds(self.timeseries_report[1:], series, self.out_f + self.catchment + suffix,
+                                     out_file_format=self.out_fmt, parallel=parallel)
+
+    def _series_or_raise(self, attribute, problem):
+        series = getattr(self, attribute)
+        if series is None:
+            raise Exception(problem)
+        return series
 
     def get_simulation_array(self):
-        if self.nd_discharge is not None:
-            return self.nd_discharge
-        raise Exception("The simulation array cannot be retrieved. Please make sure to call the simulate "
-                        "method of your SMART instance before requesting this output array.")
+        return self._series_or_raise(
+            'nd_discharge', "The simulation array cannot be retrieved. Please make sure to call the simulate "
+                            "method of your SMART instance before requesting this output array.")
 
     def get_evaluation_array(self):
-        if self.nd_flow is not None:
-            return self.nd_flow
-        raise Exception("The observation array does not exist. Please make sure that a value is assigned "
-                        "to the gauged_area_m2 attribute of your SMART class instance.")
+        return self._series_or_raise(
+            'nd_flow', "The observation array does not exist. Please make sure that a value is assigned "
+                       "to the gauged_area_m2 attribute of your SMART class instance.")

@@ -90,7 +90,7 @@ def _make_root(tmp, days=120):
     return root
 
 
-def _worker_lhs(rank, world, port, root, save_sim):
+def _worker_lhs(rank, world, port, root, save_sim, seeded=True):
     if world > 1:
         _init(rank, world, port)
     elif ROOT not in sys.path:
@@ -98,11 +98,14 @@ def _worker_lhs(rank, world, port, root, save_sim):
     from smartpy_amd.smart import SMART
     from smartpy_amd.montecarlo import LHS
     SMART.simulate_ensemble = _oracle_simulate_ensemble
-    np.random.seed(2718)                    # every rank draws the same sample, like every MPI rank of the reference
+    # seeded: every rank draws the same sample.  Unseeded (what the reference's own scripts do): every process draws
+    # another one from NumPy's global stream, and rank 0's has to win
+    np.random.seed(2718 if seeded else 1000 + rank)
     lhs = LHS('Catchment', root, 'csv', 'csv', 13, save_sim=save_sim)
     lhs.model.extra = {'aar': 1200, 'r-o_ratio': 0.45, 'r-o_split': (0.10, 0.15, 0.15, 0.30, 0.30)}
     lhs.run()
     np.save(os.path.join(root, 'objfns_w%d_r%d.npy' % (world, rank)), lhs.obj_fns)
+    np.save(os.path.join(root, 'sample_w%d_r%d.npy' % (world, rank)), lhs._sample)
     if world > 1:
         dist.destroy_process_group()
 
@@ -148,3 +151,120 @@ def test_second_stage_with_no_behavioural_set_writes_header_only(tmp_path):
         Best('Catchment', root, 'csv', 'csv', target='nse', nb_best=2)
     best = Best('Catchment', root, 'csv', 'csv', target='KGE', nb_best=3)
     assert best.best_params.shape == (3, 10) and best.db_file.endswith('Catchment.SMART.3best')
+
+
+def test_unseeded_ranks_run_rank_zeros_sample(tmp_path):
+    """Two processes that drew DIFFERENT samples (unseeded NumPy streams): run() broadcasts rank 0's matrix before
+    sharding, so the database pairs every parameter row with the results of that very row -- the same file a single
+    process with rank 0's stream writes."""
+    root1 = _make_root(str(tmp_path / 'one'))
+    root2 = _make_root(str(tmp_path / 'two'))
+    _worker_lhs(0, 1, 0, root1, False, False)                       # one process, seed 1000 = rank 0's stream
+    mp.spawn(_worker_lhs, args=(2, _free_port(), root2, False, False), nprocs=2, join=True)
+    assert open(os.path.join(root1, 'out', 'Catchment', 'Catchment.SMART.lhs')).read() == \
+        open(os.path.join(root2, 'out', 'Catchment', 'Catchment.SMART.lhs')).read()
+    s0, s1 = (np.load(os.path.join(root2, 'sample_w2_r%d.npy' % r)) for r in range(2))
+    assert np.array_equal(s0, s1) and np.array_equal(s0, np.load(os.path.join(root1, 'sample_w1_r0.npy')))
+
+
+# ---- ShardedEnsemble: sample blocks and catchment blocks, with the launch replaced by the CPU oracle ---------------
+class _OraclePrepared(object):
+    """Stand-in for engine.prepare_ensemble on a machine without a GPU: same arguments, launch() through the oracle."""
+
+    def __init__(self, params, forcing, area_m2, delta_sec, n_warm, report_gap, obs=None, gw_obs=None, extra=None,
+                 device=None, **kw):
+        self.a = (np.asarray(params, float), np.asarray(forcing, float), area_m2, delta_sec, n_warm, report_gap,
+                  obs, gw_obs, extra)
+
+    def launch(self):
+        from oracle import smart_oracle as so, objfn_oracle
+        params, forcing, area, dt, W, gap, obs, gw_obs, extra = self.a
+        squeeze = forcing.ndim == 2
+        forcing = forcing[None] if squeeze else forcing
+        C = forcing.shape[0]
+        objfn, gws = [], []
+        for c in range(C):
+            p = params if params.ndim == 2 else params[c]
+            a_c = area if np.ndim(area) == 0 else area[c]
+            dis, gw, _ = so.run_batch(float(a_c), dt, forcing.shape[1], W, forcing[c, :, 0].copy(),
+                                      forcing[c, :, 1].copy(), p, extra, so.REPORT_SUMMARY, gap)
+            o = np.full((len(p), 8), np.nan)
+            if obs is not None:
+                g = gw_obs if gw_obs is None or np.ndim(gw_obs) == 0 else gw_obs[c]
+                m = objfn_oracle.objective_matrix(dis, obs if np.ndim(obs) == 1 else obs[c], gw, g)
+                o[:, :m.shape[1]] = m
+            objfn.append(o)
+            gws.append(gw)
+        objfn, gws = torch.from_numpy(np.stack(objfn)), torch.from_numpy(np.stack(gws))
+        return _OracleResult(None, gws[0] if squeeze else gws, objfn[0] if squeeze else objfn)
+
+    def verify(self):
+        return None
+
+
+def _sharded_setup():
+    rng = np.random.default_rng(5)
+    C, N, days = 5, 6, 40
+    forcing = np.stack([np.stack([np.repeat(rng.gamma(0.7, 4.5, days) / 24, 24),
+                                  np.repeat(rng.uniform(0.2, 2.5, days) / 24, 24)], axis=1) for _ in range(C)])
+    from oracle import lhs_oracle
+    params = lhs_oracle.lhs_params(N, seed=3)
+    areas = rng.uniform(50e6, 500e6, C)
+    obs = rng.uniform(0.5, 4.0, (C, days))
+    obs[rng.random((C, days)) < 0.1] = np.nan
+    gw_obs = rng.uniform(0.05, 0.3, C)
+    extra = {'aar': 1200, 'r-o_ratio': 0.45, 'r-o_split': (0.10, 0.15, 0.15, 0.30, 0.30)}
+    return C, N, forcing, params, areas, obs, gw_obs, extra
+
+
+def _worker_sharded(rank, world, port, out_dir):
+    if world > 1:
+        _init(rank, world, port)
+    elif ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from smartpy_amd import distributed as sdist, engine
+    engine.prepare_ensemble = _OraclePrepared
+    C, N, forcing, params, areas, obs, gw_obs, extra = _sharded_setup()
+    asked = []
+
+    def forcing_of(c):          # a rank must only ever be asked for its own catchments
+        asked.append(c)
+        return forcing[c]
+    cat = sdist.ShardedEnsemble(params, forcing_of, areas, 3600.0, 240, 24, axis='catchments', n_catchments=C,
+                                obs=obs, gw_obs=gw_obs, extra=extra, device='cpu')
+    lo, hi = sdist.shard_bounds(C, world, rank)
+    assert sorted(asked) == list(range(lo, hi)) and cat.n_local == hi - lo
+    got_c = cat.step()
+    sam = sdist.ShardedEnsemble(params, forcing[1], areas[1], 3600.0, 240, 24, axis='samples', obs=obs[1],
+                                gw_obs=float(gw_obs[1]), extra=extra, device='cpu')
+    got_s = sam.step()
+    own = params[rank::world][:3]       # weak mode: every rank brings its own block of 3 rows
+    weak = sdist.ShardedEnsemble(own, forcing[2], areas[2], 3600.0, 240, 24, axis='samples', local_block=True,
+                                 obs=obs[2], extra=extra, device='cpu')
+    got_w = weak.step()
+    np.savez(os.path.join(out_dir, 'sharded_w%d_r%d.npz' % (world, rank)), c=got_c.numpy(), s=got_s.numpy(),
+             w=got_w.numpy())
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_sharded_ensemble_over_catchments_and_samples(tmp_path):
+    """BASELINE config 5's split: 5 catchments over 2 ranks (3 + 2), each rank holding only its own forcing; and the
+    sample-axis split of configs 3 / 4.  Every rank ends up with the single-process result, bit for bit."""
+    _worker_sharded(0, 1, 0, str(tmp_path))
+    mp.spawn(_worker_sharded, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    one = np.load(tmp_path / 'sharded_w1_r0.npz')
+    C, N = 5, 6
+    assert one['c'].shape == (C, N, 9) and one['s'].shape == (N, 9)
+    assert np.all(np.isfinite(one['c'])) and np.array_equal(one['c'][1], one['s'])
+    for r in range(2):
+        two = np.load(tmp_path / ('sharded_w2_r%d.npz' % r))
+        assert np.array_equal(two['c'], one['c']) and np.array_equal(two['s'], one['s'])
+        # weak mode: the gathered matrix is the ranks' own blocks in rank order
+        assert two['w'].shape == (6, 9)
+    _, _, forcing, params, areas, obs, gw_obs, extra = _sharded_setup()
+    two = np.load(tmp_path / 'sharded_w2_r0.npz')
+    whole = _OraclePrepared(np.concatenate([params[0::2][:3], params[1::2][:3]]), forcing[2], areas[2], 3600.0, 240, 24,
+                            obs=obs[2], extra=extra).launch()
+    assert np.array_equal(two['w'][:, :8], whole.objfn.numpy(), equal_nan=True)
+    assert np.array_equal(two['w'][:, 8], whole.gw.numpy())

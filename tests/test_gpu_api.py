@@ -146,6 +146,72 @@ def test_monte_carlo_pipeline_lhs_glue_best_total(root, example):
     assert np.allclose(like[:7], want[0, :7], rtol=1e-9, atol=1e-12) and like[7] == want[0, 7]
 
 
+def test_second_stages_from_the_device_and_device_sampling(root, example):
+    """(f1) GLUE / Best handed the finished LHS run itself (`sampling=`): the behavioural mask, its count and the
+    top-n rows are evaluated on the GPU over the objective functions the launch left there, and select exactly the
+    rows -- with the database's float32 '%.6e' rounding -- that the file-based constructors read back.
+    (f3) LHS(device_sampling=True): the Latin hypercube is drawn on the GPU and stays there for the launch."""
+    import torch
+    from smartpy_amd.montecarlo import LHS, GLUE, Best, Total
+    _settings(root, 'Catchment.sampling.sttngs', '01/01/2007', '31/12/2007', 180)
+    _settings(root, 'Catchment.evaluating.sttngs', '01/01/2008', '30/06/2008', 90)
+    np.random.seed(11)
+    lhs = LHS('Catchment', root, 'csv', 'csv', 1000, settings_filename='Catchment.sampling.sttngs')
+    lhs.model.extra = EXTRA
+    lhs.run()
+    assert lhs.device_obj_fns.is_cuda and lhs.device_obj_fns.shape == (1000, 8) and lhs.device_gw.shape == (1000,)
+    assert np.array_equal(lhs.device_obj_fns.cpu().numpy(), lhs.obj_fns)
+    cond = {'KGE': ('min', (0.2,)), 'PBias': ('inside', (-40.0, 40.0)), 'GW': ('equal', (1.0,))}
+    from_file = GLUE('Catchment', root, 'csv', 'csv', conditioning=cond, settings_filename='Catchment.evaluating.sttngs')
+    on_device = GLUE('Catchment', root, 'csv', 'csv', conditioning=cond, settings_filename='Catchment.evaluating.sttngs',
+                     sampling=lhs)
+    assert 0 < from_file.behavioural_params.shape[0] < 1000
+    assert on_device.behavioural_params.dtype == np.float32
+    assert np.array_equal(on_device.behavioural_params, from_file.behavioural_params)
+    assert np.array_equal(on_device.sampled_params, from_file.sampled_params)
+    assert np.array_equal(on_device.sampled_obj_fns, from_file.sampled_obj_fns)
+    for target in ('NSE', 'RMSE'):
+        kw = dict(target=target, nb_best=25, constraining={'KGEa': ('max', (1.2,))},
+                  settings_filename='Catchment.evaluating.sttngs')
+        a = Best('Catchment', root, 'csv', 'csv', **kw)
+        b = Best('Catchment', root, 'csv', 'csv', sampling=lhs, **kw)
+        assert a.best_params.shape == (25, 10) and np.array_equal(a.best_params, b.best_params)
+    with pytest.raises(Exception, match='higher than the restrained sample size'):
+        Best('Catchment', root, 'csv', 'csv', target='NSE', nb_best=900, constraining={'NSE': ('min', (0.3,))},
+             settings_filename='Catchment.evaluating.sttngs', sampling=lhs)
+    tot = Total('Catchment', root, 'csv', 'csv', settings_filename='Catchment.evaluating.sttngs', sampling=lhs)
+    assert np.array_equal(tot._sample, from_file.sampled_params.astype(np.float64))
+    on_device.model.extra = from_file.model.extra = EXTRA
+    on_device.run()
+    first = np.array(on_device.obj_fns)
+    from_file.run()
+    assert np.array_equal(first, from_file.obj_fns)                 # same rows, same evaluation-period results
+    with pytest.raises(Exception, match='has not been run yet'):
+        GLUE('Catchment', root, 'csv', 'csv', conditioning=cond, settings_filename='Catchment.evaluating.sttngs',
+             sampling=LHS('Catchment', root, 'csv', 'csv', 5, settings_filename='Catchment.sampling.sttngs'))
+
+    # ---- (f3) the sample drawn on the device
+    dev = LHS('Catchment', root, 'csv', 'csv', 5000, settings_filename='Catchment.sampling.sttngs',
+              device_sampling=True, seed=4)
+    assert dev.device_sample.is_cuda and dev.lhs_params.shape == (5000, 10)
+    assert np.array_equal(dev.device_sample.cpu().numpy(), dev.lhs_params)
+    ranges = dev.model.parameters.ranges
+    for j, name in enumerate(dev.param_names):                      # a Latin hypercube: one value per stratum
+        lo, hi = ranges[name]
+        strata = np.floor((dev.lhs_params[:, j] - lo) / (hi - lo) * 5000).astype(int)
+        assert sorted(np.clip(strata, 0, 4999)) == list(range(5000))
+    again = LHS('Catchment', root, 'csv', 'csv', 5000, settings_filename='Catchment.sampling.sttngs',
+                device_sampling=True, seed=4)
+    assert np.array_equal(again.lhs_params, dev.lhs_params)
+    dev.model.extra = EXTRA
+    dev.run()
+    rows = [0, 1777, 4999]
+    dis, gw, _ = so.run_batch(example['area'], 3600.0, 365 * 24, 180 * 24, example['rain_hourly'],
+                              example['peva_hourly'], dev.lhs_params[rows], EXTRA, so.REPORT_SUMMARY, 24)
+    want = objfn_oracle.objective_matrix(dis, example['flow_obs'][:365], gw, 0.12667)
+    assert np.allclose(dev.obj_fns[rows, :7], want[:, :7], rtol=1e-9, atol=1e-12)
+
+
 def test_smartcpp_module_contract(example):
     """What the reference's hook calls: smartcpp.allsteps(...)[2] for the warm-up, [0:2] for the run
     (structure.py:118-121,143-146); smartcpp.onestep per step for old versions (structure.py:171-187)."""

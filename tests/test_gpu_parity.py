@@ -323,30 +323,71 @@ def test_error_behaviour(eng, example):
 # ------------------------------------------------------------------------------------------------------
 # BASELINE sizes: size-independent properties
 # ------------------------------------------------------------------------------------------------------
-def test_headline_size_properties(eng, example):
-    """1e5 LHS samples x hourly 10 years (BASELINE config 3), objective functions fused, no discharge stored.
-    Properties: (i) a sample's result does not depend on its position in the batch or on its wavefront
-    neighbours (bit-identical under a permutation of the rows); (ii) 8 rows drawn at random agree with the
-    oracle; (iii) physical ranges."""
+def test_headline_size_properties(eng):
+    """1e5 LHS samples x hourly 10 years on the BENCHMARK's synthetic forcing (BASELINE config 3: bench.py's
+    default_rng(12345) series, seed-2718 LHS matrix, observations with 12 % missing), objective functions fused and
+    the discharge matrix stored, exactly what bench.py times.  Properties: (i) a sample's result does not depend on its
+    position in the batch or on its wavefront neighbours (bit-identical under a permutation of the rows); (ii) 64
+    rows drawn at random agree with the oracle -- objective functions, groundwater ratio AND their discharge series;
+    (iii) physical ranges."""
     import torch
+    import bench
     N = 100000
     params = lhs_oracle.lhs_params(N, seed=2718)
-    f = forcing_of(example['rain_hourly'], example['peva_hourly'])
+    f, rng = bench.synthetic_forcing(0, hourly=True)
+    T, W = f.shape[0], 8760
+    truth, _, _ = so.run_batch(bench.AREA, 3600.0, T, W, f[:, 0].copy(), f[:, 1].copy(), np.array([bench.TRUTH]),
+                               bench.EXTRA, so.REPORT_SUMMARY, 24)
+    obs = truth[0] * np.exp(rng.normal(0.0, 0.2, T // 24))
+    obs[rng.random(T // 24) < 0.12] = np.nan
     dev_p = torch.from_numpy(params).cuda()
-    out = eng.run_ensemble(dev_p, f, example['area'], 3600.0, 8760, 24, extra=example['extra'],
-                           obs=example['flow_obs'], gw_obs=0.12667, want_discharge=False)
+    kw = dict(extra=bench.EXTRA, obs=obs, gw_obs=0.12667)
+    out = eng.run_ensemble(dev_p, f, bench.AREA, 3600.0, W, 24, **kw)
+    assert 'smart_fast_intervals[16 slices' in out._prepared.describe()     # the kernel the bench line names
     perm = torch.randperm(N, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
-    out_p = eng.run_ensemble(dev_p[perm], f, example['area'], 3600.0, 8760, 24, extra=example['extra'],
-                             obs=example['flow_obs'], gw_obs=0.12667, want_discharge=False)
+    out_p = eng.run_ensemble(dev_p[perm], f, bench.AREA, 3600.0, W, 24, want_discharge=False, **kw)
     assert torch.equal(out.objfn[perm], out_p.objfn) and torch.equal(out.gw[perm], out_p.gw)
     gw = out.gw.cpu().numpy()
     obj = out.objfn.cpu().numpy()
     assert np.all(np.isfinite(obj)) and np.all((gw >= 0) & (gw <= 1)) and np.all(obj[:, 0] <= 1) and \
         np.all(obj[:, 6] >= 0) and set(np.unique(obj[:, 7])) <= {0.0, 1.0}
-    rows = np.random.default_rng(7).choice(N, 8, replace=False)
-    dis, gwo, _ = so.run_batch(example['area'], 3600.0, 87672, 8760, example['rain_hourly'], example['peva_hourly'],
-                               params[rows], example['extra'], so.REPORT_SUMMARY, 24)
-    want = objfn_oracle.objective_matrix(dis, example['flow_obs'], gwo, 0.12667)
+    rows = np.sort(np.random.default_rng(7).choice(N, 64, replace=False))
+    dis, gwo, _ = so.run_batch(bench.AREA, 3600.0, T, W, f[:, 0].copy(), f[:, 1].copy(), params[rows], bench.EXTRA,
+                               so.REPORT_SUMMARY, 24)
+    got = out.discharge[torch.from_numpy(rows).cuda()].cpu().numpy()
+    assert got.shape == dis.shape == (64, T // 24)
+    assert rel(got, dis) < REL_FAST                             # 64 x 3,653 daily means against the reference order
+    want = objfn_oracle.objective_matrix(dis, obs, gwo, 0.12667)
+    assert rel(obj[rows, :7], want[:, :7]) < 1e-9 and np.array_equal(obj[rows, 7], want[:, 7])
+    assert rel(gw[rows], gwo) < 1e-10
+
+
+def test_config4_size_one_million_samples(eng):
+    """BASELINE config 4's size on one GPU: 1e6 LHS samples x hourly 10 years, objective functions only (the [N, 9]
+    block the ranks all-gather).  (i) a 125,000-row block of it -- one rank's shard on 8 GPUs -- run on its own gives
+    the same bits as those rows inside the full launch (another kernel variant load, another slice schedule);
+    (ii) 8 rows against the oracle; (iii) physical ranges."""
+    import torch
+    import bench
+    N = 1000000
+    params = lhs_oracle.lhs_params(N, seed=2718)
+    f, rng = bench.synthetic_forcing(0, hourly=True)
+    T, W = f.shape[0], 8760
+    obs = np.abs(rng.normal(2.0, 1.0, T // 24))
+    obs[rng.random(T // 24) < 0.12] = np.nan
+    dev_p = torch.from_numpy(params).cuda()
+    kw = dict(extra=bench.EXTRA, obs=obs, gw_obs=0.12667, want_discharge=False)
+    out = eng.run_ensemble(dev_p, f, bench.AREA, 3600.0, W, 24, **kw)
+    assert 'smart_fast_intervals_exits[16 slices x 15625 blocks' in out._prepared.describe()
+    lo, hi = 3 * 125000, 4 * 125000                                  # rank 3's shard under shard_bounds(1e6, 8, 3)
+    part = eng.run_ensemble(dev_p[lo:hi].contiguous(), f, bench.AREA, 3600.0, W, 24, **kw)
+    assert torch.equal(part.objfn, out.objfn[lo:hi]) and torch.equal(part.gw, out.gw[lo:hi])
+    gw, obj = out.gw.cpu().numpy(), out.objfn.cpu().numpy()
+    assert np.all(np.isfinite(obj)) and np.all((gw >= 0) & (gw <= 1)) and np.all(obj[:, 0] <= 1)
+    rows = np.sort(np.random.default_rng(11).choice(N, 8, replace=False))
+    dis, gwo, _ = so.run_batch(bench.AREA, 3600.0, T, W, f[:, 0].copy(), f[:, 1].copy(), params[rows], bench.EXTRA,
+                               so.REPORT_SUMMARY, 24)
+    want = objfn_oracle.objective_matrix(dis, obs, gwo, 0.12667)
     assert rel(obj[rows, :7], want[:, :7]) < 1e-9 and np.array_equal(obj[rows, 7], want[:, 7])
     assert rel(gw[rows], gwo) < 1e-10
 
@@ -746,3 +787,106 @@ def test_final_states_do_not_change_the_discharge(eng, example, monkeypatch):
 def torch_equal(a, b):
     import torch
     return torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------------
+# the launch's status word: a slice that never gets its hand-over, a plan that no longer fits
+# ------------------------------------------------------------------------------------------------------
+def test_a_lost_time_slice_is_detected_and_the_launch_repeated(eng, example, monkeypatch):
+    """SMART_DEBUG_DROP_SLICE makes slice 0 of block 0 skip its publish, the situation a preempted queue could
+    create: its successor gives up after SMART_DEBUG_MAX_POLLS polls, the block's outputs are NaN from that slice on
+    (never a number computed from a missing state), the other blocks are untouched, and the status word says so.
+    run_ensemble() reads the word and repeats the launch without time slices."""
+    import warnings
+    from smartpy_amd import _lib
+    params = lhs_oracle.lhs_params(200, seed=77)
+    T, W = 24 * 300, 24 * 60
+    f = forcing_of(example['rain_hourly'][:T], example['peva_hourly'][:T])
+    kw = dict(extra=example['extra'], obs=example['flow_obs'][:T // 24], gw_obs=0.12667)
+    plain = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, time_slices=1, **kw)
+    monkeypatch.setenv('SMART_DEBUG_DROP_SLICE', '1')
+    monkeypatch.setenv('SMART_DEBUG_MAX_POLLS', '3000')          # ~10 ms instead of three seconds
+    p = eng.prepare_ensemble(params, f, example['area'], 3600.0, W, 24, time_slices=4, **kw)
+    bad = p.launch()
+    assert p.status() == _lib.STATUS_SLICE_TIMEOUT
+    dis, ref = bad.discharge.cpu().numpy(), plain.discharge.cpu().numpy()
+    cut = (W // 24 + T // 24) // 4 - W // 24                     # first report interval of slice 1
+    assert bits_equal(dis[64:], ref[64:]) and bits_equal(dis[:64, :cut], ref[:64, :cut])
+    assert np.all(np.isnan(dis[:64, cut:]))
+    assert np.all(np.isnan(bad.gw.cpu().numpy()[:64])) and np.all(np.isnan(bad.objfn.cpu().numpy()[:64]))
+    assert bits_equal(bad.gw.cpu().numpy()[64:], plain.gw.cpu().numpy()[64:])
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter('always')
+        fixed = p.verify()
+    assert any('time slice' in str(w.message) for w in seen)
+    assert bits_equal(fixed.discharge.cpu().numpy(), ref) and bits_equal(fixed.gw.cpu().numpy(), plain.gw.cpu().numpy())
+    # and the one-call form does all of that by itself
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter('always')
+        auto = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, time_slices=4, **kw)
+    assert bits_equal(auto.discharge.cpu().numpy(), ref)
+    assert np.array_equal(auto.objfn.cpu().numpy(), plain.objfn.cpu().numpy(), equal_nan=True)
+
+
+def test_a_stale_plan_is_detected_and_replaced(eng, example):
+    """A prepared call remembers which kernels its rows and forcing need.  Change the parameter matrix underneath it
+    (a row becomes stiff) and the kernel that meets the unplanned block flags it; verify() re-plans and repeats."""
+    import torch
+    import warnings
+    from smartpy_amd import _lib
+    T, W = 24 * 120, 24 * 20
+    f = torch.as_tensor(forcing_of(example['rain_hourly'][:T], example['peva_hourly'][:T])).cuda()
+    params = torch.as_tensor(lhs_oracle.lhs_params(192, seed=12)).cuda()
+    p = eng.prepare_ensemble(params, f, example['area'], 3600.0, W, 24, extra=example['extra'], group_variants=False)
+    p.launch()
+    assert p.status() == 0 and 'stiff' not in p.describe()
+    params[100, 9] = 0.7                       # RK < 1 h: block 1 is stiff now; the prepared call points at this tensor
+    p.launch()
+    assert p.status() == _lib.STATUS_STALE_PLAN
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter('always')
+        fixed = p.verify()
+    assert 'smart_fast_stiff' in p.describe()
+    fresh = eng.run_ensemble(params.clone(), f, example['area'], 3600.0, W, 24, extra=example['extra'],
+                             group_variants=False)
+    assert torch.equal(fixed.discharge, fresh.discharge) and torch.equal(fixed.gw, fresh.gw)
+    # the forcing can go stale too: the interval engine was planned, the series now varies inside a day
+    q = eng.prepare_ensemble(params, f, example['area'], 3600.0, W, 24, extra=example['extra'], group_variants=False)
+    f[1000, 0] += 0.01
+    q.launch()
+    assert q.status() == _lib.STATUS_STALE_PLAN
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter('always')
+        fixed = q.verify()
+    fresh = eng.run_ensemble(params.clone(), f.clone(), example['area'], 3600.0, W, 24, extra=example['extra'],
+                             group_variants=False)
+    assert torch.equal(fixed.discharge, fresh.discharge)
+
+
+def test_several_kernels_of_one_call_capture_into_a_hip_graph(eng):
+    """A daily ensemble with the default parameter ranges needs three kernels (regular, stiff, ill-conditioned rows);
+    they run side by side on forked streams that join the caller's stream again -- a pattern a HIP graph capture
+    follows.  Replays give the bits of the plain call."""
+    import torch
+    import bench
+    dev = torch.device('cuda:0')
+    f = torch.as_tensor(bench.synthetic_forcing(0, hourly=False)[0], device=dev)
+    params = torch.as_tensor(lhs_oracle.lhs_params(3000, seed=19), device=dev)
+    area = torch.tensor([bench.AREA], dtype=torch.float64, device=dev)
+    extra = torch.tensor([eng.extra_vector(bench.EXTRA)], dtype=torch.float64, device=dev)
+    p = eng.prepare_ensemble(params, f, area, 86400.0, 365, 1, extra=extra)
+    assert p.describe().count('smart_fast_') == 3
+    ref = p.launch()
+    ref_dis, ref_gw = ref.discharge.clone(), ref.gw.clone()
+    torch.cuda.synchronize()
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            p.launch()
+    for _ in range(3):
+        p._dis.zero_()
+        p._gw.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        out = p._result()
+        assert torch.equal(out.discharge, ref_dis) and torch.equal(out.gw, ref_gw)

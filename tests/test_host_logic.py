@@ -209,54 +209,51 @@ def test_device_latin_hypercube_is_latin():
 
 
 # ---- sampling database format (montecarlo.py:123-127, 211-262) ---------------------------------------------------
-class _FakeMC(object):
-    """Just enough of MonteCarlo to exercise the writer / reader without a model."""
-
-    def __init__(self, path, save_sim, names):
-        from smartpy_amd.montecarlo.montecarlo import MonteCarlo
-        self.out_format, self.db_file, self.save_sim, self.database = 'csv', path, save_sim, None
-        self.obj_fn_names = names
-        self.param_names = ['T', 'C', 'H', 'D', 'S', 'Z', 'SK', 'FK', 'GK', 'RK']
-        self._stamps = [START + timedelta(days=k) for k in range(3)]
-        for name in ('_init_db', '_write_rows', '_compress', '_get_sampled_sets_from_file', 'save'):
-            setattr(self, name, getattr(MonteCarlo, name).__get__(self))
-        self._sample = None
-
-    def _simu_stamps(self):
-        return self._stamps
-
-
 @pytest.mark.parametrize('save_sim', [False, True])
 def test_sampling_database_csv_round_trip(tmp_path, save_sim):
+    """montecarlo/database.py: header, float32 '%.6e' rows (bulk writer and the per-sample one give the same text),
+    reading back by column name, gzip."""
+    from smartpy_amd.montecarlo.database import database_for, SamplingCsv
     g4 = load_golden('g4_example_lhs.npz')
     names = ['NSE', 'KGE', 'KGEc', 'KGEa', 'KGEb', 'PBias', 'RMSE', 'GW']
-    mc = _FakeMC(str(tmp_path / 'C.SMART.lhs'), save_sim, names)
-    mc._sample = g4['params']
+    pnames = ['T', 'C', 'H', 'D', 'S', 'Z', 'SK', 'FK', 'GK', 'RK']
+    stamps = [START + timedelta(days=k) for k in range(3)] if save_sim else None
     sims = g4['discharge'][:, :3]
-    mc._init_db()
-    mc._write_rows(g4['objfns'], g4['params'], sims)
-    mc.database.close()
-    lines = open(mc.db_file).read().split('\n')
-    head = ','.join(names + mc.param_names + (['2007-01-01 09:00:00', '2007-01-02 09:00:00', '2007-01-03 09:00:00']
-                                                if save_sim else []))
+    path = str(tmp_path / 'C.SMART.lhs')
+    db = database_for('csv', path, names, pnames)
+    assert isinstance(db, SamplingCsv)
+    db.create(10, stamps)
+    db.write_table(g4['objfns'], g4['params'], sims)
+    db.close()
+    lines = open(path).read().split('\n')
+    head = ','.join(names + pnames + (['2007-01-01 09:00:00', '2007-01-02 09:00:00', '2007-01-03 09:00:00']
+                                      if save_sim else []))
     assert lines[0] == head and len(lines) == 12 and lines[-1] == ''
     row = [g4['objfns'][0], g4['params'][0]] + ([sims[0]] if save_sim else [])
     assert lines[1] == ','.join('%.6e' % np.float32(x) for x in np.concatenate(row))      # montecarlo.py:225-231
-    params, fns = mc._get_sampled_sets_from_file(mc.db_file, mc.param_names, names, False)
+    params, fns = db.read()
     # '%.6e' keeps 7 significant digits: the second stage sees the sample to ~1e-7, as in the reference
     assert params.dtype == np.float32 and np.allclose(params, g4['params'], rtol=1e-6, atol=0)
     assert np.allclose(fns, g4['objfns'], rtol=1e-6)
-    # the per-sample save() of the reference protocol writes the same row text
-    mc2 = _FakeMC(str(tmp_path / 'D.SMART.lhs'), save_sim, names)
-    mc2._sample = g4['params']
-    mc2._init_db()
+    # ... which is what selection.as_stored reproduces without a database (device-side second stages)
+    from smartpy_amd.montecarlo.selection import as_stored
+    assert np.array_equal(as_stored(g4['params']), params) and np.array_equal(as_stored(g4['objfns']), fns)
+    # a reader asking for fewer / reordered objective functions finds them by header name
+    p_again, nse_rmse = database_for('csv', path, ['RMSE', 'NSE'], pnames).read()
+    assert np.array_equal(p_again, params) and np.array_equal(nse_rmse, fns[:, [6, 0]])
+    with pytest.raises(KeyError):
+        database_for('csv', path, ['NSE', 'Bias'], pnames).read()
+    # the per-sample writer of the reference protocol gives the same text
+    one = database_for('csv', str(tmp_path / 'D.SMART.lhs'), names, pnames).create(10, stamps)
     for r in range(10):
-        mc2.save(list(g4['objfns'][r]), g4['params'][r], [sims[r]])
-    mc2.database.close()
-    assert open(mc2.db_file).read() == open(mc.db_file).read()
-    mc._compress(True)                                                                     # montecarlo.py:171-177
-    assert not os.path.exists(mc.db_file) and gzip.open(mc.db_file + '.gz', 'rt').readline().strip() == head
-    p2, f2 = mc._get_sampled_sets_from_file(mc.db_file, mc.param_names, names, True)
+        one.write_sample(None, list(g4['objfns'][r]), g4['params'][r], sims[r])
+    one.close()
+    assert open(one.path).read() == open(path).read()
+    db.compress(None)
+    assert os.path.exists(path)
+    db.compress(True)                                                                      # montecarlo.py:171-177
+    assert not os.path.exists(path) and gzip.open(path + '.gz', 'rt').readline().strip() == head
+    p2, f2 = db.read(gzipped=True)
     assert np.array_equal(p2, params) and np.array_equal(f2, fns)
 
 
