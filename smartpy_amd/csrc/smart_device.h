@@ -159,8 +159,9 @@ constexpr int kChunk = SMART_CHUNK;
 
 // The rain excess of the kChunk steps of a chunk is evaluated together, ahead of the steps (independent FMAs that
 // fill issue slots while the first step's dependent chain starts).
-template <class Model, class Body>
-__device__ __forceinline__ void time_loop(const Model &m, const double2 *__restrict__ f, long n, Body &&body)
+template <class Model, class Body, class ChunkEnd>
+__device__ __forceinline__ void time_loop_chunked(const Model &m, const double2 *__restrict__ f, long n, Body &&body,
+                                                  ChunkEnd &&chunk_end)
 {
     const long n_chunks = n / kChunk;
     double2 cur[kChunk], nxt[kChunk];
@@ -181,6 +182,7 @@ __device__ __forceinline__ void time_loop(const Model &m, const double2 *__restr
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
             body(cur[j], ex[j]);
+        chunk_end();
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
             cur[j] = nxt[j];
@@ -189,6 +191,12 @@ __device__ __forceinline__ void time_loop(const Model &m, const double2 *__restr
         const double2 v = f[t];
         body(v, m.excess(v.x, v.y));
     }
+}
+
+template <class Model, class Body>
+__device__ __forceinline__ void time_loop(const Model &m, const double2 *__restrict__ f, long n, Body &&body)
+{
+    time_loop_chunked(m, f, n, body, [] {});
 }
 
 // ---- pieces shared by the two launch bodies below ------------------------------------------------------------
@@ -653,22 +661,46 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
             });
         }
     } else {
+        // the step loop with deferred evaporation (Model::step_lazy); the demand a slice has not yet taken from the
+        // layers travels in the hand-over, so that a sliced run composes exactly like a whole one
+        m.begin_lazy(seg > 0 ? hand[15 * kWave] : 0.0);
+        // no rain and no evaporation in this step (forcing is wave-uniform: scalar unit); never when a layer may be
+        // above its capacity (Model::zero_ok)
+        const unsigned long long not_ok = m.zero_ok ? 0ull : ~0ull;
+        auto calm = [not_ok](const double2 v) {
+            return (__builtin_bit_cast(unsigned long long, v.x) | __builtin_bit_cast(unsigned long long, v.y) | not_ok) == 0;
+        };
         time_loop(m, f + wa * gap, (wb - wa) * gap,
-                  [&](const double2 v, const double ex) { m.step(v.x, v.y, ex, s0, s1, s2); });
+                  [&](const double2 v, const double ex) { m.step_lazy(ex, calm(v), s0, s1, s2); });
         if (starts_run)
             m.begin_run();
         long k = 0, r = ra;
         double acc = 0.0;
-        time_loop(m, f + ra * gap, (rb - ra) * gap, [&](const double2 v, const double ex) {
-            m.step(v.x, v.y, ex, acc, num, den);
-            if (__builtin_expect(++k == gap, 0)) { // end of report interval r (wave-uniform)
-                rep.emit(a, x, r, acc * inv_gap);
-                ++r;
-                k = 0;
-                q_out_total += acc;
-                acc = 0.0;
-            }
-        });
+        auto report = [&]() { // end of report interval r (wave-uniform)
+            rep.emit(a, x, r, acc * inv_gap);
+            ++r;
+            k = 0;
+            q_out_total += acc;
+            acc = 0.0;
+        };
+        if (gap % kChunk == 0) { // intervals end on chunk boundaries: one test per chunk of steps, not per step
+            time_loop_chunked(
+                m, f + ra * gap, (rb - ra) * gap,
+                [&](const double2 v, const double ex) { m.step_lazy(ex, calm(v), acc, num, den); },
+                [&]() {
+                    k += kChunk;
+                    if (__builtin_expect(k == gap, 0))
+                        report();
+                });
+        } else {
+            time_loop(m, f + ra * gap, (rb - ra) * gap, [&](const double2 v, const double ex) {
+                m.step_lazy(ex, calm(v), acc, num, den);
+                if (__builtin_expect(++k == gap, 0))
+                    report();
+            });
+        }
+        if (last)
+            m.flush_pending(); // the final state vector wants the layers as the reference leaves them
     }
 
     if (last) {
@@ -683,6 +715,8 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         hand[19 * kWave] = rep.C1;
         hand[20 * kWave] = rep.C2;
         hand[21 * kWave] = rep.C3;
+        if constexpr (!piecewise)
+            hand[15 * kWave] = m.pend;
         if (!(a.debug_drop && slot == 0 && seg == 0)) // test knob: a hand-over that never arrives
             publish_slice(a, slot, seg, true);
     }

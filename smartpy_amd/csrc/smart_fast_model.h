@@ -510,6 +510,115 @@ struct FastModel {
         wet_lanes(ex);
     }
 
+    // ---- step loop with deferred evaporation (forcing that varies inside the report interval) -----------------------
+    // A dry step does two unrelated things: the reservoirs drain (routing, needed every step: the river's outflow is
+    // reported) and the evaporation demand is taken from the soil layers (6 x 3 dependent instructions) -- but nothing
+    // looks at the layers again until the lane's next WET step.  The cascade composes additively (dry_interval below:
+    // demands d1 then d2 leave the same levels and hand down the same total as d1 + d2 at once), so a dry step only
+    // adds its demand to `pend` and the cascade runs once, when the lane turns wet (or its states are asked for).
+    // Lanes with nothing pending see the cascade as the identity, so a sample's arithmetic does not depend on its
+    // wave neighbours.  The layer sum is carried from wet step to wet step (`tot_c`, recomputed after a cascade).
+    // Steps with neither rain nor evaporation for the whole wavefront (night hours of sub-daily data; forcing is
+    // wave-uniform) are wet steps with zero excess: no overland flow, nothing to fill, only the leaks -- the filling
+    // cascade is skipped, bit-identical to running it with zero excess as long as no layer is above its capacity (a
+    // caller's initial state could be: zero_ok).
+    double pend, tot_c;
+    bool zero_ok;
+
+    __device__ void begin_lazy(double pending)
+    {
+        pend = pending;
+        tot_c = layer_sum();
+        const bool over = l0 > z || l1 > z || l2 > z || l3 > z || l4 > z || l5 > z;
+        zero_ok = __builtin_amdgcn_ballot_w64(over) == 0;
+    }
+
+    __device__ __forceinline__ void flush_pending()
+    {
+        // the exits only skip identity operations (a lane whose demand is met sees max(l, 0) and max(-C l, 0) = 0)
+        double d = pend;
+        dry(l0, d, pC);
+        if (__builtin_amdgcn_ballot_w64(d > 0.0) != 0) {
+            dry(l1, d, pC);
+            if (__builtin_amdgcn_ballot_w64(d > 0.0) != 0) {
+                dry(l2, d, pC);
+                dry(l3, d, pC);
+                dry(l4, d, pC);
+                dry(l5, d, pC);
+            }
+        }
+        pend = 0.0;
+        tot_c = layer_sum();
+    }
+
+    // One step, written as straight-line code around ONE predicated region: every lane routes, every lane adds its
+    // (possibly zero) evaporation demand to `pend` and its (possibly zero) inflows to the reservoirs; only the soil
+    // half of a wet step sits under `if (ex >= 0)`.  (A three-way wet / calm / dry branch with the routing in each arm
+    // cost more than it saved: the arms left the states in different registers and the joins paid for it.)
+    // `calm`: rain == 0 and peva == 0 for this step and zero_ok (wave-uniform, decided on the scalar unit by the
+    // caller).
+    __device__ __forceinline__ void step_lazy(double ex, bool calm, double &acc, double &num, double &den)
+    {
+        route_and_sum(acc, num, den);
+        pend += fmax(-ex, 0.0);
+        double x_s = 0.0, x_f = 0.0, x_g = 0.0, x_dra = 0.0, x_dgw = 0.0;
+        if (ex >= 0.0) { // structure.py:359
+            if (__builtin_amdgcn_ballot_w64(pend > 0.0) != 0)
+                flush_pending();
+            double &tot = tot_c;
+            const double s1 = sz * tot;
+            double ex_in = 0.0, rem = 0.0, e_h = 0.0;
+            if (!calm) { // scalar branch: nothing to fill on a calm step (the caller folds zero_ok into `calm`)
+                e_h = ex * hz;
+                ex_in = fma(-e_h, tot, ex); // excess left after the overland share H tot/Z ex (:363-365)
+                rem = ex_in;
+                fill3(l0, rem, z);
+                fill3(l1, rem, z);
+                fill3(l2, rem, z);
+                fill3(l3, rem, z);
+                fill3(l4, rem, z);
+                fill3(l5, rem, z);
+            }
+            const double p2 = s1 * s1, p3 = p2 * s1, p4 = p2 * p2, p5 = p4 * s1, p6 = p3 * p3;
+            l0 = fma(-l0, s1, l0);
+            l1 = fma(-l1, p2, l1);
+            l2 = fma(-l2, p3, l2);
+            l3 = fma(-l3, p4, l3);
+            l4 = fma(-l4, p5, l4);
+            l5 = fma(-l5, p6, l5);
+            const double after_int = layer_sum();
+            l0 = fma(-l0, s1, l0);
+            l1 = fma(-l1, s1 * 0.5, l1);
+            l2 = fma(-l2, s1 * (1.0 / 3.0), l2);
+            l3 = fma(-l3, s1 * 0.25, l3);
+            l4 = fma(-l4, s1 * 0.2, l4);
+            l5 = fma(-l5, s1 * (1.0 / 6.0), l5);
+            const double after_sgw = SPLIT ? layer_sum() : 0.0;
+            l0 = fma(-l0, p6, l0);
+            l1 = fma(-l1, p5, l1);
+            l2 = fma(-l2, p4, l2);
+            l3 = fma(-l3, p3, l3);
+            l4 = fma(-l4, p2, l4);
+            l5 = fma(-l5, s1, l5);
+            x_f = (tot - after_int) + fma(-pD, rem, ex_in);
+            x_s = fma(pD, rem, e_h * tot);
+            tot = layer_sum();
+            x_g = after_int - tot;
+            if (SPLIT) {
+                x_dra = pD * rem;
+                x_dgw = after_sgw - tot;
+            }
+        }
+        fma_in_place(u_ove, dec_s, x_s);
+        fma_in_place(u_int, dec_f, x_f);
+        fma_in_place(u_sgw, dec_g, x_g);
+        if (SPLIT) {
+            fma_in_place(u_dra, dec_s, x_dra);
+            fma_in_place(u_dgw, dec_g, x_dgw);
+        }
+        xg_sum += x_g;
+    }
+
     // ---- a whole report interval without rain excess (run_ensemble_merged) ------------------------------------
     // While no lane gets inflow the routing half of the model is linear with constant coefficients:
     //   U_j' = dec_j U_j  (j = quick, inter, groundwater),   U_riv' = (1 - a_r) U_riv + a_r (U_q + U_i + U_g)
