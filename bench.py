@@ -250,7 +250,7 @@ def main():
         # frac = vector instructions the kernel executes x 4 issue cycles / the issue cycles 1,024 SIMDs have in one
         # launch.  The instruction count is a property of (kernel build, workload): it comes from the committed PMC
         # summary of this same command and is only quoted while the kernel sources hash to what was profiled.
-        traffic = insts = held_clock = None
+        traffic = insts = held_clock = held_frac = None
         pmc_note = 'no PMC summary for this workload'
         tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
         if os.path.exists(tpath):
@@ -263,6 +263,7 @@ def main():
                 traffic = pmc.get('hbm_bytes_per_launch')
                 insts = pmc.get('valu_insts_per_launch')
                 held_clock = pmc.get('held_clock_hz')
+                held_frac = pmc.get('issue_frac_at_held_clock')
                 pmc_note = pmc.get('source', 'profiles/traffic_latest.json')
             else:
                 pmc_note = 'profiles/traffic_latest.json was measured on other kernel sources (hash %s, now %s): ' \
@@ -275,9 +276,10 @@ def main():
             'unit': 'T wave-instructions/s',
             'frac': issue,
             'clock_basis_hz': CLOCK_HZ,
-            'frac_at_held_clock': None if insts is None or not held_clock else
-            insts * VALU_ISSUE_CYCLES / (N_SIMD * kern_s * held_clock),
-            'held_clock_hz': held_clock,
+            # the same fraction over the shader cycles the chip actually ran (it lowers its clock under this load):
+            # taken whole from the profiled runs (SQ_INSTS_VALU x 4 / (1,024 SIMDs x GRBM_GUI_ACTIVE / 8)), not mixed
+            # with this run's timing
+            'frac_at_held_clock': held_frac, 'held_clock_hz': held_clock,
             'valu_insts_per_launch': insts,
             'valu_insts_per_wave_step': None if insts is None else insts / (blocks_local * steps_per_run),
             'kernel': kernels, 'launch_ms': launch_ms, 'traffic': traffic, 'pmc_key': pmc_key, 'pmc_source': pmc_note,

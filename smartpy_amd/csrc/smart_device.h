@@ -322,7 +322,7 @@ struct Reporter {
 
 template <class Model>
 __device__ __forceinline__ void write_results(const KArgs &a, const LaneCtx &x, const Model &m, const Reporter &rep,
-                                              double gw)
+                                              double gw, const double *flows = nullptr)
 {
     if (x.live)
         a.gw[x.c * a.N + x.n] = gw;
@@ -337,7 +337,7 @@ __device__ __forceinline__ void write_results(const KArgs &a, const LaneCtx &x, 
     }
     if (a.final_vars && x.live) {
         double v[19];
-        m.get_vars(v);
+        m.get_vars(v, flows);
         double *fp = a.final_vars + (x.c * a.N + x.n) * 19;
 #pragma unroll
         for (int i = 0; i < 19; ++i)
@@ -379,7 +379,7 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
     if constexpr (Model::kBalanceSums)
         m.begin_run();
     long k = 0, r = 0, len = a.first_len;
-    time_loop(m, f, a.T, [&](const double2 v, const double ex) {
+    auto one_step = [&](const double2 v, const double ex) {
         // the model adds this step's river outflow / groundwater outflow / total catchment outflow to the three
         // running sums itself, so that those additions sit in the same basic block as the step's dependent chains
         m.step(v.x, v.y, ex, acc, num, den);
@@ -405,11 +405,21 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
                 q_out_total += acc;
             acc = 0.0;
         }
-    });
+    };
+    // the last row of the storage table holds the seven outputs of the last step (structure.py:197): models that do not
+    // track them take the last step on its own, after working them out from the state it starts from
+    double flows[7];
+    const bool capture = a.final_vars != nullptr && !Model::kTracksOutputs;
+    time_loop(m, f, capture ? a.T - 1 : a.T, one_step);
+    if (capture) {
+        const double2 v = f[a.T - 1];
+        m.flows_of_next_step(a.dt, v.x, v.y, flows);
+        one_step(v, m.excess(v.x, v.y));
+    }
 
     if constexpr (Model::kBalanceSums)
         m.balance_sums(q_out_total, num, den);
-    write_results(a, x, m, rep, summary ? num / den : num_raw / den_raw);
+    write_results(a, x, m, rep, summary ? num / den : num_raw / den_raw, capture ? flows : nullptr);
 }
 
 // ---- piecewise-constant forcing ------------------------------------------------------------------------------
@@ -635,6 +645,22 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         rep.C3 = hand[21 * kWave];
     }
 
+    // Callers that ask for the final state vector (the SPLIT models) also get the seven outputs of the last step
+    // (structure.py:197).  They are functions of the state the last STEP starts from, which an interval-at-a-time walk
+    // never holds: the state at the start of the last report interval is parked in the sample's own final_vars row
+    // (19 doubles, written for good at the very end), and once the run is over that interval is replayed step by step
+    // -- gap - 1 steps and a look at the flows -- on a copy of the model.  Costs one interval per run, and nothing in
+    // the kernels of callers that do not ask.
+    // (the host launches a SPLIT kernel only for callers with a final_vars buffer)
+    double *const park = Model::kSplit ? a.final_vars + (x.c * a.N + x.n) * 19 : nullptr;
+    auto park_state = [&]() {
+        if constexpr (Model::kSplit) {
+            m.save_state(park, 1);
+            if constexpr (!piecewise)
+                park[15] = m.pend;
+        }
+    };
+
     // warm-up over the first W steps of the same forcing, only the states survive (structure.py:118-121); then the
     // run proper.  One branch around both loops: the flat side must not keep the interval coefficients alive.
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -647,6 +673,8 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         if (rep.want_obj) {
             interval_loop_obs(f, rep.obs, rep.ws + kWsHead, ra, rb, gap,
                               [&](long r, const double2 v, const double e, const double w) {
+                                  if (Model::kSplit && r == a.R - 1)
+                                      park_state();
                                   double acc = 0.0;
                                   interval(v, acc, num, den);
                                   rep.emit_prefetched(a, x, r, acc * inv_gap, e, w);
@@ -654,6 +682,8 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                               });
         } else {
             interval_loop(f, ra, rb, gap, [&](long r, const double2 v) {
+                if (Model::kSplit && r == a.R - 1)
+                    park_state();
                 double acc = 0.0;
                 interval(v, acc, num, den);
                 rep.emit(a, x, r, acc * inv_gap);
@@ -676,12 +706,16 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
             m.begin_run();
         long k = 0, r = ra;
         double acc = 0.0;
+        if (Model::kSplit && ra == a.R - 1 && rb > ra)
+            park_state();
         auto report = [&]() { // end of report interval r (wave-uniform)
             rep.emit(a, x, r, acc * inv_gap);
             ++r;
             k = 0;
             q_out_total += acc;
             acc = 0.0;
+            if (Model::kSplit && r == a.R - 1)
+                park_state();
         };
         if (gap % kChunk == 0) { // intervals end on chunk boundaries: one test per chunk of steps, not per step
             time_loop_chunked(
@@ -706,7 +740,26 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
     if (last) {
         m.balance_sums(q_out_total, num, den);
         double gw = num / den;
-        write_results(a, x, m, rep, gw);
+        if constexpr (Model::kSplit) { // replay the last report interval from the parked state, step by step
+            double flows[7];
+            Model m0 = m;
+            m0.load_state(park, 1);
+            if constexpr (!piecewise) {
+                m0.begin_lazy(park[15]);
+                m0.flush_pending();
+            }
+            const double2 *__restrict__ fl = f + (a.R - 1) * gap;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+            for (long j = 0; j + 1 < gap; ++j) {
+                const double2 v = fl[j];
+                m0.step(v.x, v.y, m0.excess(v.x, v.y), t0, t1, t2);
+            }
+            const double2 v = fl[gap - 1];
+            m0.flows_of_next_step(a.dt, v.x, v.y, flows);
+            write_results(a, x, m, rep, gw, flows);
+        } else {
+            write_results(a, x, m, rep, gw);
+        }
     } else {
         m.save_state(hand, kWave);
         hand[16 * kWave] = q_out_total;

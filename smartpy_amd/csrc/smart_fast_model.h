@@ -68,6 +68,7 @@ struct FastModel {
     static_assert(!(MERGE && STIFF), "the clamps of structure.py:429-450 act on each reservoir separately");
     static_assert(MERGE || !SPLIT, "SPLIT refines the merged form");
     static constexpr bool kExactDivide = false;
+    static constexpr bool kSplit = SPLIT;
 
     // per-sample constants
     double pT, pC, pD, hz, sz, z;
@@ -139,14 +140,57 @@ struct FastModel {
         u_riv = st[11] / k_r;
     }
 
-    // The seven outputs of the last step are not carried by the fast path: nothing in the reference reads
-    // them (run() returns [0:2] of run_all_steps, the warm-up hand-over uses the states only,
-    // structure.py:118-121,143-146,182-187).  They come back as NaN; the literal mode returns them.
-    __device__ void get_vars(double *v) const
+    // The seven outputs of the LAST step (structure.py:197 returns the whole last row of the storage table) are not
+    // carried through the loop: nothing reads them before the end (run() returns [0:2] of run_all_steps, the warm-up
+    // hand-over uses the states only, :118-121,143-146,182-187).  The loop skeletons call flows_of_next_step() once,
+    // on the state the last step starts from, and hand the result to get_vars().
+    static constexpr bool kTracksOutputs = false;
+
+    __device__ void flows_of_next_step(double dt, double rain_in, double peva_in, double *v) const
+    {
+        // outflows of a step are the reservoir states at its start (structure.py:427, :487)
+        if (MERGE) { // totals and (SPLIT) their drain / deep parts, volumes in mm
+            v[1] = (u_ove - u_dra) * cq_s;
+            v[2] = u_dra * cq_s;
+            v[3] = u_int * cq_f;
+            v[4] = (u_sgw - u_dgw) * cq_g;
+            v[5] = u_dgw * cq_g;
+        } else {
+            v[1] = u_ove;
+            v[2] = u_dra;
+            v[3] = u_int;
+            v[4] = u_sgw;
+            v[5] = u_dgw;
+        }
+        const double inflow = ((v[1] + v[2]) + v[3]) + (v[4] + v[5]);
+        double q_r = u_riv;
+        if (STIFF && fma(inflow - u_riv, a_r, u_riv) < 0.0) // 95 % rule, :492-496
+            q_r = 0.95 * fma(u_riv, inv_a_r, inflow);
+        v[6] = q_r;
+        // actual evaporation (:361, :401-419): the potential rate on a wet step; on a dry one the (scaled) rain plus
+        // what the cascade takes from the layers
+        const double ex = excess(rain_in, peva_in);
+        double aeva = peva_in;
+        if (!(ex >= 0.0)) {
+            const double lv[6] = {l0, l1, l2, l3, l4, l5};
+            double d = -ex;
+            aeva = rain_in * pT;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bool enough = lv[i] >= d;
+                aeva += enough ? d : lv[i];
+                d = enough ? 0.0 : pC * (d - lv[i]);
+            }
+        }
+        v[0] = aeva * mm_to_m3 / dt;
+    }
+
+    // `flows`: the seven outputs from flows_of_next_step(), or null (NaN: the caller did not capture them)
+    __device__ void get_vars(double *v, const double *flows) const
     {
 #pragma unroll
         for (int i = 0; i < 7; ++i)
-            v[i] = quiet_nan();
+            v[i] = flows ? flows[i] : quiet_nan();
         if (MERGE) { // totals and (SPLIT) their drain / deep parts, in mm; without SPLIT the pairs stay merged
             v[7] = (u_ove - u_dra) * mm_to_m3;
             v[8] = u_dra * mm_to_m3;

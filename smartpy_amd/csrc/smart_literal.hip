@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kWave) void smart_onestep_literal(long n, const dou
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     m.step(x[2], x[3], 0.0, s0, s1, s2);
     double v[19];
-    m.get_vars(v);
+    m.get_vars(v, nullptr);
 #pragma unroll
     for (int k = 0; k < 19; ++k)
         out[i * 19 + k] = v[k];

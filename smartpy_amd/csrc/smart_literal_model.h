@@ -19,6 +19,7 @@ namespace smart {
 struct LiteralModel {
     static constexpr bool kExactDivide = true;
     static constexpr bool kBalanceSums = false;
+    static constexpr bool kTracksOutputs = true; // out[] holds the seven outputs of the last step taken
 
     double area, dt;
     double pT, pC, pH, pD, pS, pZ, sk, fk, gk, rk;
@@ -59,7 +60,9 @@ struct LiteralModel {
         v_riv = st[11];
     }
 
-    __device__ void get_vars(double *v) const
+    __device__ void flows_of_next_step(double, double, double, double *) const {}
+
+    __device__ void get_vars(double *v, const double * = nullptr) const
     {
 #pragma unroll
         for (int i = 0; i < 7; ++i)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench line of every configuration (1 GPU), default bench, contract test.  usage: bash tools/gpu_r02b.sh <tag>
+# bench line of every configuration (1 GPU), default bench, contract test.  usage: bash tools/gpu_configs.sh <tag>
 TAG=${1:-b}
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -111,9 +111,15 @@ if main and 'GRBM_GUI_ACTIVE' in out['pmc'][main[0]] and 'full_size_dispatch_ms'
         durs += [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e9 for r in rows if int(r['Grid_Size_X']) == gmax]
     if durs:
         out['held_clock_hz'] = out['pmc'][main[0]]['GRBM_GUI_ACTIVE'] / 8 / (sum(durs) / len(durs))
+        c0 = out['pmc'][main[0]]
         lines += ['## clock held during the kernel', '',
                   '- GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same pass (%.4f ms) = %.3f GHz' % (
-                      sum(durs) / len(durs) * 1e3, out['held_clock_hz'] / 1e9), '']
+                      sum(durs) / len(durs) * 1e3, out['held_clock_hz'] / 1e9)]
+        if 'SQ_INSTS_VALU' in c0:
+            lines += ['- fp64 issue-slot fraction at that clock: SQ_INSTS_VALU x 4 cycles / (1,024 SIMDs x '
+                      'GRBM_GUI_ACTIVE / 8) = %.3f' % (c0['SQ_INSTS_VALU'] * 4.0 / (128 * c0['GRBM_GUI_ACTIVE'])),
+                      '- vector instructions per wave-step: see DESIGN.md 4.1 (SQ_INSTS_VALU / (blocks x steps))']
+        lines += ['']
 if workload and main and 'hbm_bytes_per_launch' in out:
     tpath = os.path.join(os.path.dirname(dst) or '.', 'traffic_latest.json')
     table = json.load(open(tpath)) if os.path.exists(tpath) else {}
@@ -127,6 +133,10 @@ if workload and main and 'hbm_bytes_per_launch' in out:
         'fetch_bytes_raw': out['hbm_read_bytes_raw'], 'write_bytes': out['hbm_write_bytes'],
         'valu_insts_per_launch': c.get('SQ_INSTS_VALU'), 'salu_insts_per_launch': c.get('SQ_INSTS_SALU'),
         'held_clock_hz': out.get('held_clock_hz'),
+        # vector instructions x 4 issue cycles over the shader cycles the chip was busy for (GRBM_GUI_ACTIVE / 8 XCDs x
+        # 1,024 SIMDs): the issue-slot fraction at the clock the chip held, from counters of the profiled runs alone
+        'issue_frac_at_held_clock': (c['SQ_INSTS_VALU'] * 4.0 / (1024 * c['GRBM_GUI_ACTIVE'] / 8.0)
+                                     if 'SQ_INSTS_VALU' in c and 'GRBM_GUI_ACTIVE' in c else None),
         'avg_ms_kernel_trace': out.get('full_size_dispatch_ms', {}).get('avg'),
         'source': dst + '.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU / GRBM_GUI_ACTIVE (separate '
                   'passes, tools/profile.sh) on the bench command of this workload; FETCH_SIZE doubled per '
