@@ -53,6 +53,9 @@
 #ifndef SMART_FAST_LEAK_BALANCE
 #define SMART_FAST_LEAK_BALANCE 1
 #endif
+#ifndef SMART_WET_UNROLL
+#define SMART_WET_UNROLL 1
+#endif
 
 namespace smart {
 
@@ -409,6 +412,10 @@ struct FastModel {
         if (kLeakBalance) {
             const double e_h = ex * hz;
             double tot = layer_sum();
+            // unrolled: a taken branch costs a wavefront that has its SIMD (nearly) to itself about as much as a
+            // dozen vector instructions (profiles/r01_microbench_valu_salu_branch.txt), and the loop's back-edge
+            // is one per 74
+#pragma unroll SMART_WET_UNROLL
             for (long k = 0; k < n; ++k) {
                 route_and_sum(acc, num, den);
                 wet_balance(ex, e_h, tot);
