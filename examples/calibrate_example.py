@@ -53,7 +53,7 @@ def main():
         print('single run: %d daily discharges, NSE = %.6f, groundwater contribution = %.4f' % (len(discharge), nse, gw))
 
     # ---- calibration: LHS over the default ranges, every row in one launch per GPU ---------------------------------
-    np.random.seed(2718)                    # every rank must draw the same sample (like every MPI rank of the reference)
+    np.random.seed(2718)                    # reproducible; with several ranks run() takes rank 0's sample either way
     t0 = time.perf_counter()
     lhs = LHS('Catchment', root, 'csv', 'csv', n)
     lhs.model.extra = EXTRA
@@ -67,8 +67,10 @@ def main():
         print('     best NSE %.4f (KGE %.4f) at %s' % (lhs.obj_fns[best, 0], lhs.obj_fns[best, 1],
                                                      {k: round(float(v), 4) for k, v in zip(lhs.param_names, lhs.lhs_params[best])}))
 
-    # ---- second stages read the database like the reference's GLUE / Best --------------------------------------------
-    glue = GLUE('Catchment', root, 'csv', 'csv', conditioning={'NSE': ('min', (0.4,)), 'KGEc': ('min', (0.9,))})
+    # ---- second stages: from the finished run itself (selection on the GPU, only the chosen rows travel) or, like the
+    # ---- reference's GLUE / Best, from the database file (leave `sampling=` out) ---------------------------------------
+    glue = GLUE('Catchment', root, 'csv', 'csv', conditioning={'NSE': ('min', (0.4,)), 'KGEc': ('min', (0.9,))},
+                sampling=lhs)
     glue.model.extra = EXTRA
     glue.run()
     top = Best('Catchment', root, 'csv', 'csv', target='KGE', nb_best=10, constraining={'GW': ('equal', (1.0,))})

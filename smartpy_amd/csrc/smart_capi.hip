@@ -504,10 +504,11 @@ static int decide(const SmartEnsemble *e, const DeviceCtx *d, const Workspace &w
     // a workspace without room for it means a plain launch
     if (x.n_seg > 1 && (!w.slices || w.slice_room < slice_bytes(e->n_samples, e->n_catchments)))
         x.n_seg = 1;
-    // early exits in the interval engine pay off once the SIMDs have two or more waves to issue from
-    // (FastModel::kExits; measured: off wins by 5 % at 1.53 blocks per SIMD, on wins by 4 % at 2.0, by 7 % at 15)
+    // early exits in the interval engine pay off once a SIMD holds three waves to issue from (FastModel::kExits;
+    // measured with the per-variant kernels, tools/ab_exits.sh: off wins by 5 % at 1.53 blocks per SIMD and by 4 % at
+    // 1.9, on wins by 6 % at 2.4 and by 7 % at 3.1 and above)
     const char *env = getenv("SMART_EXITS");
-    x.exits = env ? atoi(env) != 0 : x.load >= 1.75;
+    x.exits = env ? atoi(env) != 0 : x.load > 2.0;
     x.class_mask = plan & 0xf;
     if (plan & SMART_PLAN_CLASS_REGULAR) {
         if (x.intervals) {

@@ -9,7 +9,7 @@
 //
 //   kernel                       rows / forcing it takes                                         body
 //   smart_fast_intervals_exits   class 0, summary, gap >= 2, piecewise-constant forcing          interval engine, early exits
-//   smart_fast_intervals         same, for launches with < 1.75 blocks of 64 samples per SIMD    interval engine, straight-line
+//   smart_fast_intervals         same, for launches with <= 2 blocks of 64 samples per SIMD    interval engine, straight-line
 //   smart_fast_intervals_states  same, final state vector asked for                              interval engine, SPLIT
 //   smart_fast_steps             class 0, summary, gap >= 2, forcing varying inside the interval step loop, merged
 //   smart_fast_steps_states      same, final state vector asked for                              step loop, SPLIT
