@@ -97,6 +97,25 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def pmc_summary(pmc_key, path=None, source_hash=None):
+    """The committed PMC figures of one workload (profiles/traffic_latest.json, written by tools/summarize_profile.py
+    from rocprofv3 --pmc passes of this same command) -> (figures, where they come from).  They are properties of
+    (kernel build, workload), so they are only handed out while the kernel sources still hash to what was profiled;
+    otherwise ({}, the reason) and the bench line carries nulls rather than numbers measured on other code."""
+    path = path or os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+    if not os.path.exists(path):
+        return {}, 'no PMC summary file (profiles/traffic_latest.json)'
+    with open(path) as fh:
+        pmc = json.load(fh).get('workloads', {}).get(pmc_key)
+    if pmc is None:
+        return {}, 'no PMC summary for workload %s in profiles/traffic_latest.json' % pmc_key
+    now = source_hash or kernel_source_hash()
+    if pmc.get('source_hash') != now:
+        return {}, 'profiles/traffic_latest.json was measured on other kernel sources (hash %s, now %s): not quoted' \
+                   % (pmc.get('source_hash'), now)
+    return pmc, pmc.get('source', 'profiles/traffic_latest.json')
+
+
 def cpu_baseline_and_parity(forcing, n_warm, gap, dt, device, budget_s=12.0):
     """(1) The oracle's OpenMP batch runner (a C port of the reference loop) on the host cores, on a bounded sample of
     the same workload: reported next to the GPU number, never part of the timed GPU region.  (2) The same rows through
@@ -250,24 +269,9 @@ def main():
         # frac = vector instructions the kernel executes x 4 issue cycles / the issue cycles 1,024 SIMDs have in one
         # launch.  The instruction count is a property of (kernel build, workload): it comes from the committed PMC
         # summary of this same command and is only quoted while the kernel sources hash to what was profiled.
-        traffic = insts = held_clock = held_frac = None
-        pmc_note = 'no PMC summary for this workload'
-        tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                pmc_all = json.load(fh)
-            pmc = pmc_all.get('workloads', {}).get(pmc_key)
-            if pmc is None:
-                pmc_note = 'profiles/traffic_latest.json holds no PMC summary for workload %s' % pmc_key
-            elif pmc.get('source_hash') == kernel_source_hash():
-                traffic = pmc.get('hbm_bytes_per_launch')
-                insts = pmc.get('valu_insts_per_launch')
-                held_clock = pmc.get('held_clock_hz')
-                held_frac = pmc.get('issue_frac_at_held_clock')
-                pmc_note = pmc.get('source', 'profiles/traffic_latest.json')
-            else:
-                pmc_note = 'profiles/traffic_latest.json was measured on other kernel sources (hash %s, now %s): ' \
-                           'not quoted' % (pmc.get('source_hash'), kernel_source_hash())
+        pmc, pmc_note = pmc_summary(pmc_key)
+        traffic, insts = pmc.get('hbm_bytes_per_launch'), pmc.get('valu_insts_per_launch')
+        held_clock, held_frac = pmc.get('held_clock_hz'), pmc.get('issue_frac_at_held_clock')
         issue = None if insts is None else insts * VALU_ISSUE_CYCLES / (N_SIMD * kern_s * CLOCK_HZ)
         roofline = {
             'bound': 'valu-fp64-issue',

@@ -33,6 +33,30 @@ def test_synthetic_forcing_matches_the_survey_figures():
     assert not np.array_equal(other, daily)
 
 
+def test_pmc_figures_are_only_quoted_for_the_code_they_were_measured_on(tmp_path):
+    """roofline.frac needs the vector-instruction count of exactly this workload on exactly this kernel build."""
+    sys.path.insert(0, ROOT)
+    import bench
+    key = 'config3:runs_per_gpu=100000:discharge=1:math=fast'
+    table = {'workloads': {key: {'source_hash': 'abc', 'valu_insts_per_launch': 5.0e9, 'hbm_bytes_per_launch': 3.0e9,
+                                 'held_clock_hz': 2.1e9, 'issue_frac_at_held_clock': 0.8, 'source': 'somewhere.md'}}}
+    path = tmp_path / 'traffic.json'
+    path.write_text(json.dumps(table))
+    got, note = bench.pmc_summary(key, str(path), source_hash='abc')
+    assert got['valu_insts_per_launch'] == 5.0e9 and note == 'somewhere.md'
+    got, note = bench.pmc_summary(key, str(path), source_hash='other')
+    assert got == {} and 'other kernel sources' in note
+    got, note = bench.pmc_summary('config3:runs_per_gpu=20000:discharge=1:math=fast', str(path), source_hash='abc')
+    assert got == {} and 'no PMC summary for workload' in note
+    got, note = bench.pmc_summary(key, str(tmp_path / 'missing.json'))
+    assert got == {} and 'no PMC summary file' in note
+    # the committed file, whatever its freshness, has the shape bench.py reads
+    committed = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_latest.json')))
+    assert key in committed['workloads'] and len(bench.kernel_source_hash()) == 16
+    for entry in committed['workloads'].values():
+        assert 0 < entry['issue_frac_at_held_clock'] <= 1.0 and entry['valu_insts_per_launch'] > 0
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_fields():
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1',
@@ -49,7 +73,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     r = d['roofline']
     # the issue-slot fraction needs the PMC instruction count of this very workload and kernel build: absent for the
     # reduced sample count used here, and then it is null rather than a number measured on something else
-    assert r['bound'] == 'valu-fp64-issue' and r['frac'] is None and 'no PMC summary' in r['pmc_source']
+    assert r['bound'] == 'valu-fp64-issue' and r['frac'] is None and 'no PMC summary for workload' in r['pmc_source']
     assert r['hbm']['unit'] == 'GB/s' and 0 < r['hbm']['frac'] < 1 and r['algorithmic_ratio']['ratio'] > 0
     assert 'smart_fast_intervals' in r['kernel'] and r['launch_ms'] > 0
     p = d['parity']
