@@ -257,8 +257,9 @@ def test_run_lhs_terminates_like_the_reference_smoke_test(root, in_fmt, out_fmt)
 
 def test_rccl_code_path_with_a_single_rank_group():
     """A box with one GPU cannot hold a two-rank RCCL group, but a one-rank group runs the very calls the multi-GPU
-    path makes on device tensors (all_gather_into_tensor, all_reduce, barrier with device_ids): the backend-specific
-    half of smartpy_amd/distributed.py that the gloo tests on CPU cannot reach."""
+    path makes on device tensors (all_gather_into_tensor, all_reduce, broadcast, barrier with device_ids): the
+    backend-specific half of smartpy_amd/distributed.py that the gloo tests on CPU cannot reach -- including the
+    sharded launches of bench.py --config 4 (rows) and --config 5 (catchments) with their gather over RCCL."""
     import subprocess
     import sys
     code = r'''
@@ -275,6 +276,32 @@ out = sd.gather_rows(x, 3)
 assert out.is_cuda and torch.equal(out, x)
 assert sd.max_over_ranks(2.5, x.device) == 2.5 and sd.sum_over_ranks(1.5, x.device) == 1.5
 sd.barrier()
+# the sample broadcast of MonteCarlo.run() and the two sharded launches of bench.py --config 4 / 5, over RCCL
+import numpy as np
+import bench
+from smartpy_amd import engine
+from smartpy_amd.sampling import latin_hypercube
+from smartpy_amd.parameters import Parameters
+m = np.arange(30, dtype=np.float64).reshape(3, 10) / 7
+assert np.array_equal(sd.broadcast_matrix(m), m)
+f = bench.synthetic_forcing(0, True)[0][:24 * 200]
+p = latin_hypercube(500, Parameters().ranges, seed=3)
+obs = np.abs(np.random.default_rng(0).normal(2, 1, 200))
+rows = sd.ShardedEnsemble(torch.from_numpy(p).cuda(), f, bench.AREA, 3600.0, 24 * 30, 24, axis='samples', obs=obs,
+                          gw_obs=0.12667, extra=bench.EXTRA, want_discharge=False)
+got = rows.step()
+one = engine.run_ensemble(p, f, bench.AREA, 3600.0, 24 * 30, 24, obs=obs, gw_obs=0.12667, extra=bench.EXTRA)
+assert got.shape == (500, 9) and torch.equal(got[:, :8], one.objfn) and torch.equal(got[:, 8], one.gw)
+rows.verify()
+cats = sd.ShardedEnsemble(torch.from_numpy(p[:100]).cuda(), lambda c: bench.synthetic_forcing(c, True)[0][:24 * 200],
+                          np.array([1e8, 2e8, 3e8]), 3600.0, 24 * 30, 24, axis='catchments', n_catchments=3,
+                          obs=np.tile(obs, (3, 1)), gw_obs=0.12667, extra=bench.EXTRA, want_discharge=False)
+got = cats.step()
+assert got.shape == (3, 100, 9)
+for c in range(3):
+    one = engine.run_ensemble(p[:100], bench.synthetic_forcing(c, True)[0][:24 * 200], (c + 1) * 1e8, 3600.0, 24 * 30, 24,
+                              obs=obs, gw_obs=0.12667, extra=bench.EXTRA)
+    assert torch.equal(got[c, :, :8], one.objfn) and torch.equal(got[c, :, 8], one.gw)
 dist.destroy_process_group()
 print('rccl ok')
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
