@@ -2,11 +2,12 @@
 # rocprofv3 evidence for the bench command: kernel-trace stats, then PMC passes (each in its own run).
 # usage: bash tools/profile.sh <tag> [bench args...]
 TAG=${1:-r01}; shift
-ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline --no-flat}
+ARGS=${@:---steps 20 --warmup 5 --no-cpu-baseline --no-flat}     # the driver's own K / W
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 python3 -c "import bench; print(bench.kernel_source_hash())" > $OUT/source_hash.txt
+echo "$ARGS" > $OUT/args.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py $ARGS > $OUT/trace_bench.log 2>&1
 echo "trace rc=$?"
 for PASS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE"; do

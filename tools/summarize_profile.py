@@ -19,6 +19,20 @@ def is_main(name):
     return 'smart_fast_' in name or 'smart_ensemble' in name
 
 out = {'source': src}
+# bench.py's untimed warm-up launches come first: they are left out of every per-launch mean below
+n_warm = 0
+args_file = os.path.join(src, 'args.txt')
+if os.path.exists(args_file):
+    words = open(args_file).read().split()
+    out['bench_args'] = ' '.join(words)
+    if '--warmup' in words:
+        n_warm = int(words[words.index('--warmup') + 1])
+
+
+def timed(values):
+    """the per-dispatch values of the timed steps (the warm-up dispatches dropped, when there are enough left)"""
+    return values[n_warm:] if len(values) > n_warm else values
+
 lines = ['# rocprofv3 summary (%s)' % os.path.basename(src), '']
 
 # ---- kernel trace: per-kernel stats ----------------------------------------------------------------
@@ -43,11 +57,16 @@ if trace:
         rows = [r for r in csv.DictReader(f) if is_main(r['Kernel_Name'])]
     if rows:
         gmax = max(int(r['Grid_Size_X']) for r in rows)
-        full = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows if int(r['Grid_Size_X']) == gmax]
+        rows.sort(key=lambda r: int(r['Start_Timestamp']))
+        every = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows if int(r['Grid_Size_X']) == gmax]
+        full = timed(every)
         out['full_size_dispatch_ms'] = {'n': len(full), 'avg': sum(full) / len(full), 'min': min(full), 'max': max(full),
-                                        'grid_x': gmax}
-        lines += ['## full-size dispatches of the dominant kernel (grid %d threads; the bench also runs it once with N = 1)' % gmax,
-                  '', '- n = %d, avg = %.4f ms, min = %.4f ms, max = %.4f ms' % (len(full), sum(full) / len(full), min(full), max(full)), '']
+                                        'grid_x': gmax, 'warmup_dispatches_dropped': len(every) - len(full),
+                                        'warmup_ms': every[:len(every) - len(full)]}
+        lines += ['## full-size dispatches of the dominant kernel (grid %d threads; `bench.py %s`)' % (gmax, out.get('bench_args', '')),
+                  '', '- the %d timed steps: avg = %.4f ms, min = %.4f ms, max = %.4f ms' % (len(full), sum(full) / len(full), min(full), max(full)),
+                  '- the %d warm-up launches before them (clock still ramping): %s ms' % (
+                      len(every) - len(full), ', '.join('%.3f' % v for v in every[:len(every) - len(full)])), '']
         r = [r for r in rows if int(r['Grid_Size_X']) == gmax][-1]
         keep = {k: r[k] for k in r if k in ('Kernel_Name', 'VGPR_Count', 'Accum_VGPR_Count', 'SGPR_Count', 'LDS_Block_Size',
                                             'Scratch_Size', 'Workgroup_Size', 'Grid_Size', 'Workgroup_Size_X', 'Grid_Size_X')}
@@ -57,6 +76,7 @@ if trace:
 # ---- PMC passes ------------------------------------------------------------------------------------
 pmc = defaultdict(lambda: defaultdict(list))
 allrows = []
+order = {}
 for path in glob.glob(os.path.join(src, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
     with open(path) as f:
         allrows += list(csv.DictReader(f))
@@ -68,14 +88,15 @@ for row in allrows:
         continue
     if is_main(row['Kernel_Name']) and int(row['Grid_Size']) != big:
         continue
-    pmc[row['Kernel_Name'].split('(')[0]][row['Counter_Name']].append(float(row['Counter_Value']))
+    pmc[row['Kernel_Name'].split('(')[0]][row['Counter_Name']].append((int(row['Dispatch_Id']), float(row['Counter_Value'])))
 if pmc:
     lines += ['## PMC counters (one `--pmc` pass each; value = mean per dispatch)', '', '| kernel | counter | mean per dispatch | dispatches |', '|---|---|---|---|']
     out['pmc'] = {}
     for k in sorted(pmc):
         out['pmc'][k] = {}
         for c in sorted(pmc[k]):
-            v = pmc[k][c]
+            v = [x[1] for x in sorted(pmc[k][c])]
+            v = timed(v) if is_main(k) else v
             out['pmc'][k][c] = sum(v) / len(v)
             lines.append('| `%s` | %s | %.6g | %d |' % (k[:60], c, sum(v) / len(v), len(v)))
     lines.append('')
@@ -108,7 +129,8 @@ if main and 'GRBM_GUI_ACTIVE' in out['pmc'][main[0]] and 'full_size_dispatch_ms'
         with open(path) as f:
             rows = [r for r in csv.DictReader(f) if is_main(r['Kernel_Name'])]
         gmax = max(int(r['Grid_Size_X']) for r in rows)
-        durs += [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e9 for r in rows if int(r['Grid_Size_X']) == gmax]
+        rows.sort(key=lambda r: int(r['Start_Timestamp']))
+        durs += timed([(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e9 for r in rows if int(r['Grid_Size_X']) == gmax])
     if durs:
         out['held_clock_hz'] = out['pmc'][main[0]]['GRBM_GUI_ACTIVE'] / 8 / (sum(durs) / len(durs))
         c0 = out['pmc'][main[0]]
