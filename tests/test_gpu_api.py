@@ -255,6 +255,59 @@ def test_run_lhs_terminates_like_the_reference_smoke_test(root, in_fmt, out_fmt)
     assert lhs.obj_fns.shape == (5, 8) and np.all(np.isfinite(lhs.obj_fns))
 
 
+def test_netcdf_in_and_out_through_the_dataset_double(root, monkeypatch):
+    """The fourth variant of the reference's smoke test (NetCDF in, NetCDF out) plus a second stage reading the .nc
+    database, with tests/fake_netcdf.FakeDataset standing in for the absent netCDF4 package: the .nc inputs are made
+    from the example's CSV files, and every number must equal the CSV-in / CSV-out run of the same sample."""
+    import csv
+    from fake_netcdf import FakeDataset
+    import smartpy_amd.inout as inout
+    import smartpy_amd.montecarlo.database as database
+    from smartpy_amd.montecarlo import LHS, GLUE
+    monkeypatch.setattr(inout, 'Dataset', FakeDataset)
+    monkeypatch.setattr(database, 'Dataset', FakeDataset)
+    folder = os.path.join(root, 'in', 'Catchment')
+    for kind in ('rain', 'peva', 'flow'):
+        with open(os.path.join(folder, 'Catchment.' + kind)) as f:
+            rows = list(csv.DictReader(f))
+        stamps = [(datetime.strptime(r['DateTime'], '%Y-%m-%d %H:%M:%S') - datetime(1970, 1, 1)).total_seconds()
+                  for r in rows]
+        values = [float(r[kind]) if r[kind] not in ('', '-99') else np.nan for r in rows]
+        with FakeDataset(os.path.join(folder, 'Catchment.%s.nc' % kind), 'w') as nc:
+            nc.createDimension('DateTime', len(rows))
+            nc.createVariable('DateTime', np.float64, ('DateTime',))
+            nc.createVariable(kind, np.float64, ('DateTime',))
+            nc.variables['DateTime'][0:len(rows)] = stamps
+            nc.variables[kind][0:len(rows)] = values
+    _settings(root, 'Catchment.short.sttngs', '01/01/2007', '31/12/2007', 100)
+    np.random.seed(3)
+    a = LHS('Catchment', root, 'csv', 'csv', 40, save_sim=True, settings_filename='Catchment.short.sttngs')
+    a.model.extra = EXTRA
+    a.run()
+    np.random.seed(3)
+    b = LHS('Catchment', root, 'netcdf', 'netcdf', 40, save_sim=True, settings_filename='Catchment.short.sttngs')
+    b.model.extra = EXTRA
+    assert np.array_equal(b.model.nd_rain, a.model.nd_rain) and np.array_equal(b.model.nd_peva, a.model.nd_peva)
+    assert np.array_equal(b.model.nd_flow, a.model.nd_flow, equal_nan=True)
+    b.run(compression=True)
+    assert np.array_equal(b.obj_fns, a.obj_fns) and b.db_file.endswith('Catchment.SMART.lhs.nc')
+    nc = FakeDataset(b.db_file, 'r')
+    assert nc.variables['Parameters'].filters == {'zlib': True, 'complevel': 6}
+    assert np.array_equal(nc.variables['ObjFunctions'][:, :], a.obj_fns.astype(np.float32))
+    assert nc.variables['Simulations'][:, :].shape == (40, 365)
+    assert os.path.exists(os.path.join(root, 'out', 'Catchment', 'Catchment.obs.flow.nc'))
+    glue = GLUE('Catchment', root, 'netcdf', 'netcdf', conditioning={'KGE': ('min', (0.0,))},
+                settings_filename='Catchment.short.sttngs')
+    keep = a.obj_fns[:, 1].astype(np.float32) >= 0.0
+    assert 0 < keep.sum() and np.array_equal(glue.behavioural_params, a.lhs_params[keep].astype(np.float32))
+    # the per-sample protocol writes NetCDF rows at the index of their parameter set (montecarlo.py:215-224)
+    b._init_db()
+    like = [0.5] * 8
+    b.save(like, b.lhs_params[7], [np.arange(365.0)])
+    b.database.close()
+    assert np.array_equal(FakeDataset(b.db_file, 'r').variables['ObjFunctions'][7], np.float32(like))
+
+
 def test_rccl_code_path_with_a_single_rank_group():
     """A box with one GPU cannot hold a two-rank RCCL group, but a one-rank group runs the very calls the multi-GPU
     path makes on device tensors (all_gather_into_tensor, all_reduce, broadcast, barrier with device_ids): the

@@ -424,3 +424,122 @@ def test_package_surface():
     with pytest.raises(Exception, match='warm-up duration'):
         structure.run(1.0, timedelta(hours=1), [0.0] * 24, [0.0] * 24, [1.0] * 10, None, list(range(25)),
                       list(range(2)), 'summary', warm_up=2)
+
+
+# ---- the NetCDF flavours, driven through a test double of netCDF4.Dataset (the package is absent from this image) ----
+@pytest.fixture()
+def fake_netcdf(monkeypatch):
+    from fake_netcdf import FakeDataset
+    import smartpy_amd.inout as inout
+    import smartpy_amd.montecarlo.database as database
+    FakeDataset.opened = []
+    monkeypatch.setattr(inout, 'Dataset', FakeDataset)
+    monkeypatch.setattr(database, 'Dataset', FakeDataset)
+    return FakeDataset
+
+
+@pytest.mark.parametrize('save_sim', [False, True])
+def test_sampling_database_netcdf_schema_and_round_trip(tmp_path, fake_netcdf, save_sim):
+    """montecarlo.py:91-118 (schema), :211-224 (rows), :157-169 (zlib rewrite), :236-243 (reading back): dimension
+    and variable names, dtypes, units strings, DateTime in seconds since the epoch, float32 storage."""
+    from smartpy_amd.montecarlo.database import database_for, SamplingNetcdf
+    from smartpy_amd.version import __version__
+    g4 = load_golden('g4_example_lhs.npz')
+    names = ['NSE', 'KGE', 'KGEc', 'KGEa', 'KGEb', 'PBias', 'RMSE', 'GW']
+    pnames = ['T', 'C', 'H', 'D', 'S', 'Z', 'SK', 'FK', 'GK', 'RK']
+    stamps = [START + timedelta(days=k) for k in range(3)] if save_sim else None
+    sims = g4['discharge'][:, :3]
+    path = str(tmp_path / 'C.SMART.lhs.nc')
+    db = database_for('netcdf', path, names, pnames)
+    assert isinstance(db, SamplingNetcdf)
+    db.create(10, stamps, parallel=True)
+    assert fake_netcdf.opened[-1] == (path, 'w', True)                 # montecarlo.py:93 opens with parallel=self.p
+    db.write_table(g4['objfns'], g4['params'], sims)
+    db.close()
+    nc = fake_netcdf(path, 'r')
+    assert nc.description == "Monte Carlo Simulation outputs with SMARTpy v{}.".format(__version__)
+    want_dims = {'NbSamples': 10, 'NbParameters': 10, 'NbObjFunctions': 8}
+    if save_sim:
+        want_dims['DateTime'] = 3
+    assert {k: len(v) for k, v in nc.dimensions.items()} == want_dims
+    v = nc.variables
+    assert sorted(v) == sorted(['Parameters', 'ObjFunctions'] + (['DateTime', 'Simulations'] if save_sim else []))
+    assert v['Parameters'].datatype == np.float32 and v['Parameters'].dimensions == ('NbSamples', 'NbParameters')
+    assert v['Parameters'].units == 'T, C, H, D, S, Z, SK, FK, GK, RK'
+    assert v['ObjFunctions'].datatype == np.float32 and v['ObjFunctions'].units == ', '.join(names)
+    assert np.array_equal(v['Parameters'][:, :], g4['params'].astype(np.float32))
+    assert np.array_equal(v['ObjFunctions'][:, :], g4['objfns'].astype(np.float32), equal_nan=True)
+    if save_sim:
+        assert v['DateTime'].datatype == np.float64 and v['DateTime'].units == "seconds since 1970-01-01 00:00:00.0"
+        assert v['DateTime'][0] == (START - datetime(1970, 1, 1)).total_seconds() and v['DateTime'][2] - v['DateTime'][0] == 172800
+        assert v['Simulations'].dimensions == ('NbSamples', 'DateTime') and v['Simulations'].units == "Discharge in m3/s"
+        assert np.array_equal(v['Simulations'][:, :], sims.astype(np.float32))
+    params, fns = db.read()
+    assert params.dtype == np.float32 and np.array_equal(params, g4['params'].astype(np.float32))
+    assert np.array_equal(fns, g4['objfns'].astype(np.float32), equal_nan=True)
+    # the per-sample writer of the reference protocol lands every row at its own index, in any order
+    one = database_for('netcdf', str(tmp_path / 'D.SMART.lhs.nc'), names, pnames).create(10, stamps)
+    for r in (3, 0, 9, 1, 2, 8, 4, 7, 5, 6):
+        one.write_sample(r, list(g4['objfns'][r]), g4['params'][r], sims[r])
+    one.close()
+    again = fake_netcdf(one.path, 'r')
+    for name in v:
+        assert np.array_equal(again.variables[name][:], v[name][:], equal_nan=True)
+    # compression: None / False leave the file alone; True = zlib level 6; a number = that level (montecarlo.py:158-169)
+    db.compress(None)
+    db.compress(False)
+    assert not fake_netcdf(path, 'r').variables['Parameters'].filters['zlib']
+    for level, want in ((True, 6), (3, 3)):
+        db.compress(level)
+        packed = fake_netcdf(path, 'r')
+        assert not os.path.exists(path.replace('.nc', '_.nc')) and packed.description == nc.description
+        for name in v:
+            assert packed.variables[name].filters == {'zlib': True, 'complevel': want}
+            assert packed.variables[name].units == v[name].units
+            assert np.array_equal(packed.variables[name][:], v[name][:], equal_nan=True)
+
+
+def test_netcdf_flow_files_and_forcing_readers(tmp_path, fake_netcdf):
+    """inout.py:299-310 (flow writer), :212-231 / :256-274 (readers) through the same double: what is written as a
+    flow file reads back as an observation series with its NaN entries dropped, and a regular series reads back with
+    its interval checked."""
+    import smartpy_amd.inout as io
+    stamps = [START + timedelta(days=k) for k in range(6)]
+    flow = np.array([1.5, np.nan, 2.25, 3.0, np.nan, 0.125])
+    base = str(tmp_path / 'C.obs.flow')
+    io.write_flow_file_from_nds(stamps, flow, base, out_file_format='netcdf', parallel=False)
+    nc = fake_netcdf(base + '.nc', 'r')
+    assert nc.description.startswith('Discharge file generated with SMARTpy v')
+    assert nc.variables['flow'].datatype == np.float32 and nc.variables['DateTime'].datatype == np.float64
+    assert nc.variables['DateTime'].units == 'seconds since 1970-01-01 00:00:00.0'
+    data = io.read_netcdf_time_series_with_missing_check(base + '.nc', 'DateTime', 'flow')
+    assert list(data) == [stamps[0], stamps[2], stamps[3], stamps[5]] and list(data.values()) == [1.5, 2.25, 3.0, 0.125]
+    got_stamps, got_values = io._read_flow_arrays(base + '.nc', 'netcdf')
+    assert got_stamps == list(data) and np.array_equal(got_values, [1.5, 2.25, 3.0, 0.125])
+    # a regular rain series
+    rain = np.array([0.0, 2.5, 1.25, 0.0, 7.0, 0.5])
+    with fake_netcdf(str(tmp_path / 'C.rain.nc'), 'w') as f:
+        f.createDimension('DateTime', 6)
+        f.createVariable('DateTime', np.float64, ('DateTime',))
+        f.createVariable('rain', np.float32, ('DateTime',))
+        f.variables['DateTime'][0:6] = [(s - datetime(1970, 1, 1)).total_seconds() for s in stamps]
+        f.variables['rain'][0:6] = rain
+    data, first, last, delta = io.read_netcdf_time_series_with_delta_check(str(tmp_path / 'C.rain.nc'), 'DateTime', 'rain')
+    assert (first, last, delta) == (stamps[0], stamps[-1], timedelta(days=1)) and [data[s] for s in stamps] == list(rain)
+    with pytest.raises(Exception, match='Variable DateTime or peva does not exist'):
+        io.read_netcdf_time_series_with_delta_check(str(tmp_path / 'C.rain.nc'), 'DateTime', 'peva')
+    with pytest.raises(Exception, match='could not be found'):
+        io.read_netcdf_time_series_with_missing_check(str(tmp_path / 'nothing.nc'), 'DateTime', 'flow')
+
+
+def test_without_netcdf4_the_reference_message_is_raised(tmp_path, monkeypatch):
+    import smartpy_amd.inout as io
+    import smartpy_amd.montecarlo.database as database
+    monkeypatch.setattr(io, 'Dataset', None)
+    monkeypatch.setattr(database, 'Dataset', None)
+    with pytest.raises(Exception, match="requires the package 'netCDF4'"):
+        database.database_for('netcdf', str(tmp_path / 'x.nc'), ['NSE'], ['T']).create(1)
+    with pytest.raises(Exception, match="requires the package 'netCDF4'"):
+        database.database_for('netcdf', str(tmp_path / 'x.nc'), ['NSE'], ['T']).read()
+    with pytest.raises(Exception, match="requires the package 'netCDF4'"):
+        io.write_flow_file_from_nds([START], [1.0], str(tmp_path / 'y'), out_file_format='netcdf')
