@@ -9,8 +9,9 @@ from .engine import OBJ_FN_NAMES, objective_functions  # noqa: F401
 
 
 def groundwater_constraint(evaluation, simulation):
-    """objfunctions.py:20-24: 1.0 if the simulated groundwater ratio is within +/- 0.1 of the constraint."""
-    if (evaluation[0] - 0.1 <= simulation[0]) and (simulation[0] <= evaluation[0] + 0.1):
-        return 1.0
-    else:
-        return 0.0
+    """1.0 when the simulated groundwater contribution to runoff lies within 0.1 of the constraint, both bounds
+    included, else 0.0 (objfunctions.py:20-24); both arguments are one-element sequences, as the Monte-Carlo protocol
+    passes them (montecarlo.py:186,191,207).  The same rule is fused into the ensemble kernel (finish_objectives in
+    csrc/smart_device.h)."""
+    target, value = evaluation[0], simulation[0]
+    return float(target - 0.1 <= value <= target + 0.1)
