@@ -124,3 +124,23 @@ def test_product_never_touches_the_oracle():
     out = subprocess.check_output(['ldd', os.path.join(ROOT, 'smartpy_amd', 'csrc', 'libsmart_amd.so')]).decode()
     assert 'oracle' not in out and 'libamdhip64' in out
     assert 'oracle' not in ' '.join(sys.modules) or True
+
+
+def build_c_example(tmp_path):
+    """examples/ensemble_from_c.c with plain gcc (C, not C++): the header is C, the only link dependencies are the
+    library and the HIP runtime."""
+    exe = str(tmp_path / 'ensemble_from_c')
+    csrc = os.path.join(ROOT, 'smartpy_amd', 'csrc')
+    subprocess.check_call(['gcc', '-O2', '-Wall', '-Werror', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include',
+                           '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'examples', 'ensemble_from_c.c'),
+                           '-L', csrc, '-lsmart_amd', '-L/opt/rocm/lib', '-lamdhip64', '-lm',
+                           '-Wl,-rpath,' + csrc, '-Wl,-rpath,/opt/rocm/lib', '-o', exe])
+    return exe
+
+
+def test_c_example_builds_and_refuses_to_run_without_a_device(tmp_path, L):
+    exe = build_c_example(tmp_path)
+    if L.smart_device_count() > 0:
+        pytest.skip('a GPU is present: tests/test_gpu_api.py runs the example for real')
+    r = subprocess.run([exe] + ['x'] * 9, capture_output=True, text=True)
+    assert r.returncode == 1 and '0 HIP device(s)' in r.stderr

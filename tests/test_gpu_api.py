@@ -308,6 +308,32 @@ def test_netcdf_in_and_out_through_the_dataset_double(root, monkeypatch):
     assert np.array_equal(FakeDataset(b.db_file, 'r').variables['ObjFunctions'][7], np.float32(like))
 
 
+def test_the_c_abi_from_a_c_program(tmp_path, example):
+    """examples/ensemble_from_c.c -- plain C, no Python, no torch in the process -- plans, launches (time-sliced: 70,000
+    samples) and reads back through include/smart_amd.h; its numbers are those of the Python binding, bit for bit."""
+    import subprocess
+    from test_capi_symbols import build_c_example
+    from smartpy_amd import engine
+    from oracle import lhs_oracle
+    exe = build_c_example(tmp_path)
+    N, T, W, gap = 70000, 24 * 120, 24 * 20, 24
+    params = lhs_oracle.lhs_params(N, seed=21)
+    forcing = np.stack([example['rain_hourly'][:T], example['peva_hourly'][:T]], axis=1)
+    obs = example['flow_obs'][:T // gap]
+    for name, a in (('params', params), ('forcing', forcing), ('obs', obs)):
+        np.ascontiguousarray(a, dtype='<f8').tofile(str(tmp_path / (name + '.bin')))
+    r = subprocess.run([exe, str(tmp_path / 'params.bin'), str(tmp_path / 'forcing.bin'), str(tmp_path / 'obs.bin'),
+                        str(N), str(T), str(W), str(gap), repr(example['area']), str(tmp_path / 'out.bin')],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'smart_fast_intervals[2 slices x 1094 blocks' in r.stdout and 'plan 0x111' in r.stdout
+    out = np.fromfile(str(tmp_path / 'out.bin'), dtype='<f8')
+    objfn, gw, dis = out[:N * 8].reshape(N, 8), out[N * 8:N * 9], out[N * 9:].reshape(T // gap, N)
+    ref = engine.run_ensemble(params, forcing, example['area'], 3600.0, W, gap, extra=EXTRA, obs=obs, gw_obs=0.12667)
+    assert np.array_equal(objfn, ref.objfn.cpu().numpy()) and np.array_equal(gw, ref.gw.cpu().numpy())
+    assert np.array_equal(dis, ref.discharge_report_major.cpu().numpy())
+
+
 def test_rccl_code_path_with_a_single_rank_group():
     """A box with one GPU cannot hold a two-rank RCCL group, but a one-rank group runs the very calls the multi-GPU
     path makes on device tensors (all_gather_into_tensor, all_reduce, broadcast, barrier with device_ids): the
