@@ -894,3 +894,52 @@ def test_several_kernels_of_one_call_capture_into_a_hip_graph(eng):
         torch.cuda.synchronize()
         out = p._result()
         assert torch.equal(out.discharge, ref_dis) and torch.equal(out.gw, ref_gw)
+
+
+def test_concurrent_launches_from_two_threads_on_two_streams(eng):
+    """include/smart_amd.h promises that calls on different streams may run concurrently.  Two host threads, each with
+    its own stream, workspace and outputs, launch at the same time -- a daily ensemble (three kernels forked onto the
+    device's auxiliary streams, which the two callers share) and an hourly one (time-sliced) -- twenty times over;
+    every result equals the one the call gives on its own."""
+    import threading
+    import torch
+    import bench
+    dev = torch.device('cuda:0')
+    daily = torch.as_tensor(bench.synthetic_forcing(0, hourly=False)[0], device=dev)
+    hourly = torch.as_tensor(bench.synthetic_forcing(1, hourly=True)[0][:24 * 400], device=dev)
+    p_daily = torch.as_tensor(lhs_oracle.lhs_params(5000, seed=23), device=dev)
+    p_hourly = torch.as_tensor(lhs_oracle.lhs_params(70000, seed=24), device=dev)
+    jobs = [eng.prepare_ensemble(p_daily, daily, bench.AREA, 86400.0, 365, 1, extra=bench.EXTRA),
+            eng.prepare_ensemble(p_hourly, hourly, bench.AREA, 3600.0, 24 * 40, 24, extra=bench.EXTRA,
+                                 want_discharge=False)]
+    assert jobs[0].describe().count('smart_fast_') == 3 and 'slices' in jobs[1].describe()
+    want = []
+    for j in jobs:
+        r = j.launch()
+        torch.cuda.synchronize()
+        want.append((r.gw.clone(), None if r.discharge is None else r.discharge.clone()))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    start = threading.Barrier(2)
+    failures = []
+
+    def worker(k):
+        try:
+            with torch.cuda.stream(streams[k]):
+                for rep in range(20):
+                    jobs[k]._gw.fill_(float('nan'))
+                    start.wait()
+                    r = jobs[k].launch()
+                    assert jobs[k].status() == 0
+                    assert torch.equal(r.gw, want[k][0])
+                    if want[k][1] is not None:
+                        assert torch.equal(r.discharge, want[k][1])
+        except Exception as e:                  # noqa: BLE001 -- reported by the main thread
+            failures.append('%d: %r' % (k, e))
+            start.abort()
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not failures, failures
