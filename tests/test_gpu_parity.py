@@ -675,12 +675,15 @@ def test_early_exits_do_not_change_results(eng, example, monkeypatch):
 
 
 def test_randomized_interval_engine(eng, monkeypatch):
-    """30 seeded random set-ups with forcing that is constant over each report interval (what the interval engine
-    takes): storms, droughts, exact zeros, gaps 2..48, warm-up or not, forced time slices and exits at random --
-    fast mode within tolerance of the reference-exact oracle on well-conditioned rows."""
+    """45 seeded random set-ups: storms, droughts, exact zeros, gaps 2..48, warm-up or not, forced time slices and
+    exits at random, the final row asked for or not.  Two thirds have forcing that is constant over each report
+    interval (what the interval engine takes); one third spread each interval's totals unevenly over its steps, with
+    calm steps (no rain, no evaporation) in between -- the step loop with deferred evaporation.  Fast mode within
+    tolerance of the reference-exact oracle on well-conditioned rows: discharge, groundwater ratio, objective
+    functions, and all 19 values of the final row."""
     rng = np.random.default_rng(20261003)
     worst = 0.0
-    for case in range(30):
+    for case in range(45):
         dt = float(rng.choice([900.0, 3600.0, 10800.0]))
         gap = int(rng.choice([2, 3, 8, 24, 48]))
         n_rep = int(rng.integers(64, 200))
@@ -690,8 +693,17 @@ def test_randomized_interval_engine(eng, monkeypatch):
         rain_iv = rng.gamma(0.4, 8.0, n_rep) * (rng.random(n_rep) < rng.uniform(0.2, 0.9)) * rng.choice([1.0, 1.0, 15.0])
         peva_iv = np.maximum(0.0, rng.normal(1.5, 1.0, n_rep))
         peva_iv[rng.random(n_rep) < 0.08] = 0.0
-        rain = np.repeat(rain_iv * scale / gap, gap)
-        peva = np.repeat(peva_iv * scale / gap, gap)
+        varying = case >= 30
+        if varying:     # the interval's total in a few of its steps, the others calm or evaporation only
+            w_r = rng.random((n_rep, gap)) * (rng.random((n_rep, gap)) < 0.3)
+            w_r[w_r.sum(1) == 0, 0] = 1.0
+            w_e = rng.random((n_rep, gap)) * (rng.random((n_rep, gap)) < 0.5)
+            w_e[w_e.sum(1) == 0, -1] = 1.0
+            rain = (rain_iv[:, None] * scale * w_r / w_r.sum(1, keepdims=True)).ravel()
+            peva = (peva_iv[:, None] * scale * w_e / w_e.sum(1, keepdims=True)).ravel()
+        else:
+            rain = np.repeat(rain_iv * scale / gap, gap)
+            peva = np.repeat(peva_iv * scale / gap, gap)
         area = float(np.exp(rng.uniform(np.log(5e6), np.log(5e9))))
         n = int(rng.integers(1, 300))
         params = lhs_oracle.lhs_params(max(n, 2), seed=int(rng.integers(1 << 30)))[:n]
@@ -700,15 +712,20 @@ def test_randomized_interval_engine(eng, monkeypatch):
         obs = rng.random(n_rep) * 3
         obs[rng.random(n_rep) < 0.15] = np.nan
         slices, exits = rng.choice(['', '0', '3', '9']), rng.choice(['', '0', '1'])
+        want_final = bool(rng.random() < 0.5)
         for name, val in (('SMART_TIME_SLICES', slices), ('SMART_EXITS', exits)):
             if val:
                 monkeypatch.setenv(name, str(val))
             else:
                 monkeypatch.delenv(name, raising=False)
-        fast = eng.run_ensemble(params, forcing_of(rain, peva), area, dt, W, gap, extra=extra, obs=obs, gw_obs=0.2)
-        d1, g1, _ = so.run_batch(area, dt, T, W, rain, peva, params, extra, so.REPORT_SUMMARY, gap)
-        tag = 'case %d: dt=%g gap=%d T=%d W=%d n=%d extra=%s slices=%r exits=%r' % (
-            case, dt, gap, T, W, n, extra is not None, slices, exits)
+        fast = eng.run_ensemble(params, forcing_of(rain, peva), area, dt, W, gap, extra=extra, obs=obs, gw_obs=0.2,
+                                want_final=want_final)
+        kernels = fast._prepared.describe()
+        if 'smart_fast_intervals' in kernels or 'smart_fast_steps' in kernels:       # some rows are regular ones
+            assert ('smart_fast_steps' in kernels) == varying and ('_states' in kernels) == want_final, kernels
+        d1, g1, f1 = so.run_batch(area, dt, T, W, rain, peva, params, extra, so.REPORT_SUMMARY, gap, want_final=True)
+        tag = 'case %d: dt=%g gap=%d T=%d W=%d n=%d extra=%s slices=%r exits=%r final=%r varying=%r' % (
+            case, dt, gap, T, W, n, extra is not None, slices, exits, want_final, varying)
         good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
         if good.any():
             e = rel(fast.discharge.cpu().numpy()[good], d1[good], floor=1e-300)
@@ -720,6 +737,8 @@ def test_randomized_interval_engine(eng, monkeypatch):
             got = fast.objfn.cpu().numpy()[good]
             fin = np.isfinite(want[:, :7]).all(axis=1)
             assert rel(got[fin, :7], want[fin, :7], floor=1e-12) <= 1e-7, tag
+            if want_final:
+                assert rel(fast.final_vars.cpu().numpy()[good], f1[good], floor=1e-250) <= 1e-8, tag
     assert worst < 1e-10
 
 
