@@ -1,7 +1,7 @@
 """The flat-forcing leg of bench.py on its own (for rocprofv3 --pmc runs of the step-loop kernel)."""
 import sys
 sys.path.insert(0, '.')
-import numpy as np
+
 import torch
 import bench
 from smartpy_amd import engine

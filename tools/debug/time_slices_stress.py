@@ -6,7 +6,7 @@ whatever order and on whatever CUs the competing work leaves free -- the situati
 
     python tools/debug/time_slices_stress.py <n_samples> <launches> [busy]
 """
-import os, sys, time
+import sys, time
 sys.path.insert(0, '.')
 import torch
 import bench
