@@ -392,7 +392,9 @@ static int plan_time_slices(const SmartEnsemble *e, int n_simd, int *per_simd, d
         return 1;
     if (forced > 1)
         return forced < n_all / 4 ? forced : (int)(n_all / 4);
-    if (blocks <= n_simd)
+    // nothing to even out at or below one block per SIMD; and beyond ~48 per SIMD (3e6 samples) the ragged end of an
+    // unsliced launch is under 2 % of it while the hand-over buffer (11 KB per block) starts to count
+    if (blocks <= n_simd || blocks > 48L * n_simd)
         return 1;
     return (int)(n_all / 64 < 16 ? n_all / 64 : 16);
 }
