@@ -100,19 +100,29 @@ def variant_classes(params, delta_sec):
     return cls
 
 
-def _variant_grouping(params, delta_sec):
+def _variant_grouping(params, delta_sec, sort_rows=False):
     """A wavefront runs ONE variant for its 64 lanes, the most general one any of its rows needs.  To keep a row's
     arithmetic (and cost) independent of its neighbours, rows are grouped by variant before the launch, each group
     padded to whole wavefronts with copies of its last row.  Returns (gather [N_run], inverse [N]) or None when the
-    matrix needs no regrouping (one variant only -- always the case for hourly steps with the default ranges)."""
+    matrix needs no reordering (one variant only -- always the case for hourly steps with the default ranges).
+
+    sort_rows: within a variant, order the rows by T (the rainfall correction factor).  Wet or dry is decided by the
+    sign of rain * T - peva, so a wavefront whose 64 rows have nearly the same T takes one side of that branch
+    together on (almost) every step instead of executing both: -2 % launch time (tools/debug/sort_rows.py).  Only
+    asked for when no discharge matrix is stored -- its columns would have to be permuted back, which costs more
+    than the launch gains; the per-sample results are permuted back on the way out either way."""
     cls = variant_classes(params, delta_sec)
-    if int(cls.min()) == int(cls.max()):
+    mixed = int(cls.min()) != int(cls.max())
+    if not mixed and not sort_rows:
         return None
     pieces = []
     for c in range(4):
-        idx = torch.nonzero(cls == c)[:, 0]
+        idx = torch.nonzero(cls == c)[:, 0] if mixed else (torch.arange(params.shape[0], device=params.device)
+                                                            if c == int(cls[0]) else cls[:0])
         if idx.numel():
-            pad = (-idx.numel()) % 64
+            if sort_rows:
+                idx = idx[torch.argsort(params[idx, 0], stable=True)]
+            pad = (-idx.numel()) % 64 if mixed else 0
             pieces.append(torch.cat([idx, idx[-1:].expand(pad)]) if pad else idx)
     gather = torch.cat(pieces)
     inverse = torch.empty(params.shape[0], dtype=torch.int64, device=params.device)
@@ -282,7 +292,8 @@ def prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, re
     # what is already known about these very tensors (only when the caller handed over device tensors: anything
     # converted above is a fresh object, and a fresh object is classified afresh)
     memo_on = [t for t in (params_in, forcing_in) if isinstance(t, torch.Tensor) and t.is_cuda]
-    memo_key = (float(delta_sec), int(report_gap), rtype, C, N, T, bool(group_variants))
+    sort_rows = not want_discharge and discharge_out is None
+    memo_key = (float(delta_sec), int(report_gap), rtype, C, N, T, bool(group_variants), sort_rows)
     memo = _Memo.lookup('fast', memo_on, memo_key) if len(memo_on) == 2 and mmode == MATH_FAST else None
 
     # rows grouped by arithmetic variant (fast mode, one shared [N, 10] matrix spanning more than one wavefront)
@@ -290,7 +301,7 @@ def prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, re
     p.device, p.n_samples, p._squeeze = device, N, squeeze
     p._grouping, p._caller_out = None, None
     if group_variants and mmode == MATH_FAST and pstride == 0 and N > 64:
-        p._grouping = memo[0][0] if memo else _variant_grouping(params, float(delta_sec))
+        p._grouping = memo[0][0] if memo else _variant_grouping(params, float(delta_sec), sort_rows)
         if p._grouping is not None:
             gather = p._grouping[0]
             params = params[gather].contiguous()
