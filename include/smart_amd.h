@@ -74,6 +74,9 @@ extern "C" {
 #define SMART_PLAN_CLASS_ILLCOND 0x08    /* some delta_sec / (k*3600) > 2: run in the literal arithmetic           */
 #define SMART_PLAN_FORCING_PIECEWISE 0x10 /* a catchment whose forcing is constant within every report interval    */
 #define SMART_PLAN_FORCING_VARYING 0x20   /* a catchment whose forcing is not                                      */
+#define SMART_PLAN_ROWS_ORDERED 0x40       /* set by the caller (not by smart_plan_ensemble): neighbouring rows behave    */
+                                           /* alike -- ordered by T, then by S*Z, as smartpy_amd/engine.py does when no   */
+                                           /* discharge matrix is stored.  Wave-uniform early exits then pay off sooner.  */
 #define SMART_PLAN_VALID 0x100
 
 /* status bits of a finished launch (smart_launch_status) */

@@ -509,8 +509,11 @@ static int decide(const SmartEnsemble *e, const DeviceCtx *d, const Workspace &w
     // early exits in the interval engine pay off once a SIMD holds three waves to issue from (FastModel::kExits;
     // measured with the per-variant kernels, tools/ab_exits.sh: off wins by 5 % at 1.53 blocks per SIMD and by 4 % at
     // 1.9, on wins by 6 % at 2.4 and by 7 % at 3.1 and above)
+    // With rows ordered so that a wavefront's 64 samples behave alike (SMART_PLAN_ROWS_ORDERED) the exits trigger far
+    // more often: on from 1.7 blocks per SIMD (tools/debug/sort_rows.py: at 1.9, 12.8 ms with exits against 13.1
+    // without; at 1.53, 11.15 against 10.95).
     const char *env = getenv("SMART_EXITS");
-    x.exits = env ? atoi(env) != 0 : x.load > 2.0;
+    x.exits = env ? atoi(env) != 0 : x.load > ((e->plan & SMART_PLAN_ROWS_ORDERED) ? 1.7 : 2.0);
     x.class_mask = plan & 0xf;
     if (plan & SMART_PLAN_CLASS_REGULAR) {
         if (x.intervals) {

@@ -53,6 +53,9 @@
 #ifndef SMART_FAST_LEAK_BALANCE
 #define SMART_FAST_LEAK_BALANCE 1
 #endif
+#ifndef SMART_FILL_EXITS
+#define SMART_FILL_EXITS 2 // exits after the first and after the second layer of the filling cascade (kExits kernels)
+#endif
 #ifndef SMART_WET_UNROLL
 #define SMART_WET_UNROLL 1
 #endif
@@ -364,10 +367,16 @@ struct FastModel {
         fill3(l0, rem, z);
         if (!kExits || __builtin_amdgcn_ballot_w64(rem > 0.0) != 0) {
             fill3(l1, rem, z);
-            fill3(l2, rem, z);
-            fill3(l3, rem, z);
-            fill3(l4, rem, z);
-            fill3(l5, rem, z);
+            if (!kExits || SMART_FILL_EXITS < 2 || __builtin_amdgcn_ballot_w64(rem > 0.0) != 0) {
+                fill3(l2, rem, z);
+                if (!kExits || SMART_FILL_EXITS < 3 || __builtin_amdgcn_ballot_w64(rem > 0.0) != 0) {
+                    fill3(l3, rem, z);
+                    if (!kExits || SMART_FILL_EXITS < 4 || __builtin_amdgcn_ballot_w64(rem > 0.0) != 0) {
+                        fill3(l4, rem, z);
+                        fill3(l5, rem, z);
+                    }
+                }
+            }
         }
         const double p2 = s1 * s1, p3 = p2 * s1, p4 = p2 * p2, p5 = p4 * s1, p6 = p3 * p3;
         l0 = fma(-l0, s1, l0);
