@@ -24,10 +24,15 @@ def binned(p, bins, second):
 for n in [int(a) for a in sys.argv[1:]] or [100000, 125000, 1000000]:
     p = torch.as_tensor(latin_hypercube(n, Parameters().ranges, seed=2718), device=dev)
     sz = p[:, 4] * p[:, 5]
-    keys = {'as drawn': None, 'by T': p[:, 0], 'T in 64 bins, then S*Z': binned(p, 64, sz),
-            'T in 16 bins, then S*Z': binned(p, 16, sz), 'T in 256 bins, then S*Z': binned(p, 256, sz),
-            'by S*Z': sz, 'T in 64 bins, then S*Z*(1-H)': binned(p, 64, sz * (1 - p[:, 2])),
-            'T in 64 bins, then S*Z/(1-H)': binned(p, 64, sz / (1 - p[:, 2]))}
+    span = lambda v: (v - v.min()) / (v.max() - v.min())        # noqa: E731
+    keys = {'as drawn': None, 'T in 64 bins, then S*Z': binned(p, 64, sz), 'T in 32 bins, then S*Z': binned(p, 32, sz),
+            'S*Z in 64 bins, then T': torch.clamp((span(sz) * 64).floor(), max=63) * 2.0 + span(p[:, 0]),
+            'S*Z in 256 bins, then T': torch.clamp((span(sz) * 256).floor(), max=255) * 2.0 + span(p[:, 0]),
+            'T in 64 bins, then S*Z*(1+C)': binned(p, 64, sz * (1 + p[:, 1])),
+            'T in 64 bins, then S*sqrt(Z)': binned(p, 64, p[:, 4] * p[:, 5].sqrt()),
+            'T in 64 bins, then S*Z^1.5': binned(p, 64, p[:, 4] * p[:, 5] ** 1.5),
+            'T 16 x S*Z 16 bins, then H': (torch.clamp((span(p[:, 0]) * 16).floor(), max=15) * 64.0
+                                           + torch.clamp((span(sz) * 16).floor(), max=15) * 2.0 + span(p[:, 2]))}
     for rep in range(2):
         for name, key in keys.items():
             q = p if key is None else p[torch.argsort(key)].contiguous()
