@@ -962,3 +962,29 @@ def test_concurrent_launches_from_two_threads_on_two_streams(eng):
     for t in threads:
         t.join(timeout=300)
     assert not failures, failures
+
+
+def test_row_ordering_is_invisible_in_the_results(eng):
+    """Without a stored discharge matrix the engine orders the rows (by arithmetic class, then T bins, then S * Z) and
+    permutes the per-sample results back.  Same bits as the run with the matrix stored, which keeps the caller's
+    order -- daily steps (three classes, each padded to whole wavefronts) and hourly ones (one class), objective
+    functions, groundwater ratios and final rows, from device tensors (memoised ordering) and from numpy."""
+    import torch
+    import bench
+    for hourly, n, dt, gap, warm in ((False, 5000, 86400.0, 1, 365), (True, 3001, 3600.0, 24, 24 * 30)):
+        f = bench.synthetic_forcing(3, hourly=hourly)[0][:24 * 300 if hourly else 2000]
+        params = lhs_oracle.lhs_params(n, seed=31)
+        obs = np.abs(np.random.default_rng(2).normal(2.0, 1.0, len(f) // gap))
+        obs[::9] = np.nan
+        kw = dict(extra=bench.EXTRA, obs=obs, gw_obs=0.15, want_final=True)
+        kept = eng.run_ensemble(params, f, bench.AREA, dt, warm, gap, **kw)
+        assert kept._prepared._grouping is None or not hourly
+        for p_in in (params, torch.as_tensor(params).cuda()):
+            for _ in range(2):                                   # the second call takes the memoised ordering
+                free = eng.run_ensemble(p_in, torch.as_tensor(f).cuda(), bench.AREA, dt, warm, gap,
+                                        want_discharge=False, **kw)
+                assert free._prepared._grouping is not None and free.discharge is None
+                assert torch.equal(free.objfn, kept.objfn) and torch.equal(free.gw, kept.gw)
+                assert torch.equal(free.final_vars.view(torch.int64), kept.final_vars.view(torch.int64))
+        gather = free._prepared._grouping[0].cpu().numpy()
+        assert sorted(set(gather.tolist())) == list(range(n))            # every row runs (padding repeats some)
