@@ -14,7 +14,8 @@ groundwater arrays.  `--config` picks the BASELINE.json configuration (default 3
 Rank 0 prints ONE JSON line; DESIGN.md section 5 explains every field.  At N = 1 the line also carries, measured in
 the same run: `parity` (GPU against the CPU oracle on the rows the cpu_baseline leg simulates anyway),
 `flat_forcing` (the same workload with forcing that varies inside the day: the step loop instead of the interval
-engine) and `cpu_baseline`.
+engine), `objectives_only` (the same runs without the stored discharge matrix, the Monte-Carlo default) and
+`cpu_baseline`.
 """
 import argparse
 import hashlib
@@ -326,6 +327,19 @@ def main():
                 'kernel': flat.describe(), 'launch_ms': f_ms, 'value': units_per_launch / (f_ms * 1e-3),
                 'unit': 'sample-timesteps/s', 'wet_fraction': wet_fraction(vary, W)}
             del flat
+        if world == 1 and cfg == 3 and store and not args.no_flat and args.math == 'fast':
+            # the same runs the way MonteCarlo.run() launches them by default (save_sim=False): objective functions and
+            # groundwater ratios only, no discharge matrix -- which lets the engine order the rows
+            lean = engine.prepare_ensemble(d_params, d_forcing, AREA, dt, W, gap, obs=obs, gw_obs=GW_OBS,
+                                           **dict(kw, want_discharge=False))
+            l_elapsed, l_ms, _ = timed_steps(lean.launch, max(2, args.steps // 2), 1, device)
+            lean.verify()
+            line['objectives_only'] = {
+                'what': 'same runs without the stored discharge matrix (MonteCarlo.run with save_sim=False): rows '
+                        'ordered by T and S*Z before the launch, results permuted back',
+                'kernel': lean.describe(), 'launch_ms': l_ms, 'value': units_per_launch / (l_ms * 1e-3),
+                'unit': 'sample-timesteps/s'}
+            del lean
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'], line['parity'] = cpu_baseline_and_parity(forcing, W, gap, dt, device)
         elif not args.no_cpu_baseline:

@@ -78,6 +78,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert 'smart_fast_intervals' in r['kernel'] and r['launch_ms'] > 0
     p = d['parity']
     assert p['ok'] is True and p['max_rel_discharge'] <= 1e-9 and p['gate'] == 1e-6 and p['rows'] >= 64
+    assert 'smart_fast_intervals' in d['objectives_only']['kernel'] and d['objectives_only']['value'] > 0.9 * d['value']
     f = d['flat_forcing']
     assert 'smart_fast_steps' in f['kernel'] and 0 < f['value'] < d['value'] * 1.05
     assert abs(d['value'] - 20000 * 96432 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
