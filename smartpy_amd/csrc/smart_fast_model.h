@@ -145,6 +145,26 @@ struct FastModel {
         l4 = st[9] * m3_to_mm;
         l5 = st[10] * m3_to_mm;
         u_riv = st[11] / k_r;
+        note_capacity();
+    }
+
+    // Wave-uniform early exits in the FILLING cascade assume that a layer below the one just filled cannot overflow
+    // by itself.  True for every state the model produces with C >= 0 -- but a caller's initial state may hold a
+    // layer above its capacity z = Z / 6 (the reference then spills it downwards at the next wet step,
+    // structure.py:367-374, even on a step whose own excess is used up in the top layer), and with C < 0 (GUARD) the
+    // evaporation cascade itself pushes layers above capacity.  over_mask is all ones in those cases and ORed into
+    // every exit's ballot, so that such a wavefront walks all six layers.
+    unsigned long long over_mask;
+
+    __device__ void note_capacity()
+    {
+        const bool over = l0 > z || l1 > z || l2 > z || l3 > z || l4 > z || l5 > z;
+        over_mask = GUARD || __builtin_amdgcn_ballot_w64(over) != 0 ? ~0ull : 0ull;
+    }
+
+    __device__ __forceinline__ bool excess_left(double ex) const
+    {
+        return (__builtin_amdgcn_ballot_w64(ex > 0.0) | over_mask) != 0;
     }
 
     // The seven outputs of the LAST step (structure.py:197 returns the whole last row of the storage table) are not
@@ -297,7 +317,7 @@ struct FastModel {
         ex = fma(-hp, ex, ex);
         fill(l0, ex, z);
 #if SMART_FAST_EARLY_EXIT
-        if (__builtin_amdgcn_ballot_w64(ex > 0.0) != 0)
+        if (excess_left(ex))
 #endif
         {
             fill(l1, ex, z);
@@ -365,13 +385,13 @@ struct FastModel {
         const double ex_in = fma(-e_h, tot, ex); // excess left after the overland share H tot/Z ex (:363-365)
         double rem = ex_in;
         fill3(l0, rem, z);
-        if (!kExits || __builtin_amdgcn_ballot_w64(rem > 0.0) != 0) {
+        if (!kExits || excess_left(rem)) {
             fill3(l1, rem, z);
-            if (!kExits || SMART_FILL_EXITS < 2 || __builtin_amdgcn_ballot_w64(rem > 0.0) != 0) {
+            if (!kExits || SMART_FILL_EXITS < 2 || excess_left(rem)) {
                 fill3(l2, rem, z);
-                if (!kExits || SMART_FILL_EXITS < 3 || __builtin_amdgcn_ballot_w64(rem > 0.0) != 0) {
+                if (!kExits || SMART_FILL_EXITS < 3 || excess_left(rem)) {
                     fill3(l3, rem, z);
-                    if (!kExits || SMART_FILL_EXITS < 4 || __builtin_amdgcn_ballot_w64(rem > 0.0) != 0) {
+                    if (!kExits || SMART_FILL_EXITS < 4 || excess_left(rem)) {
                         fill3(l4, rem, z);
                         fill3(l5, rem, z);
                     }
@@ -443,15 +463,19 @@ struct FastModel {
     {
         double d = -ex;
         dry(l0, d, pC);
+        // the cascade is over for a lane once nothing is handed down.  With C >= 0 that is "no demand left"; a
+        // negative C (GUARD) hands a NEGATIVE demand down, which the next layer takes as an addition
+        // (structure.py:410-413: `if lvl >= deficit` holds for any negative deficit), so there only an exact zero ends it
+        auto handed_down = [](double x) { return GUARD ? x != 0.0 : x > 0.0; };
 #if SMART_FAST_EARLY_EXIT
         // the demand is met by the top layer for every lane of the wave on 57 % of the dry steps, by the top two on
         // 77 %, and reaches the bottom on 11 % (64 random LHS rows, synthetic hourly forcing): two exits, then all
-        if (__builtin_amdgcn_ballot_w64(d > 0.0) != 0)
+        if (__builtin_amdgcn_ballot_w64(handed_down(d)) != 0)
 #endif
         {
             dry(l1, d, pC);
 #if SMART_FAST_EARLY_EXIT && SMART_FAST_DRY_EXIT2
-            if (__builtin_amdgcn_ballot_w64(d > 0.0) != 0)
+            if (__builtin_amdgcn_ballot_w64(handed_down(d)) != 0)
 #endif
             {
                 dry(l2, d, pC);
@@ -525,6 +549,7 @@ struct FastModel {
         u_ove = v[6], u_int = v[7], u_sgw = v[8], u_riv = v[9];
         g0 = v[10], r0 = v[11], xg_sum = v[12];
         u_dra = v[13], u_dgw = v[14];
+        note_capacity();
     }
 
     // ---- groundwater ratio without per-step sums (regular merged variant) -------------------------------------
@@ -590,8 +615,8 @@ struct FastModel {
     {
         pend = pending;
         tot_c = layer_sum();
-        const bool over = l0 > z || l1 > z || l2 > z || l3 > z || l4 > z || l5 > z;
-        zero_ok = __builtin_amdgcn_ballot_w64(over) == 0;
+        note_capacity();
+        zero_ok = over_mask == 0;
     }
 
     __device__ __forceinline__ void flush_pending()

@@ -601,6 +601,108 @@ def test_randomized_configurations(eng):
     assert worst_fast < 1e-10
 
 
+def test_initial_states_above_capacity(eng, example, monkeypatch):
+    """A caller's initial state may hold soil layers above their capacity Z / 6 (nothing the model produces itself;
+    the reference spills such a layer downwards at the next wet step, structure.py:367-374, even when that step's own
+    excess is used up in the top layer).  The wave-uniform early exits of the filling cascade must not skip that
+    spill: every kernel with exits -- interval engine with exits forced on, its final-state variant, the step loops,
+    raw reports, daily steps -- against the oracle started from the same states."""
+    rng = np.random.default_rng(5)
+    n = 80
+    params = lhs_oracle.lhs_params(n, seed=77)
+    z = params[:, 5] / 6.0
+    area = example['area']
+    init = np.zeros((n, 12))
+    init[:, :5] = rng.uniform(1e3, 1e5, (n, 5))
+    init[:, 11] = rng.uniform(1e3, 1e5, n)
+    level = z[:, None] * rng.uniform(0.2, 0.9, (n, 6))
+    level[::3, 2] = 1.6 * z[::3]                 # third layer 60 % above capacity, top layers with room to spare
+    level[1::4, 4] = 2.5 * z[1::4]
+    level[5::7, :] = 1.2 * z[5::7, None]
+    init[:, 5:11] = level / 1e3 * area
+    for hourly, report, exits, final in ((True, 'summary', '1', False), (True, 'summary', '0', False),
+                                         (True, 'summary', '1', True), (True, 'raw', '1', False),
+                                         (False, 'summary', '1', True)):
+        dt, gap = (3600.0, 24) if hourly else (86400.0, 1)
+        T = 24 * 60 if hourly else 200
+        rain = example['rain_hourly'][:T] * 0.3 if hourly else example['rain_daily'][:T] * 0.3
+        peva = example['peva_hourly'][:T] if hourly else example['peva_daily'][:T]
+        rtype = so.REPORT_SUMMARY if report == 'summary' else so.REPORT_RAW
+        monkeypatch.setenv('SMART_EXITS', exits)
+        for varying in (False, True):
+            r = rain.copy()
+            if varying and hourly:
+                r[::5] *= 1.7
+            out = eng.run_ensemble(params, forcing_of(r, peva), area, dt, 0, gap, report=report, initial=init,
+                                   want_final=final)
+            tag = '%s %s exits=%s final=%s varying=%s: %s' % ('hourly' if hourly else 'daily', report, exits, final,
+                                                             varying, out._prepared.describe())
+            good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
+            for row in np.flatnonzero(good)[:40]:
+                full = np.concatenate([np.zeros(7), init[row]])
+                want, gw, fin = so.all_steps(area, dt, T, r, peva, params[row], full, rtype, gap)
+                assert rel(out.discharge[row].cpu().numpy(), want, floor=1e-300) <= REL_FAST, (tag, row)
+                if final:
+                    assert rel(out.final_vars[row].cpu().numpy(), fin, floor=1e-250) <= 1e-8, (tag, row)
+
+
+def test_randomized_wide_parameter_ranges(eng):
+    """25 seeded set-ups with parameters far outside the default sampling ranges -- S up to 0.9 and C below 0 (the GUARD
+    kernel: the `leak < level` guards and the sign of the evaporation decay matter), routing constants from minutes
+    to years (STIFF: clamps and the river's 95 % rule), shallow and deep soils, H up to 0.9 -- every arithmetic class
+    in one launch, summary and raw reports, the final row asked for.  Well-conditioned rows (dt / k <= 2) within
+    tolerance of the reference-exact oracle on discharge, groundwater ratio and all 19 values of the final row;
+    ill-conditioned rows bit-identical to the literal kernel."""
+    rng = np.random.default_rng(77)
+    seen = set()
+    for case in range(25):
+        dt = float(rng.choice([900.0, 3600.0, 86400.0]))
+        gap = int(rng.choice([1, 4, 24]))
+        n_rep = int(rng.integers(20, 80))
+        T = n_rep * gap
+        W = int(rng.integers(0, n_rep // 2 + 1)) * gap if rng.random() < 0.6 else 0
+        scale = dt / 86400.0
+        rain = rng.gamma(0.4, 8.0, T) * (rng.random(T) < rng.uniform(0.2, 0.9)) * scale * rng.choice([1.0, 10.0])
+        peva = np.maximum(0.0, rng.normal(1.5, 1.0, T)) * scale
+        peva[rng.random(T) < 0.1] = 0.0
+        area = float(np.exp(rng.uniform(np.log(5e6), np.log(5e9))))
+        n = int(rng.integers(65, 400))
+        params = np.column_stack([
+            rng.uniform(0.7, 1.3, n), rng.uniform(-0.2, 1.2, n), rng.uniform(0.0, 0.9, n), rng.uniform(0.0, 1.0, n),
+            rng.uniform(0.0, 0.9, n) * (rng.random(n) < 0.5) + rng.uniform(0.0, 0.013, n), rng.uniform(5.0, 300.0, n),
+            np.exp(rng.uniform(np.log(0.2), np.log(500.0), n)), np.exp(rng.uniform(np.log(1.0), np.log(3000.0), n)),
+            np.exp(rng.uniform(np.log(10.0), np.log(20000.0), n)), np.exp(rng.uniform(np.log(0.2), np.log(300.0), n))])
+        extra = {'aar': float(rng.uniform(600, 2500)), 'r-o_ratio': float(rng.uniform(0.2, 0.7)),
+                 'r-o_split': tuple(rng.dirichlet(np.ones(5)))} if rng.random() < 0.7 else None
+        report, rtype = ('summary', so.REPORT_SUMMARY) if rng.random() < 0.7 else ('raw', so.REPORT_RAW)
+        f = forcing_of(rain, peva)
+        fast = eng.run_ensemble(params, f, area, dt, W, gap, report=report, extra=extra, want_final=True)
+        seen.update(k.split('[')[0] for k in fast._prepared.describe().split(' + '))
+        d1, g1, f1 = so.run_batch(area, dt, T, W, rain, peva, params, extra, rtype, gap, want_final=True)
+        tag = 'case %d: dt=%g gap=%d T=%d W=%d n=%d %s extra=%s' % (case, dt, gap, T, W, n, report, extra is not None)
+        good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
+        assert good.sum() >= 5, tag
+        assert rel(fast.discharge.cpu().numpy()[good], d1[good], floor=1e-300) <= REL_FAST, tag
+        ok = np.isfinite(g1[good])
+        assert rel(fast.gw.cpu().numpy()[good][ok], g1[good][ok], floor=1e-300) <= 1e-9, tag
+        # the final row: relative 1e-8, or absolute 1e-13 of the row's largest entry -- a layer that the reference empties
+        # exactly (`lvl >= deficit` false by one ulp) may keep 1e-15 mm in the other arithmetic, and the other way round
+        fv, scale = fast.final_vars.cpu().numpy()[good], np.abs(f1[good]).max(axis=1, keepdims=True)
+        assert np.all(np.abs(fv - f1[good]) <= 1e-8 * np.abs(f1[good]) + 1e-13 * scale), tag
+        if (~good).any():
+            lit = eng.run_ensemble(params[~good], f, area, dt, W, gap, report=report, extra=extra, math_mode='literal',
+                                   want_final=True)
+            # same arithmetic, step for step: the final rows agree to the bit; the report means do unless the
+            # literal kernel reproduces numpy's pairwise summation order for them (summary reports, gap 8..128)
+            assert bits_equal(fast.final_vars.cpu().numpy()[~good], lit.final_vars.cpu().numpy()), tag
+            if report == 'raw' or gap < 8:
+                assert bits_equal(fast.discharge.cpu().numpy()[~good], lit.discharge.cpu().numpy()), tag
+            else:
+                assert rel(fast.discharge.cpu().numpy()[~good], lit.discharge.cpu().numpy()) <= 1e-13, tag
+    assert {'smart_fast_stiff', 'smart_fast_guard', 'smart_fast_illcond', 'smart_fast_plain'} <= seen, seen
+    assert seen & {'smart_fast_intervals_states', 'smart_fast_steps_states'}, seen
+
+
 # ------------------------------------------------------------------------------------------------------
 # time-sliced launch (smart_device.h): same arithmetic, different schedule
 # ------------------------------------------------------------------------------------------------------

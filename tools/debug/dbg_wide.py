@@ -1,0 +1,59 @@
+"""Replays one set-up of tests/test_gpu_parity.py::test_randomized_wide_parameter_ranges and says which rows of which
+arithmetic class leave the reference, and at which step.  usage: python tools/debug/dbg_wide.py <case>"""
+import sys
+sys.path.insert(0, '.')
+import numpy as np
+import torch
+from smartpy_amd import engine as eng
+from oracle import smart_oracle as so
+want_case = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+rng = np.random.default_rng(77)
+for case in range(want_case + 1):
+    dt = float(rng.choice([900.0, 3600.0, 86400.0]))
+    gap = int(rng.choice([1, 4, 24]))
+    n_rep = int(rng.integers(20, 80))
+    T = n_rep * gap
+    W = int(rng.integers(0, n_rep // 2 + 1)) * gap if rng.random() < 0.6 else 0
+    scale = dt / 86400.0
+    rain = rng.gamma(0.4, 8.0, T) * (rng.random(T) < rng.uniform(0.2, 0.9)) * scale * rng.choice([1.0, 10.0])
+    peva = np.maximum(0.0, rng.normal(1.5, 1.0, T)) * scale
+    peva[rng.random(T) < 0.1] = 0.0
+    area = float(np.exp(rng.uniform(np.log(5e6), np.log(5e9))))
+    n = int(rng.integers(65, 400))
+    params = np.column_stack([
+        rng.uniform(0.7, 1.3, n), rng.uniform(-0.2, 1.2, n), rng.uniform(0.0, 0.9, n), rng.uniform(0.0, 1.0, n),
+        rng.uniform(0.0, 0.9, n) * (rng.random(n) < 0.5) + rng.uniform(0.0, 0.013, n), rng.uniform(5.0, 300.0, n),
+        np.exp(rng.uniform(np.log(0.2), np.log(500.0), n)), np.exp(rng.uniform(np.log(1.0), np.log(3000.0), n)),
+        np.exp(rng.uniform(np.log(10.0), np.log(20000.0), n)), np.exp(rng.uniform(np.log(0.2), np.log(300.0), n))])
+    extra = {'aar': float(rng.uniform(600, 2500)), 'r-o_ratio': float(rng.uniform(0.2, 0.7)),
+             'r-o_split': tuple(rng.dirichlet(np.ones(5)))} if rng.random() < 0.7 else None
+    report, rtype = ('summary', so.REPORT_SUMMARY) if rng.random() < 0.7 else ('raw', so.REPORT_RAW)
+f = np.stack([rain, peva], 1)
+print('case', want_case, dt, gap, T, W, n, report, extra is not None)
+fast = eng.run_ensemble(params, f, area, dt, W, gap, report=report, extra=extra, want_final=True)
+print(fast._prepared.describe())
+d1, g1, f1 = so.run_batch(area, dt, T, W, rain, peva, params, extra, rtype, gap, want_final=True)
+got = fast.discharge.cpu().numpy()
+err = np.max(np.abs(got - d1) / np.maximum(np.abs(d1), 1e-300), axis=1)
+cls = eng.variant_classes(torch.as_tensor(params), dt).numpy()
+for c in range(4):
+    m = cls == c
+    if m.any():
+        print('class', c, 'rows', m.sum(), 'max err', err[m].max())
+np.set_printoptions(precision=5, linewidth=200)
+good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
+for b in np.argsort(np.where(good, err, 0))[-4:]:
+    print(b, 'class', cls[b], 'err', err[b], 'dt/k', dt / (params[b, 6:10] * 3600), params[b])
+b = int(np.argmax(np.where(good, err, 0)))
+p1 = params[b:b + 1]
+ref_d, _, _ = so.run_batch(area, dt, T, 0, rain, peva, p1, extra, so.REPORT_RAW, 1)
+fd = eng.run_ensemble(p1, f, area, dt, 0, 1, report='raw', extra=extra).discharge.cpu().numpy()
+e = np.abs(fd - ref_d) / np.maximum(np.abs(ref_d), 1e-300)
+first = int(np.argmax(e[0] > 1e-10))
+print('row', b, 'run on its own from step 0, no warm-up: first step off by > 1e-10:', first, 'of', T, 'err', e[0, first], 'max', e.max())
+for t in range(max(first - 2, 0), first + 2):
+    _, _, fr = so.run_batch(area, dt, t + 1, 0, rain, peva, p1, extra, so.REPORT_RAW, 1, want_final=True)
+    ff = eng.run_ensemble(p1, f[:t + 1], area, dt, 0, 1, report='raw', extra=extra, want_final=True).final_vars.cpu().numpy()
+    print('after step', t, 'rain %.4g peva %.4g ex %.4g' % (rain[t], peva[t], rain[t] * p1[0, 0] - peva[t]))
+    print('  ref ', fr[0])
+    print('  fast', ff[0])
