@@ -646,6 +646,56 @@ def test_initial_states_above_capacity(eng, example, monkeypatch):
                     assert rel(out.final_vars[row].cpu().numpy(), fin, floor=1e-250) <= 1e-8, (tag, row)
 
 
+def test_parameter_and_forcing_corner_cases(eng, example):
+    """Rows that sit exactly on the boundaries between the arithmetic classes and on the degenerate values of every
+    parameter, under forcings that are all zero, all rain, and exactly balanced (rain * T == peva on every step: a wet
+    step with zero excess) -- hourly with daily reports (interval engine, time slices forced), hourly raw, and daily.
+    Discharge, groundwater ratio and final row against the reference-exact oracle."""
+    base = np.array(example['params'], dtype=np.float64)        # T C H D S Z SK FK GK RK of the shipped example
+    rows = [base]
+
+    def variant(**kw):
+        r = base.copy()
+        for k, v in kw.items():
+            r['T C H D S Z SK FK GK RK'.split().index(k)] = v
+        rows.append(r)
+    for v in (0.0, 1.0):
+        variant(C=v), variant(D=v)
+    variant(H=0.0), variant(H=1.0), variant(S=0.0), variant(S=0.5), variant(S=0.5000001), variant(T=1.0), variant(T=0.5)
+    variant(Z=0.6), variant(Z=3000.0)
+    variant(SK=1.0, RK=1.0), variant(SK=0.5, RK=0.5), variant(SK=24.0, RK=24.0), variant(SK=12.0, RK=12.0)
+    variant(SK=1.0, FK=1.0, GK=1.0, RK=1.0), variant(FK=24.0, GK=24.0), variant(SK=1e6, FK=1e6, GK=1e6, RK=1e6)
+    variant(C=0.0, S=0.0, H=0.0, D=0.0), variant(C=1.0, S=0.5, H=1.0, D=1.0)
+    params = np.tile(np.array(rows), (3, 1))     # > 64 rows: the engine groups them by class, one kernel per class
+    n_days = 90
+    pe_d = np.maximum(0.0, 1.5 + np.sin(np.arange(n_days) / 9.0))
+    rain_d = np.where(np.arange(n_days) % 7 < 3, 6.0, 0.0) * (1 + np.cos(np.arange(n_days)))
+    forcings = {'example-like': (rain_d, pe_d), 'nothing at all': (np.zeros(n_days), np.zeros(n_days)),
+                'rain only': (np.full(n_days, 12.0), np.zeros(n_days)), 'evaporation only': (np.zeros(n_days), pe_d),
+                'balanced (T = 1)': (pe_d.copy(), pe_d), 'cloudburst': (np.where(np.arange(n_days) == 40, 400.0, 0.0), pe_d)}
+    for name, (r_d, e_d) in forcings.items():
+        for hourly, report, slices in ((True, 'summary', 3), (True, 'raw', 0), (False, 'summary', 0)):
+            dt, gap = (3600.0, 24) if hourly else (86400.0, 1)
+            rain = np.repeat(r_d / 24, 24) if hourly else r_d
+            peva = np.repeat(e_d / 24, 24) if hourly else e_d
+            T, W = len(rain), (24 * 10 if hourly else 10)
+            rtype = so.REPORT_SUMMARY if report == 'summary' else so.REPORT_RAW
+            out = eng.run_ensemble(params, forcing_of(rain, peva), example['area'], dt, W, gap, report=report,
+                                   extra=example['extra'], want_final=True, time_slices=slices)
+            d1, g1, f1 = so.run_batch(example['area'], dt, T, W, rain, peva, params, example['extra'], rtype, gap,
+                                      want_final=True)
+            tag = '%s, %s %s: %s' % (name, 'hourly' if hourly else 'daily', report, out._prepared.describe())
+            good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
+            scale = np.maximum(np.abs(d1[good]).max(axis=1, keepdims=True), 1e-300)
+            got = out.discharge.cpu().numpy()[good]
+            assert np.all(np.abs(got - d1[good]) <= REL_FAST * np.abs(d1[good]) + 1e-13 * scale), tag
+            gg, ok = out.gw.cpu().numpy()[good], np.isfinite(g1[good])
+            assert np.all(np.abs(gg[ok] - g1[good][ok]) <= 1e-9), tag
+            assert np.array_equal(np.isnan(gg), np.isnan(g1[good])), tag        # 0 / 0 where nothing ever runs off
+            fv, fs = out.final_vars.cpu().numpy()[good], np.abs(f1[good]).max(axis=1, keepdims=True)
+            assert np.all(np.abs(fv - f1[good]) <= 1e-8 * np.abs(f1[good]) + 1e-13 * fs), tag
+
+
 def test_randomized_wide_parameter_ranges(eng):
     """25 seeded set-ups with parameters far outside the default sampling ranges -- S up to 0.9 and C below 0 (the GUARD
     kernel: the `leak < level` guards and the sign of the evaporation decay matter), routing constants from minutes
