@@ -93,7 +93,10 @@ __device__ inline void finish_objectives(const double *st, double A, double B, d
     const double var_e = see * inv_n;
     const double cov = (C3 - sd * m1) * inv_n;
     double cc = cov / sqrt(var_s * var_e);
-    cc = fmin(fmax(cc, -1.0), 1.0); // np.corrcoef clips
+    // np.corrcoef clips to [-1, 1]; a NaN (constant observations or a single one: 0 / 0) stays a NaN there, which
+    // fmin / fmax would turn into -1 -- tested on the bit pattern, the translation units assume NaN-free arithmetic
+    if (!is_nan_bits(cc))
+        cc = fmin(fmax(cc, -1.0), 1.0);
     const double alpha = sqrt(var_s / var_e);
     const double beta = 1.0 + A / se;
     o[0] = 1.0 - B / see;

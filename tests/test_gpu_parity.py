@@ -278,6 +278,39 @@ def test_fused_objective_functions_and_g4(eng, example):
 # ------------------------------------------------------------------------------------------------------
 # edge cases and error behaviour (structure.py:69-70, 90-95, 190)
 # ------------------------------------------------------------------------------------------------------
+def test_objective_functions_of_degenerate_observations(eng, example):
+    """Observation series on which the formulas divide zero by zero -- constant values, a single valid one -- give the
+    NaN / inf pattern numpy gives the reference (np.corrcoef of a constant series is NaN, NSE is -inf), from the fused
+    moments and from the stored-matrix kernel alike; with no valid observation at all, or all-zero ones, the reference
+    raises ZeroDivisionError inside spotpy's pbias (montecarlo.py:202) and the engine returns non-finite values."""
+    import warnings
+    params = lhs_oracle.lhs_params(70, seed=3)
+    T, W = 24 * 100, 24 * 10
+    rain, peva = example['rain_hourly'][:T], example['peva_hourly'][:T]
+    dis, gw, _ = so.run_batch(example['area'], 3600.0, T, W, rain, peva, params, example['extra'], so.REPORT_SUMMARY, 24)
+    R = T // 24
+    for name, obs in (('constant', np.full(R, 2.0)), ('single value', np.where(np.arange(R) == 17, 1.5, np.nan)),
+                      ('two values', np.where(np.arange(R) % 50 == 7, 1.5 + np.arange(R) / 100.0, np.nan))):
+        out = eng.run_ensemble(params, forcing_of(rain, peva), example['area'], 3600.0, W, 24, extra=example['extra'],
+                               obs=obs, gw_obs=0.12667)
+        two = eng.objective_functions(out.discharge_report_major, obs, out.gw, 0.12667).cpu().numpy()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            want = objfn_oracle.objective_matrix(dis, obs, gw, 0.12667)
+        for got in (out.objfn.cpu().numpy(), two):
+            assert np.array_equal(np.isnan(got), np.isnan(want)), name
+            assert np.array_equal(np.isinf(got), np.isinf(want)) and np.array_equal(np.sign(got[np.isinf(got)]),
+                                                                                    np.sign(want[np.isinf(want)])), name
+            fin = np.isfinite(want)
+            assert rel(got[fin], want[fin], floor=1e-12) <= 1e-7, name
+    for obs in (np.full(R, np.nan), np.zeros(R)):
+        with pytest.raises(ZeroDivisionError):
+            objfn_oracle.objective_matrix(dis[:1], obs, gw[:1], 0.12667)
+        out = eng.run_ensemble(params, forcing_of(rain, peva), example['area'], 3600.0, W, 24, extra=example['extra'],
+                               obs=obs, gw_obs=0.12667)
+        assert not np.isfinite(out.objfn.cpu().numpy()[:, :2]).any()
+
+
 def test_ragged_sample_counts_and_padding(eng, example):
     """N not a multiple of the wavefront, N = 1, and a padded leading dimension."""
     import torch
