@@ -128,10 +128,11 @@ __global__ __launch_bounds__(WX *WR *kWave) void smart_objfn_matrix(long N, long
         n = N - 1;
     const double ebar = st[1];
     const double *col = sim + n;
+    const double shift = col[0]; // any constant per sample works (finish_objectives); the first value keeps the digits
     double A = 0.0, B = 0.0, C1 = 0.0, C2 = 0.0, C3 = 0.0;
     auto add = [&](double e, double s) {
         if (!is_nan_bits(e)) { // montecarlo.py:195-196
-            const double d = s - e, u = s - ebar;
+            const double d = s - e, u = s - shift;
             A += d;
             B += d * d;
             C1 += u;

@@ -51,7 +51,7 @@ struct KArgs {
     int debug_drop = 0;          // test knob: slice 0 of block 0 never publishes (its successors must time out)
 };
 
-constexpr int kSegFields = 22;
+constexpr int kSegFields = 23;
 constexpr int kHdrInts = 64;      // workspace header: [0] status word, [1 + k] ticket counter of sliced kernel k
 constexpr int kHdrStatus = 0, kHdrTicket = 1;
 constexpr int kStatusSliceTimeout = 1, kStatusStalePlan = 2; // = SMART_STATUS_* of include/smart_amd.h
@@ -82,7 +82,10 @@ __host__ __device__ __forceinline__ double quiet_nan() { return __builtin_bit_ca
 
 // objective functions from the one-pass moments (montecarlo.py:193-209; formulas of spotpy's nashsutcliffe,
 // kge(return_all=True), pbias, rmse).  Moments are taken about the observation mean, known before the run:
-//   A = sum(s - e)   B = sum((s - e)^2)   C1 = sum(s - ebar)   C2 = sum((s - ebar)^2)   C3 = sum((e - ebar)(s - ebar))
+//   A = sum(s - e)   B = sum((s - e)^2)   C1 = sum(s - c)   C2 = sum((s - c)^2)   C3 = sum((e - ebar)(s - c))
+// with ebar the observation mean and c ANY constant per sample (variance and covariance do not depend on it); the
+// kernels take c = the sample's own first reported discharge: a simulated series that barely moves (std 1e-4 of its
+// mean) then keeps its variance through the one-pass form, where c = ebar lost half the digits (KGEa off by 2e-7)
 __device__ inline void finish_objectives(const double *st, double A, double B, double C1, double C2, double C3,
                                          double gw_sim, double gw_obs, double *o)
 {
@@ -269,7 +272,7 @@ __device__ __forceinline__ void init_model(const KArgs &a, const LaneCtx &x, Mod
 struct Reporter {
     const double *__restrict__ obs; // this catchment's observations | null
     const double *__restrict__ ws;  // this catchment's workspace (statistics + e - mean) | null
-    double ebar;
+    double shift; // c above: this sample's discharge of report step 0
     bool want_obj;
     double A = 0.0, B = 0.0, C1 = 0.0, C2 = 0.0, C3 = 0.0;
 
@@ -279,7 +282,7 @@ struct Reporter {
         want_obj = a.objfn != nullptr;
         ws = ws_all ? ws_all + x.c * (kWsHead + a.R) : nullptr;
         obs = obs_all ? obs_all + x.c * a.R : nullptr;
-        ebar = want_obj ? ws[1] : 0.0;
+        shift = 0.0;
     }
 
     __device__ __forceinline__ void emit(const KArgs &a, const LaneCtx &x, long r, double val)
@@ -292,9 +295,11 @@ struct Reporter {
 #endif
         if (want_obj) {
             const double e = obs[r];
+            if (r == 0)
+                shift = val;
             if (!is_nan_bits(e)) { // montecarlo.py:195-196
                 const double d = val - e;
-                const double u = val - ebar;
+                const double u = val - shift;
                 A += d;
                 B += d * d;
                 C1 += u;
@@ -311,9 +316,11 @@ struct Reporter {
     {
         if (a.discharge && x.live)
             a.discharge[(x.c * a.R + r) * a.ld + x.n] = val;
+        if (want_obj && r == 0)
+            shift = val;
         if (want_obj && !is_nan_bits(e)) { // montecarlo.py:195-196
             const double d = val - e;
-            const double u = val - ebar;
+            const double u = val - shift;
             A += d;
             B += d * d;
             C1 += u;
@@ -646,6 +653,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         rep.C1 = hand[19 * kWave];
         rep.C2 = hand[20 * kWave];
         rep.C3 = hand[21 * kWave];
+        rep.shift = hand[22 * kWave];
     }
 
     // Callers that ask for the final state vector (the SPLIT models) also get the seven outputs of the last step
@@ -771,6 +779,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         hand[19 * kWave] = rep.C1;
         hand[20 * kWave] = rep.C2;
         hand[21 * kWave] = rep.C3;
+        hand[22 * kWave] = rep.shift;
         if constexpr (!piecewise)
             hand[15 * kWave] = m.pend;
         if (!(a.debug_drop && slot == 0 && seg == 0)) // test knob: a hand-over that never arrives

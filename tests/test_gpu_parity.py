@@ -773,7 +773,10 @@ def run_wide_cases(eng, seed, n_cases):
         good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
         if good.sum() < 5:
             continue
-        assert rel(fast.discharge.cpu().numpy()[good], d1[good], floor=1e-300) <= REL_FAST, tag
+        # relative 1e-9, or absolute 1e-13 of the row's largest discharge: a catchment that has run dry carries flows of
+        # 1e-20 m3/s whose sign the river's 95 % rule flips on rounding noise (dt / RK > 1) -- zero, to any hydrologist
+        got, top = fast.discharge.cpu().numpy()[good], np.abs(d1[good]).max(axis=1, keepdims=True)
+        assert np.all(np.abs(got - d1[good]) <= REL_FAST * np.abs(d1[good]) + 1e-13 * top), tag
         ok = np.isfinite(g1[good])
         assert rel(fast.gw.cpu().numpy()[good][ok], g1[good][ok], floor=1e-300) <= 1e-9, tag
         # the final row: relative 1e-8, or absolute 1e-13 of the row's largest entry -- a layer that the reference empties
@@ -873,9 +876,19 @@ def test_randomized_interval_engine(eng, monkeypatch):
     calm steps (no rain, no evaporation) in between -- the step loop with deferred evaporation.  Fast mode within
     tolerance of the reference-exact oracle on well-conditioned rows: discharge, groundwater ratio, objective
     functions, and all 19 values of the final row."""
-    rng = np.random.default_rng(20261003)
+    def setenv(name, val):
+        if val:
+            monkeypatch.setenv(name, str(val))
+        else:
+            monkeypatch.delenv(name, raising=False)
+    assert run_interval_cases(eng, setenv, 20261003, 45) < 1e-10
+
+
+def run_interval_cases(eng, setenv, seed, n_cases):
+    """-> largest relative discharge error seen (tools/debug/fuzz_wide.py runs more seeds of this)."""
+    rng = np.random.default_rng(seed)
     worst = 0.0
-    for case in range(45):
+    for case in range(n_cases):
         dt = float(rng.choice([900.0, 3600.0, 10800.0]))
         gap = int(rng.choice([2, 3, 8, 24, 48]))
         n_rep = int(rng.integers(64, 200))
@@ -885,7 +898,7 @@ def test_randomized_interval_engine(eng, monkeypatch):
         rain_iv = rng.gamma(0.4, 8.0, n_rep) * (rng.random(n_rep) < rng.uniform(0.2, 0.9)) * rng.choice([1.0, 1.0, 15.0])
         peva_iv = np.maximum(0.0, rng.normal(1.5, 1.0, n_rep))
         peva_iv[rng.random(n_rep) < 0.08] = 0.0
-        varying = case >= 30
+        varying = case % 3 == 2
         if varying:     # the interval's total in a few of its steps, the others calm or evaporation only
             w_r = rng.random((n_rep, gap)) * (rng.random((n_rep, gap)) < 0.3)
             w_r[w_r.sum(1) == 0, 0] = 1.0
@@ -905,19 +918,16 @@ def test_randomized_interval_engine(eng, monkeypatch):
         obs[rng.random(n_rep) < 0.15] = np.nan
         slices, exits = rng.choice(['', '0', '3', '9']), rng.choice(['', '0', '1'])
         want_final = bool(rng.random() < 0.5)
-        for name, val in (('SMART_TIME_SLICES', slices), ('SMART_EXITS', exits)):
-            if val:
-                monkeypatch.setenv(name, str(val))
-            else:
-                monkeypatch.delenv(name, raising=False)
+        setenv('SMART_TIME_SLICES', slices)
+        setenv('SMART_EXITS', exits)
         fast = eng.run_ensemble(params, forcing_of(rain, peva), area, dt, W, gap, extra=extra, obs=obs, gw_obs=0.2,
                                 want_final=want_final)
         kernels = fast._prepared.describe()
         if 'smart_fast_intervals' in kernels or 'smart_fast_steps' in kernels:       # some rows are regular ones
             assert ('smart_fast_steps' in kernels) == varying and ('_states' in kernels) == want_final, kernels
         d1, g1, f1 = so.run_batch(area, dt, T, W, rain, peva, params, extra, so.REPORT_SUMMARY, gap, want_final=True)
-        tag = 'case %d: dt=%g gap=%d T=%d W=%d n=%d extra=%s slices=%r exits=%r final=%r varying=%r' % (
-            case, dt, gap, T, W, n, extra is not None, slices, exits, want_final, varying)
+        tag = 'seed %d case %d: dt=%g gap=%d T=%d W=%d n=%d extra=%s slices=%r exits=%r final=%r varying=%r' % (
+            seed, case, dt, gap, T, W, n, extra is not None, slices, exits, want_final, varying)
         good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
         if good.any():
             e = rel(fast.discharge.cpu().numpy()[good], d1[good], floor=1e-300)
@@ -930,8 +940,9 @@ def test_randomized_interval_engine(eng, monkeypatch):
             fin = np.isfinite(want[:, :7]).all(axis=1)
             assert rel(got[fin, :7], want[fin, :7], floor=1e-12) <= 1e-7, tag
             if want_final:
-                assert rel(fast.final_vars.cpu().numpy()[good], f1[good], floor=1e-250) <= 1e-8, tag
-    assert worst < 1e-10
+                fv, fs = fast.final_vars.cpu().numpy()[good], np.abs(f1[good]).max(axis=1, keepdims=True)
+                assert np.all(np.abs(fv - f1[good]) <= 1e-8 * np.abs(f1[good]) + 1e-13 * fs), tag
+    return worst
 
 
 def test_launch_captures_into_a_hip_graph(eng, example):

@@ -7,7 +7,8 @@ import torch
 from smartpy_amd import engine as eng
 from oracle import smart_oracle as so
 want_case = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-rng = np.random.default_rng(77)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 77
+rng = np.random.default_rng(seed)
 for case in range(want_case + 1):
     dt = float(rng.choice([900.0, 3600.0, 86400.0]))
     gap = int(rng.choice([1, 4, 24]))

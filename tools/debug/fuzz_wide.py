@@ -1,5 +1,7 @@
-"""More seeds of tests/test_gpu_parity.py::run_wide_cases than the test suite runs (parameters far outside the default
-ranges, every arithmetic class, final rows).  usage: python tools/debug/fuzz_wide.py <first seed> <n seeds> [cases]"""
+"""More seeds of tests/test_gpu_parity.py::run_wide_cases (parameters far outside the default ranges, every arithmetic
+class, final rows) and ::run_interval_cases (interval engine and step loop, slices and exits at random) than the test
+suite runs.  usage: python tools/debug/fuzz_wide.py <first seed> <n seeds> [cases]"""
+import os
 import sys
 import traceback
 sys.path.insert(0, '.')
@@ -12,7 +14,11 @@ bad = 0
 for seed in range(first, first + count):
     try:
         t.run_wide_cases(engine, seed, cases)
+        t.run_interval_cases(engine, lambda k, v: os.environ.__setitem__(k, str(v)) if v else os.environ.pop(k, None),
+                             seed, cases)
     except AssertionError:
         bad += 1
-        print('seed', seed, 'FAILED:', traceback.format_exc().splitlines()[-1][:300], flush=True)
+        tb = traceback.format_exc().splitlines()
+        where = [ln.strip() for ln in tb if ln.strip().startswith('assert')]
+        print('seed', seed, 'FAILED:', tb[-1][:300], '|', where[-1][:160] if where else '', flush=True)
 print('%d seeds x %d cases: %d failed' % (count, cases, bad))
