@@ -729,6 +729,90 @@ def test_parameter_and_forcing_corner_cases(eng, example):
             assert np.all(np.abs(fv - f1[good]) <= 1e-8 * np.abs(f1[good]) + 1e-13 * fs), tag
 
 
+def run_batch_cases(eng, seed, n_cases):
+    """Seeded set-ups of the batched entry's own dimensions: 1..4 catchments (areas, forcings, observations and
+    groundwater constraints of their own), parameters shared or per catchment, runs started from given states (some
+    with layers above capacity) or from the educated guess, summary / raw, with or without the final row, forced time
+    slices -- every (catchment, row) against the oracle started from the same states."""
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        C = int(rng.integers(1, 5))
+        hourly = bool(rng.random() < 0.6)
+        dt, gap = (3600.0, int(rng.choice([6, 24]))) if hourly else (86400.0, 1)
+        n_rep = int(rng.integers(30, 90))
+        T = n_rep * gap
+        W = int(rng.integers(0, n_rep // 3 + 1)) * gap if rng.random() < 0.5 else 0
+        n = int(rng.integers(3, 140))
+        scale = dt / 86400.0
+        per_iv = rng.random() < 0.6
+        forcing = np.empty((C, T, 2))
+        for c in range(C):
+            r = rng.gamma(0.5, 7.0, n_rep) * (rng.random(n_rep) < 0.6) * scale
+            e = np.maximum(0.0, rng.normal(1.5, 0.8, n_rep)) * scale
+            if per_iv or not hourly:
+                forcing[c, :, 0], forcing[c, :, 1] = np.repeat(r, gap), np.repeat(e, gap)
+            else:
+                forcing[c, :, 0] = np.repeat(r, gap) * rng.uniform(0.0, 2.0, T)
+                forcing[c, :, 1] = np.repeat(e, gap) * rng.uniform(0.0, 2.0, T)
+        areas = np.exp(rng.uniform(np.log(2e7), np.log(2e9), C))
+        per_catchment = bool(rng.random() < 0.5)
+        params = np.stack([lhs_oracle.lhs_params(max(n, 2), seed=int(rng.integers(1 << 30)))[:n]
+                           for _ in range(C if per_catchment else 1)])
+        use_initial = bool(rng.random() < 0.6)
+        initial = None
+        if use_initial:
+            initial = np.zeros((C, n, 12))
+            for c in range(C):
+                p = params[c if per_catchment else 0]
+                initial[c, :, :5] = rng.uniform(0.0, 5e4, (n, 5))
+                initial[c, :, 11] = rng.uniform(0.0, 5e4, n)
+                lev = (p[:, 5:6] / 6.0) * rng.uniform(0.0, 1.0, (n, 6))
+                lev[rng.random((n, 6)) < 0.05] *= 2.5               # a few layers above capacity
+                initial[c, :, 5:11] = lev / 1e3 * areas[c]
+        extra = None if use_initial else {'aar': float(rng.uniform(600, 2500)), 'r-o_ratio': float(rng.uniform(0.2, 0.7)),
+                                          'r-o_split': tuple(rng.dirichlet(np.ones(5)))}
+        report, rtype = ('summary', so.REPORT_SUMMARY) if rng.random() < 0.7 else ('raw', so.REPORT_RAW)
+        final = bool(rng.random() < 0.5)
+        obs = rng.random((C, T // gap)) * 4
+        obs[rng.random(obs.shape) < 0.1] = np.nan
+        gw_obs = rng.uniform(0.05, 0.4, C)
+        slices = int(rng.choice([0, 1, 3, 7]))
+        out = eng.run_ensemble(params if per_catchment else params[0], forcing, areas, dt, W, gap, report=report,
+                               extra=extra, initial=initial, obs=obs, gw_obs=gw_obs, want_final=final,
+                               time_slices=slices)
+        tag = 'seed %d case %d: C=%d n=%d dt=%g gap=%d T=%d W=%d %s initial=%s per_catchment=%s final=%s slices=%d: %s' % (
+            seed, case, C, n, dt, gap, T, W, report, use_initial, per_catchment, final, slices, out._prepared.describe())
+        dis, gwr, obj = out.discharge.cpu().numpy(), out.gw.cpu().numpy(), out.objfn.cpu().numpy()
+        fin = out.final_vars.cpu().numpy() if final else None
+        for c in range(C):
+            p = params[c if per_catchment else 0]
+            rows = rng.choice(n, min(n, 6), replace=False)
+            for row in rows:
+                if (p[row, 6:10] * 3600.0 < 0.5 * dt).any():
+                    continue
+                rain, peva = forcing[c, :, 0].copy(), forcing[c, :, 1].copy()
+                if use_initial:
+                    start = np.concatenate([np.zeros(7), initial[c, row]])
+                    if W:
+                        start = so.all_steps(areas[c], dt, W, rain, peva, p[row], start, rtype, gap)[2]
+                    want, gw1, f1 = so.all_steps(areas[c], dt, T, rain, peva, p[row], start, rtype, gap)
+                else:
+                    want, gw1, f1 = so.run(areas[c], dt, T, W, rain, peva, p[row], extra, rtype, gap)
+                top = max(np.abs(want).max(), 1e-300)
+                assert np.all(np.abs(dis[c, row] - want) <= REL_FAST * np.abs(want) + 1e-13 * top), (tag, c, row)
+                if np.isfinite(gw1):
+                    assert abs(gwr[c, row] - gw1) <= 1e-9, (tag, c, row)
+                wo = np.array(objfn_oracle.objective_functions(want, obs[c], gw1, gw_obs[c]), dtype=np.float64)
+                if np.isfinite(wo[:7]).all():
+                    assert rel(obj[c, row, :7], wo[:7], floor=1e-9) <= 1e-6 and obj[c, row, 7] == wo[7], (tag, c, row)
+                if final:
+                    assert np.all(np.abs(fin[c, row] - f1) <= 1e-8 * np.abs(f1) + 1e-13 * np.abs(f1).max()), (tag, c, row)
+
+
+def test_randomized_batches_catchments_and_initial_states(eng):
+    run_batch_cases(eng, 4242, 20)
+
+
 def test_randomized_wide_parameter_ranges(eng):
     seen = run_wide_cases(eng, 77, 25)
     assert {'smart_fast_stiff', 'smart_fast_guard', 'smart_fast_illcond', 'smart_fast_plain'} <= seen, seen

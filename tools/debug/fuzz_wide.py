@@ -14,9 +14,10 @@ bad = 0
 for seed in range(first, first + count):
     try:
         t.run_wide_cases(engine, seed, cases)
+        t.run_batch_cases(engine, seed, cases)
         t.run_interval_cases(engine, lambda k, v: os.environ.__setitem__(k, str(v)) if v else os.environ.pop(k, None),
                              seed, cases)
-    except AssertionError:
+    except (AssertionError, Exception):
         bad += 1
         tb = traceback.format_exc().splitlines()
         where = [ln.strip() for ln in tb if ln.strip().startswith('assert')]
