@@ -852,6 +852,14 @@ def run_wide_cases(eng, seed, n_cases):
         fast = eng.run_ensemble(params, f, area, dt, W, gap, report=report, extra=extra, want_final=True)
         seen.update(k.split('[')[0] for k in fast._prepared.describe().split(' + '))
         d1, g1, f1 = so.run_batch(area, dt, T, W, rain, peva, params, extra, rtype, gap, want_final=True)
+        # the literal kernel on the same rows: the oracle's bits, whatever the parameters
+        lit_all = eng.run_ensemble(params, f, area, dt, W, gap, report=report, extra=extra, math_mode='literal',
+                                   want_final=True)
+        d0, g0, f0 = so.run_batch(area, dt, T, W, rain, peva, params, extra, rtype, gap, pow_mode=so.POW_MUL,
+                                  sum_mode=so.SUM_GPU, want_final=True)
+        assert bits_equal(lit_all.discharge.cpu().numpy(), d0) and bits_equal(lit_all.final_vars.cpu().numpy(), f0), \
+            'literal: seed %d case %d' % (seed, case)
+        assert np.array_equal(lit_all.gw.cpu().numpy(), g0, equal_nan=True), 'literal gw: seed %d case %d' % (seed, case)
         tag = 'seed %d case %d: dt=%g gap=%d T=%d W=%d n=%d %s extra=%s' % (seed, case, dt, gap, T, W, n, report,
                                                                             extra is not None)
         good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
