@@ -205,6 +205,53 @@ __device__ __forceinline__ void time_loop(const Model &m, const double2 *__restr
     time_loop_chunked(m, f, n, body, [] {});
 }
 
+// The same walk for the step loop with deferred evaporation (Model::step_lazy), which wants to know, as a lane mask
+// in scalar registers, which lanes are on the wet side of each step (ex >= 0): the kChunk compares of a chunk are
+// issued together with its excesses, ahead of the first step, so that the branches of a step depend on scalar
+// registers written long before and not on a vector compare the wave would have to wait for (-2.7 % on the bench's
+// sub-daily forcing, same-box A/B).
+// (Tried on top, measured, dropped: straight-line arms for chunks whose steps are dry -- or calm -- for every lane,
+// to spare them the taken branch per step.  The three-way join made hipcc carry the layers in two register sets and
+// copy between them: 135 v_mov_b64 in the loop instead of 61, 20.1 ms instead of 18.1.)
+template <class Model, class Calm, class ChunkEnd>
+__device__ __forceinline__ void time_loop_lazy(Model &m, const double2 *__restrict__ f, long n, Calm &&calm,
+                                               double &acc, double &num, double &den, ChunkEnd &&chunk_end)
+{
+    const long n_chunks = n / kChunk;
+    double2 cur[kChunk], nxt[kChunk];
+    if (n_chunks > 0) {
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            cur[j] = f[j];
+    }
+    for (long ch = 0; ch < n_chunks; ++ch) {
+        const long pre = (ch + 1 < n_chunks ? ch + 1 : ch) * kChunk; // last chunk: harmless re-load of itself
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            nxt[j] = f[pre + j];
+        double ex[kChunk];
+        unsigned long long wet[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            ex[j] = m.excess(cur[j].x, cur[j].y);
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            wet[j] = __builtin_amdgcn_ballot_w64(ex[j] >= 0.0);
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            m.step_lazy(ex[j], wet[j], calm(cur[j]), acc, num, den);
+        chunk_end();
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            cur[j] = nxt[j];
+    }
+    for (long t = n_chunks * kChunk; t < n; ++t) {
+        const double2 v = f[t];
+        const double ex = m.excess(v.x, v.y);
+        m.step_lazy(ex, __builtin_amdgcn_ballot_w64(ex >= 0.0), calm(v), acc, num, den);
+    }
+}
+
 // ---- pieces shared by the two launch bodies below ------------------------------------------------------------
 struct LaneCtx {
     int lane;
@@ -711,8 +758,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         auto calm = [not_ok](const double2 v) {
             return (__builtin_bit_cast(unsigned long long, v.x) | __builtin_bit_cast(unsigned long long, v.y) | not_ok) == 0;
         };
-        time_loop(m, f + wa * gap, (wb - wa) * gap,
-                  [&](const double2 v, const double ex) { m.step_lazy(ex, calm(v), s0, s1, s2); });
+        time_loop_lazy(m, f + wa * gap, (wb - wa) * gap, calm, s0, s1, s2, [] {});
         if (starts_run)
             m.begin_run();
         long k = 0, r = ra;
@@ -729,20 +775,20 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                 park_state();
         };
         if (gap % kChunk == 0) { // intervals end on chunk boundaries: one test per chunk of steps, not per step
-            time_loop_chunked(
-                m, f + ra * gap, (rb - ra) * gap,
-                [&](const double2 v, const double ex) { m.step_lazy(ex, calm(v), acc, num, den); },
-                [&]() {
-                    k += kChunk;
-                    if (__builtin_expect(k == gap, 0))
-                        report();
-                });
-        } else {
-            time_loop(m, f + ra * gap, (rb - ra) * gap, [&](const double2 v, const double ex) {
-                m.step_lazy(ex, calm(v), acc, num, den);
-                if (__builtin_expect(++k == gap, 0))
+            time_loop_lazy(m, f + ra * gap, (rb - ra) * gap, calm, acc, num, den, [&]() {
+                k += kChunk;
+                if (__builtin_expect(k == gap, 0))
                     report();
             });
+        } else { // the test after every step
+            const double2 *__restrict__ fr = f + ra * gap;
+            for (long t = 0; t < (rb - ra) * gap; ++t) {
+                const double2 v = fr[t];
+                const double ex = m.excess(v.x, v.y);
+                m.step_lazy(ex, __builtin_amdgcn_ballot_w64(ex >= 0.0), calm(v), acc, num, den);
+                if (__builtin_expect(++k == gap, 0))
+                    report();
+            }
         }
         if (last)
             m.flush_pending(); // the final state vector wants the layers as the reference leaves them

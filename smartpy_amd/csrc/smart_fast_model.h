@@ -359,8 +359,12 @@ struct FastModel {
     // A = their sum after the first pass and B = their sum after the third,
     //     interflow leak = F - A,      shallow + deep leak = A - B,
     // and B is the `tot` the next step starts from (:350), F = tot + what infiltrated.  18 + 10 + 3 instructions
-    // instead of 36 + 1 + 5; the differences cost <= 1e-13 relative on a step's flows (levels ~1e2 mm, leaks
-    // >= 1e-3 mm), unbiased.  Filling as t = l + ex; l = min(t, z); ex = t - l (3 instead of 4 per layer).
+    // instead of 36 + 1 + 5.  A difference of layer sums carries their rounding: an absolute ~1e-14 mm per step at
+    // levels of ~1e2 mm, <= 1e-11 relative on leaks >= 1e-3 mm -- and the same amount every step while the soil sits
+    // at capacity, so a reservoir of constant k collects up to k/dt of them (measured: 1.7e-11 relative on the
+    // groundwater total after 7,680 steps).  Fine for a total that is millimetres; not for the deep part on its own,
+    // which SPLIT therefore sums directly (deep_leak).  Filling as t = l + ex; l = min(t, z); ex = t - l (3 instead
+    // of 4 per layer).
     static constexpr bool kLeakBalance = SMART_FAST_LEAK_BALANCE && MERGE && !GUARD;
     static_assert(kLeakBalance || !SPLIT, "SPLIT is implemented in wet_balance()");
 
@@ -369,6 +373,19 @@ struct FastModel {
     // for a compare and a branch: a win when the SIMD has three waves to issue from (vector-ALU bound: -7 % at 1e6
     // samples), a loss when it has one or two (latency bound: +5 % at 1e5).  The launch picks (KArgs::exits).
     static constexpr bool kExits = EXITS;
+
+    // what the third leak pass is about to take from the six layers (structure.py:393-399: l s^(7-i))
+    __device__ __forceinline__ double deep_leak(double s1, double p2, double p3, double p4, double p5, double p6) const
+    {
+        return fma(l5, s1, fma(l4, p2, fma(l3, p3, fma(l2, p4, fma(l1, p5, l0 * p6)))));
+    }
+
+    __device__ __forceinline__ static double opaque_zero()
+    {
+        double x;
+        asm volatile("v_mov_b64 %0, 0" : "=v"(x)); // volatile: one of its own for each caller
+        return x;
+    }
 
     __device__ static void fill3(double &l, double &ex, double z)
     {
@@ -412,7 +429,10 @@ struct FastModel {
         l3 = fma(-l3, s1 * 0.25, l3);
         l4 = fma(-l4, s1 * 0.2, l4);
         l5 = fma(-l5, s1 * (1.0 / 6.0), l5);
-        const double after_sgw = SPLIT ? layer_sum() : 0.0; // SPLIT: the deep leak is what the third pass takes
+        // SPLIT: the deep leak is what the third pass takes, summed layer by layer like the reference does (the deep
+        // reservoir can be a thousand times smaller than the layers: a difference of layer sums would leave it their
+        // rounding, the same amount every step while the soil sits at capacity)
+        const double deep = SPLIT ? deep_leak(s1, p2, p3, p4, p5, p6) : 0.0;
         l0 = fma(-l0, p6, l0);
         l1 = fma(-l1, p5, l1);
         l2 = fma(-l2, p4, l2);
@@ -430,7 +450,7 @@ struct FastModel {
         fma_in_place(u_sgw, dec_g, xg);
         if (SPLIT) {
             fma_in_place(u_dra, dec_s, pD * rem);
-            fma_in_place(u_dgw, dec_g, after_sgw - tot);
+            fma_in_place(u_dgw, dec_g, deep);
         }
         if (kBalanceSums)
             xg_sum += xg;
@@ -610,10 +630,15 @@ struct FastModel {
     // caller's initial state could be: zero_ok).
     double pend, tot_c;
     bool zero_ok;
+    // lanes that may have something pending (SGPR pair): which side of zero a step's excess falls on is known as a
+    // lane mask a chunk of steps ahead (time_loop_masks), so whether the cascade has to run is decided on the scalar
+    // unit from masks that have long been there -- not by comparing `pend` and waiting for the answer
+    unsigned long long pend_mask;
 
     __device__ void begin_lazy(double pending)
     {
         pend = pending;
+        pend_mask = __builtin_amdgcn_ballot_w64(pending > 0.0);
         tot_c = layer_sum();
         note_capacity();
         zero_ok = over_mask == 0;
@@ -643,29 +668,41 @@ struct FastModel {
     // cost more than it saved: the arms left the states in different registers and the joins paid for it.)
     // `calm`: rain == 0 and peva == 0 for this step and zero_ok (wave-uniform, decided on the scalar unit by the
     // caller).
-    __device__ __forceinline__ void step_lazy(double ex, bool calm, double &acc, double &num, double &den)
+    // `wet`: ballot of ex >= 0 over the wavefront, worked out ahead of the step by the caller
+    __device__ __forceinline__ void step_lazy(double ex, unsigned long long wet, bool calm, double &acc, double &num,
+                                              double &den)
     {
         route_and_sum(acc, num, den);
         pend += fmax(-ex, 0.0);
-        double x_s = 0.0, x_f = 0.0, x_g = 0.0, x_dra = 0.0, x_dgw = 0.0;
-        if (ex >= 0.0) { // structure.py:359
-            // (laid out as the unlikely side: -1 %; marking the calm side unlikely as well, or materialising the three
-            // zeros below ahead of the scalar branch to spare its else block, cost 1 % and 5 %: tools/ab_variants.sh)
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(pend > 0.0) != 0, 0))
+        // (the zeros of x_s and x_f as values the compiler cannot see through: a calm step then finds them where the
+        // dry lanes' zeros are, instead of in a block of its own that sets them again, and the filling code falls
+        // through into the leaks)
+        double x_s = opaque_zero(), x_f = opaque_zero(), x_g = 0.0, x_dra = 0.0, x_dgw = 0.0;
+        // after a step the lanes with something pending are exactly the ones that were on its dry side: the cascade
+        // has to run when a lane that was dry on the previous step is wet on this one
+        const bool cascade = (pend_mask & wet) != 0;
+        pend_mask = ~wet;
+        if (__builtin_amdgcn_inverse_ballot_w64(wet)) { // structure.py:359
+            if (__builtin_expect(cascade, 0))
                 flush_pending();
             double &tot = tot_c;
             const double s1 = sz * tot;
-            double ex_in = 0.0, rem = 0.0, e_h = 0.0;
-            if (!calm) { // scalar branch: nothing to fill on a calm step (the caller folds zero_ok into `calm`)
-                e_h = ex * hz;
-                ex_in = fma(-e_h, tot, ex); // excess left after the overland share H tot/Z ex (:363-365)
-                rem = ex_in;
+            if (__builtin_expect(!calm, 1)) { // scalar branch: nothing to fill on a calm step (zero_ok is in `calm`)
+                const double e_h = ex * hz;
+                const double ex_in = fma(-e_h, tot, ex); // excess left after the overland share H tot/Z ex (:363-365)
+                double rem = ex_in;
                 fill3(l0, rem, z);
                 fill3(l1, rem, z);
                 fill3(l2, rem, z);
                 fill3(l3, rem, z);
                 fill3(l4, rem, z);
                 fill3(l5, rem, z);
+                // what the quick and the inter reservoir get from the rain itself; a calm step leaves the zeros the
+                // dry lanes use (no block of its own to set them: the fill falls through into the leaks)
+                x_f = fma(-pD, rem, ex_in);
+                x_s = fma(pD, rem, e_h * tot);
+                if (SPLIT)
+                    x_dra = pD * rem;
             }
             const double p2 = s1 * s1, p3 = p2 * s1, p4 = p2 * p2, p5 = p4 * s1, p6 = p3 * p3;
             l0 = fma(-l0, s1, l0);
@@ -681,21 +718,18 @@ struct FastModel {
             l3 = fma(-l3, s1 * 0.25, l3);
             l4 = fma(-l4, s1 * 0.2, l4);
             l5 = fma(-l5, s1 * (1.0 / 6.0), l5);
-            const double after_sgw = SPLIT ? layer_sum() : 0.0;
+            const double deep = SPLIT ? deep_leak(s1, p2, p3, p4, p5, p6) : 0.0;
             l0 = fma(-l0, p6, l0);
             l1 = fma(-l1, p5, l1);
             l2 = fma(-l2, p4, l2);
             l3 = fma(-l3, p3, l3);
             l4 = fma(-l4, p2, l4);
             l5 = fma(-l5, s1, l5);
-            x_f = (tot - after_int) + fma(-pD, rem, ex_in);
-            x_s = fma(pD, rem, e_h * tot);
+            x_f = (tot - after_int) + x_f;
             tot = layer_sum();
             x_g = after_int - tot;
-            if (SPLIT) {
-                x_dra = pD * rem;
-                x_dgw = after_sgw - tot;
-            }
+            if (SPLIT)
+                x_dgw = deep;
         }
         fma_in_place(u_ove, dec_s, x_s);
         fma_in_place(u_int, dec_f, x_f);

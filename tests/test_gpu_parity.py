@@ -29,6 +29,20 @@ def rel(a, b, floor=0.0):
     return float(np.max(r)) if r.size else 0.0
 
 
+def excess(got, want, rtol, top=None, top_frac=1e-13):
+    """Largest |got - want| / (rtol * |want| + top_frac * top); <= 1 passes.  `top` is the largest magnitude of the row
+    (default: of `want` along its last axis): a value that has drained to 1e-9 of its row's peak carries the absolute
+    rounding of the states it came from, not nine digits of its own."""
+    got, want = np.asarray(got, float), np.asarray(want, float)
+    if want.size == 0:
+        return 0.0
+    if top is None:
+        top = np.abs(want).max(axis=-1, keepdims=True) if want.ndim > 1 else np.abs(want).max()
+    with np.errstate(invalid='ignore', divide='ignore'):
+        r = np.abs(got - want) / (rtol * np.abs(want) + top_frac * top)
+    return float(np.nanmax(np.where(np.abs(got - want) == 0, 0.0, r)))
+
+
 def bits_equal(a, b):
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
@@ -870,7 +884,7 @@ def run_wide_cases(eng, seed, n_cases):
         got, top = fast.discharge.cpu().numpy()[good], np.abs(d1[good]).max(axis=1, keepdims=True)
         assert np.all(np.abs(got - d1[good]) <= REL_FAST * np.abs(d1[good]) + 1e-13 * top), tag
         ok = np.isfinite(g1[good])
-        assert rel(fast.gw.cpu().numpy()[good][ok], g1[good][ok], floor=1e-300) <= 1e-9, tag
+        assert excess(fast.gw.cpu().numpy()[good][ok], g1[good][ok], 1e-9, top=1.0) <= 1.0, tag   # a ratio in [0, 1]
         # the final row: relative 1e-8, or absolute 1e-13 of the row's largest entry -- a layer that the reference empties
         # exactly (`lvl >= deficit` false by one ulp) may keep 1e-15 mm in the other arithmetic, and the other way round
         fv, scale = fast.final_vars.cpu().numpy()[good], np.abs(f1[good]).max(axis=1, keepdims=True)
@@ -1022,18 +1036,19 @@ def run_interval_cases(eng, setenv, seed, n_cases):
             seed, case, dt, gap, T, W, n, extra is not None, slices, exits, want_final, varying)
         good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
         if good.any():
-            e = rel(fast.discharge.cpu().numpy()[good], d1[good], floor=1e-300)
-            worst = max(worst, e)
-            assert e <= REL_FAST, tag
-            ok = np.isfinite(g1[good])
-            assert rel(fast.gw.cpu().numpy()[good][ok], g1[good][ok]) <= 1e-9, tag
+            got = fast.discharge.cpu().numpy()[good]
+            assert excess(got, d1[good], REL_FAST) <= 1.0, tag
+            big = np.abs(d1[good]) > 1e-6 * np.abs(d1[good]).max(axis=1, keepdims=True)
+            worst = max(worst, rel(got[big], d1[good][big]))
+            ok = np.isfinite(g1[good])         # a ratio of sums: absolute floor of 1e-13 on a number in [0, 1]
+            assert excess(fast.gw.cpu().numpy()[good][ok], g1[good][ok], 1e-9, top=1.0) <= 1.0, tag
             want = objfn_oracle.objective_matrix(d1[good], obs, g1[good], 0.2)
             got = fast.objfn.cpu().numpy()[good]
             fin = np.isfinite(want[:, :7]).all(axis=1)
-            assert rel(got[fin, :7], want[fin, :7], floor=1e-12) <= 1e-7, tag
+            # scores are O(1) combinations of moments: one that comes out as 1e-9 has cancelled eight of its digits
+            assert excess(got[fin, :7], want[fin, :7], 1e-7, top=1.0, top_frac=1e-12) <= 1.0, tag
             if want_final:
-                fv, fs = fast.final_vars.cpu().numpy()[good], np.abs(f1[good]).max(axis=1, keepdims=True)
-                assert np.all(np.abs(fv - f1[good]) <= 1e-8 * np.abs(f1[good]) + 1e-13 * fs), tag
+                assert excess(fast.final_vars.cpu().numpy()[good], f1[good], 1e-8) <= 1.0, tag
     return worst
 
 
