@@ -85,3 +85,34 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 1e6 and 'sample' in c
     assert d['value'] > 50 * c['value']          # sanity: the GPU path is orders of magnitude ahead of the host cores
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('config, samples', [(3, 20000), (4, 40000), (5, 1000)])
+def test_bench_with_two_ranks_launched_the_way_the_driver_does(config, samples):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` on a one-GPU box: both ranks share GPU 0
+    and the collectives go through gloo (SMART_DIST_BACKEND; RCCL refuses two ranks on one device) -- the sharding,
+    gathering, barrier + max-over-ranks timing and the single JSON line are the code of the multi-GPU run."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SMART_DIST_BACKEND='gloo')
+    out = subprocess.check_output(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+         '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
+         '--warmup', '1', '--config', str(config), '--samples', str(samples), '--no-cpu-baseline', '--no-flat'],
+        cwd=ROOT, env=env, stderr=subprocess.DEVNULL, timeout=600).decode()
+    lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                   # rank 0 prints, rank 1 does not
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['value'] > 0
+    c = d['config']
+    if config == 3:         # weak: every rank its own block of the ensemble
+        assert d['scaling'] == 'weak' and c['runs_per_gpu'] == samples and c['runs_total'] == 2 * samples
+    elif config == 4:       # strong: one ensemble cut by rows
+        assert d['scaling'] == 'strong' and c['runs_total'] == samples and c['runs_per_gpu'] == samples // 2
+    else:                   # strong: 64 catchments cut by catchment
+        assert d['scaling'] == 'strong' and c['runs_total'] == 64 * samples and c['runs_per_gpu'] == 32 * samples
+    per_step = c['runs_total'] * 96432            # sample-timesteps of one step, warm-up included
+    assert abs(d['value'] - per_step / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
