@@ -29,14 +29,14 @@ def spy_rel(a, b, floor=0.0):
     return r
 
 
-def spy_excess(got, want, rtol, top=None, top_frac=1e-13):
-    r = orig_excess(got, want, rtol, top, top_frac)
+def spy_excess(got, want, rtol, top=None, top_frac=1e-13, tiny=1e-40):
+    r = orig_excess(got, want, rtol, top, top_frac, tiny)
     if r > 1.0:
         got, want = np.asarray(got, float), np.asarray(want, float)
         tp = top if top is not None else (np.abs(want).max(axis=-1, keepdims=True) if want.ndim > 1 else np.abs(want).max())
-        show('excess', r, np.abs(got - want) / (rtol * np.abs(want) + top_frac * tp), got, want)
+        show('excess', r, np.abs(got - want) / (rtol * np.abs(want) + top_frac * tp + tiny), got, want)
         if want.ndim > 1:
-            i = np.unravel_index(np.nanargmax(np.abs(got - want) / (rtol * np.abs(want) + top_frac * tp)), want.shape)[0]
+            i = np.unravel_index(np.nanargmax(np.abs(got - want) / (rtol * np.abs(want) + top_frac * tp + tiny)), want.shape)[0]
             print('  got ', got[i][:24])
             print('  want', want[i][:24])
     return r

@@ -4,7 +4,10 @@ must read 0 every time.  With `busy` as third argument a second stream keeps the
 (matrix products of varying size) while the sliced launches run: workgroups of the ensemble kernel then start in
 whatever order and on whatever CUs the competing work leaves free -- the situation the ticket scheme is for.
 
-    python tools/debug/time_slices_stress.py <n_samples> <launches> [busy]
+With `flat` the forcing varies inside the day: the step loop with deferred evaporation, whose pending demand travels
+in the hand-over.
+
+    python tools/debug/time_slices_stress.py <n_samples> <launches> [busy] [flat]
 """
 import sys, time
 sys.path.insert(0, '.')
@@ -14,11 +17,14 @@ from smartpy_amd import engine, sampling
 from smartpy_amd.parameters import Parameters
 dev = torch.device('cuda:0')
 forcing = bench.synthetic_forcing(0, True)[0]
+flat = 'flat' in sys.argv[3:]
+if flat:
+    forcing = bench.hourly_varying_forcing(forcing)
 T, W = forcing.shape[0], 8760
 ft = torch.as_tensor(forcing, device=dev)
 obs = torch.rand(T // 24, dtype=torch.float64, device=dev) + 0.5
 n, reps = int(sys.argv[1]), int(sys.argv[2])
-busy = len(sys.argv) > 3 and sys.argv[3] == 'busy'
+busy = 'busy' in sys.argv[3:]
 params = torch.as_tensor(sampling.latin_hypercube(n, Parameters().ranges, seed=11), device=dev)
 kw = dict(extra=bench.EXTRA, obs=obs, gw_obs=0.12667, want_discharge=False)
 plain = engine.prepare_ensemble(params, ft, bench.AREA, 3600.0, W, 24, time_slices=1, **kw)
@@ -47,5 +53,5 @@ for i in range(reps):
         bad += 1
 torch.cuda.synchronize()
 print('N=%d%s: %s; %d launches, %.2f ms each incl. poison + compare, %d differ, %d with a non-zero status word'
-      % (n, ' + competing stream' if busy else '', p.describe(), reps, (time.perf_counter() - t0) / reps * 1e3, bad,
+      % (n, (' sub-daily forcing' if flat else '') + (' + competing stream' if busy else ''), p.describe(), reps, (time.perf_counter() - t0) / reps * 1e3, bad,
          timeouts))
