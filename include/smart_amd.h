@@ -71,7 +71,7 @@ extern "C" {
 #define SMART_PLAN_CLASS_STIFF 0x02      /* some k*3600 < delta_sec: clamps (structure.py:429-450) and the river's */
                                          /* 95 % rule (:492-496) are reachable                                     */
 #define SMART_PLAN_CLASS_GUARD 0x04      /* S, C or Z outside those ranges: the leak guards (:383,390,397) matter  */
-#define SMART_PLAN_CLASS_ILLCOND 0x08    /* some delta_sec / (k*3600) > 2: run in the literal arithmetic           */
+#define SMART_PLAN_CLASS_ILLCOND 0x08    /* delta_sec / (RK*3600) > 2 (the river): run in the literal arithmetic   */
 #define SMART_PLAN_FORCING_PIECEWISE 0x10 /* a catchment whose forcing is constant within every report interval    */
 #define SMART_PLAN_FORCING_VARYING 0x20   /* a catchment whose forcing is not                                      */
 #define SMART_PLAN_ROWS_ORDERED 0x40       /* set by the caller (not by smart_plan_ensemble): neighbouring rows behave    */

@@ -18,7 +18,7 @@
 //     loop only if one of its lanes needs it (a wave-uniform branch outside the loop);
 //   * reservoirs that share a time constant are merged and the two sums behind the groundwater ratio come
 //     from mass balances (MERGE, below) when the caller does not ask for the final state vector;
-//   * a wavefront holding a sample with dt / k > 2, where the reference's own update amplifies rounding
+//   * a wavefront holding a sample with dt / RK > 2, where the reference's own river update amplifies rounding
 //     differences, runs the literal model (smart_literal_model.h) instead;
 //   * summary reports over forcing that is constant within the report interval (daily data spread over the hours,
 //     the reference's own input pipeline) advance one interval at a time (run_ensemble_merged in smart_device.h):
@@ -816,9 +816,16 @@ __device__ inline int wave_class(const KArgs &a, long block, long catchment)
     const double dt = a.dt;
     const bool stiff = !(p[6] * 3600.0 >= dt && p[7] * 3600.0 >= dt && p[8] * 3600.0 >= dt && p[9] * 3600.0 >= dt);
     const bool guard = !(p[4] >= 0.0 && p[4] <= 0.5 && p[1] >= 0.0 && p[5] > 0.0);
-    // dt / k > 2: the reference's explicit update multiplies a perturbation by |1 - dt/k| > 1 every step
-    const double half = 0.5 * dt;
-    const bool unstable = !(p[6] * 3600.0 >= half && p[7] * 3600.0 >= half && p[8] * 3600.0 >= half && p[9] * 3600.0 >= half);
+    // dt / RK > 2: the river's explicit update multiplies a perturbation by |1 - dt/RK| > 1 on every step its 95 % rule
+    // does not fire, and the rule itself only damps it to 5 % (structure.py:490-498) -- between dt/RK = 10 and 20 the
+    // two alternate without settling and the last bit of the inflow decides the discharge.  The five catchment
+    // reservoirs are no concern at any dt/k: their clamp at zero (:429-450) forgets the perturbation altogether
+    // (measured to dt/k = 200: <= 3e-10 of the reference; tools/debug/illcond_err.py).
+#ifdef SMART_NO_ILLCOND // measurement builds only (tools/debug/illcond_err.py): what the fast arithmetic does on such rows
+    const bool unstable = false;
+#else
+    const bool unstable = !(p[9] * 3600.0 >= 0.5 * dt);
+#endif
     const bool any_stiff = __builtin_amdgcn_ballot_w64(stiff) != 0;
     const bool any_guard = __builtin_amdgcn_ballot_w64(guard) != 0;
     const bool any_unstable = __builtin_amdgcn_ballot_w64(unstable) != 0;

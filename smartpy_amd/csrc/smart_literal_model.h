@@ -7,9 +7,9 @@
 // ((s*s)*s)*... .  With the CPU oracle configured the same way this model is bit-identical to it.
 //
 // Used by the literal kernel (smart_literal.hip) and, inside the fast kernel, for wavefronts that hold a sample
-// with dt / k > 2 on one of its four reservoir constants: there the reference's explicit Euler update amplifies
-// any rounding difference by |1 - dt/k| per step, so only the reference's own operation order reproduces its
-// discharge ("Ill-conditioned samples").
+// with dt / RK > 2: there the river's explicit Euler update amplifies any rounding difference by |1 - dt/RK| on
+// every step its 95 % rule does not fire, so only the reference's own operation order reproduces its discharge
+// ("Ill-conditioned samples").
 #pragma once
 
 #include "smart_device.h"

@@ -453,17 +453,18 @@ def _synthetic_forcing(catchment, hourly):
 
 def test_config2_daily_1e4_samples(eng, example):
     """BASELINE config 2: 1e4 LHS samples, daily 10-yr synthetic forcing.  With daily steps the default ranges
-    reach dt / k > 2 (RK < 12 h: 11.6 % of the rows, SK < 12 h: 4.6 %): there the reference's explicit update
-    multiplies any rounding difference by |1 - dt/k| (up to 23) per step, so a re-ordered computation drifts by
-    ~1e-5 from it.  Such rows are computed with the reference's own operation order inside the fast kernel (the
-    engine groups the rows by variant, so that only their wavefronts pay for it): bit-identical to the literal
-    kernel; all other rows stay within the fast tolerance; and the result of a row does not depend on its
-    neighbours (bit-identical under a permutation of the batch)."""
+    reach dt / RK > 2 (RK < 12 h: 11.6 % of the rows): there the river's explicit update multiplies any rounding
+    difference by |1 - dt/RK| (up to 23) on the steps its 95 % rule does not fire, so a re-ordered computation drifts
+    by 1e-5 and more from the reference.  Such rows are computed with the reference's own operation order inside the
+    fast kernel (the engine groups the rows by variant, so that only their wavefronts pay for it): bit-identical to
+    the literal kernel; all other rows -- those with dt / SK > 2 among them (4.6 %: the catchment reservoirs' clamp
+    at zero forgets a perturbation) -- stay within the fast tolerance; and the result of a row does not depend on
+    its neighbours (bit-identical under a permutation of the batch)."""
     import torch
     rain, peva, _ = _synthetic_forcing(0, hourly=False)
     f = forcing_of(rain, peva)
     params = lhs_oracle.lhs_params(10000, seed=2718)
-    unstable = (params[:, 6:10] * 3600.0 < 43200.0).any(axis=1)
+    unstable = params[:, 9] * 3600.0 < 43200.0
     assert 0.1 < unstable.mean() < 0.3
     cls = eng.variant_classes(torch.from_numpy(params), 86400.0).numpy()
     assert np.array_equal(cls == 3, unstable) and (cls == 1).sum() > 500 and (cls == 0).sum() > 5000
@@ -479,9 +480,10 @@ def test_config2_daily_1e4_samples(eng, example):
     assert bits_equal(got_lit, dis) and bits_equal(lit.gw.cpu().numpy(), gw)
     ref, gw_ref, fin_ref = so.run_batch(example['area'], 86400.0, 3653, 365, rain, peva, params, example['extra'],
                                         so.REPORT_SUMMARY, 1, want_final=True)          # reference-exact (libm pow)
-    assert rel(got[~unstable], ref[~unstable], floor=1e-300) <= REL_FAST
-    assert rel(out.gw.cpu().numpy()[~unstable], gw_ref[~unstable]) <= 1e-10
-    assert rel(out.final_vars.cpu().numpy()[~unstable, 7:], fin_ref[~unstable, 7:], floor=1e-290) <= 1e-8
+    assert excess(got[~unstable], ref[~unstable], REL_FAST) <= 1.0
+    assert excess(out.gw.cpu().numpy()[~unstable], gw_ref[~unstable], 1e-10, top=1.0) <= 1.0
+    assert excess(out.final_vars.cpu().numpy()[~unstable], fin_ref[~unstable], 1e-8) <= 1.0
+    assert (params[~unstable, 6] * 3600.0 < 43200.0).sum() > 300          # rows with dt / SK > 2 are among them
     assert rel(got, ref, floor=1e-300) <= 1e-3         # ill-conditioned rows: whatever libm's last bit does to them
     # permutation of the batch: bit-identical row by row, although the wavefronts are composed differently
     perm = np.random.default_rng(3).permutation(len(params))
@@ -639,7 +641,7 @@ def test_randomized_configurations(eng):
         assert bits_equal(lit.final_vars.cpu().numpy(), f0), tag
         fast = eng.run_ensemble(params, f, area, dt, W, gap, report=report, extra=extra)
         d1, g1, _ = so.run_batch(area, dt, T, W, rain, peva, params, extra, rtype, gap)
-        good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
+        good = ~(params[:, 9] * 3600.0 < 0.5 * dt)          # dt / RK <= 2: not the literal model's
         if good.any():
             e = rel(fast.discharge.cpu().numpy()[good], d1[good], floor=1e-300)
             worst_fast = max(worst_fast, e)
@@ -686,7 +688,7 @@ def test_initial_states_above_capacity(eng, example, monkeypatch):
                                    want_final=final)
             tag = '%s %s exits=%s final=%s varying=%s: %s' % ('hourly' if hourly else 'daily', report, exits, final,
                                                              varying, out._prepared.describe())
-            good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
+            good = ~(params[:, 9] * 3600.0 < 0.5 * dt)          # dt / RK <= 2: not the literal model's
             for row in np.flatnonzero(good)[:40]:
                 full = np.concatenate([np.zeros(7), init[row]])
                 want, gw, fin = so.all_steps(area, dt, T, r, peva, params[row], full, rtype, gap)
@@ -734,7 +736,7 @@ def test_parameter_and_forcing_corner_cases(eng, example):
             d1, g1, f1 = so.run_batch(example['area'], dt, T, W, rain, peva, params, example['extra'], rtype, gap,
                                       want_final=True)
             tag = '%s, %s %s: %s' % (name, 'hourly' if hourly else 'daily', report, out._prepared.describe())
-            good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
+            good = ~(params[:, 9] * 3600.0 < 0.5 * dt)          # dt / RK <= 2: not the literal model's
             assert excess(out.discharge.cpu().numpy()[good], d1[good], REL_FAST) <= 1.0, tag
             gg, ok = out.gw.cpu().numpy()[good], np.isfinite(g1[good])
             assert np.all(np.abs(gg[ok] - g1[good][ok]) <= 1e-9), tag
@@ -801,7 +803,7 @@ def run_batch_cases(eng, seed, n_cases):
             p = params[c if per_catchment else 0]
             rows = rng.choice(n, min(n, 6), replace=False)
             for row in rows:
-                if (p[row, 6:10] * 3600.0 < 0.5 * dt).any():
+                if p[row, 9] * 3600.0 < 0.5 * dt:
                     continue
                 rain, peva = forcing[c, :, 0].copy(), forcing[c, :, 1].copy()
                 if use_initial:
@@ -874,7 +876,7 @@ def run_wide_cases(eng, seed, n_cases):
         assert np.array_equal(lit_all.gw.cpu().numpy(), g0, equal_nan=True), 'literal gw: seed %d case %d' % (seed, case)
         tag = 'seed %d case %d: dt=%g gap=%d T=%d W=%d n=%d %s extra=%s' % (seed, case, dt, gap, T, W, n, report,
                                                                             extra is not None)
-        good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
+        good = ~(params[:, 9] * 3600.0 < 0.5 * dt)          # dt / RK <= 2: not the literal model's
         if good.sum() < 5:
             continue
         # relative 1e-9, or absolute 1e-13 of the row's largest discharge: a catchment that has run dry carries flows of
@@ -1030,7 +1032,7 @@ def run_interval_cases(eng, setenv, seed, n_cases):
         d1, g1, f1 = so.run_batch(area, dt, T, W, rain, peva, params, extra, so.REPORT_SUMMARY, gap, want_final=True)
         tag = 'seed %d case %d: dt=%g gap=%d T=%d W=%d n=%d extra=%s slices=%r exits=%r final=%r varying=%r' % (
             seed, case, dt, gap, T, W, n, extra is not None, slices, exits, want_final, varying)
-        good = ~(params[:, 6:10] * 3600.0 < 0.5 * dt).any(axis=1)
+        good = ~(params[:, 9] * 3600.0 < 0.5 * dt)          # dt / RK <= 2: not the literal model's
         if good.any():
             got = fast.discharge.cpu().numpy()[good]
             assert excess(got, d1[good], REL_FAST) <= 1.0, tag
