@@ -399,6 +399,54 @@ def test_public_surface_has_every_name_of_the_reference():
 
 
 # ---- sharding arithmetic -----------------------------------------------------------------------------------------
+def test_rows_are_classified_and_grouped_by_arithmetic_variant():
+    """engine.variant_classes mirrors wave_class() of csrc/smart_fast_model.h: 1 stiff (some k*3600 < dt), 2 guarded
+    (S outside [0, 0.5], C < 0, Z <= 0), 3 ill-conditioned (dt / RK > 2 -- the river constant only: the catchment
+    reservoirs' clamp at zero forgets a perturbation); the most demanding wins.  _variant_grouping
+    puts each class into whole wavefronts of 64 (padded with copies of its last row), keeps every row, and with
+    sort_rows orders a class by T (64 bins), then S * Z."""
+    import torch
+    from smartpy_amd import engine
+    from oracle import lhs_oracle
+    p = lhs_oracle.lhs_params(3000, seed=9)
+    dt = 86400.0
+    p[:40, 6] = 0.5                 # dt / SK = 48: stiff, NOT ill-conditioned
+    p[:40, 9] = 50.0
+    p[40:60, 9] = 11.9              # dt / RK just above 2
+    p[60:70, 9] = 12.0              # exactly 2: still the fast arithmetic (its STIFF variant: RK * 3600 < dt)
+    p[60:70, 6:9] = 100.0
+    p[70:80, 4] = 0.6               # S > 0.5: guarded ...
+    p[80:90, 4], p[80:90, 9] = 0.6, 1.0     # ... unless the river sends the row to the literal model anyway
+    cls = engine.variant_classes(torch.from_numpy(p), dt).numpy()
+    k = p[:, 6:10] * 3600.0
+    want = np.zeros(len(p), dtype=np.int64)
+    want[(k < dt).any(axis=1)] = 1
+    want[~((p[:, 4] >= 0) & (p[:, 4] <= 0.5) & (p[:, 1] >= 0) & (p[:, 5] > 0))] = 2
+    want[k[:, 3] < 0.5 * dt] = 3
+    assert np.array_equal(cls, want)
+    assert (cls[:40] == 1).all() and (cls[40:60] == 3).all() and (cls[60:70] == 1).all()
+    assert (cls[70:80][k[70:80, 3] >= 0.5 * dt] == 2).all() and (cls[80:90] == 3).all()
+    assert engine.variant_classes(torch.from_numpy(p), 3600.0).max() == 2      # hourly steps: nothing stiff by default
+
+    for sort_rows in (False, True):
+        gather, inverse = engine._variant_grouping(torch.from_numpy(p), dt, sort_rows)
+        gather, inverse = gather.numpy(), inverse.numpy()
+        assert len(gather) % 64 == 0 and np.array_equal(gather[inverse], np.arange(len(p)))     # every row, once
+        g = cls[gather]
+        assert np.all(np.diff(g) >= 0)                                                           # class by class
+        for c in np.unique(cls):
+            assert (g == c).sum() % 64 == 0 and (g == c).sum() - (cls == c).sum() < 64          # whole wavefronts
+        if sort_rows:
+            rows = gather[g == 0]
+            t = p[rows, 0]
+            bins = np.minimum(np.floor((t - t.min()) / (t.max() - t.min()) * 64), 63)
+            assert np.all(np.diff(bins) >= 0)
+            first = rows[bins == bins[0]]
+            assert np.all(np.diff(p[first, 4] * p[first, 5]) >= 0)
+    one = engine._variant_grouping(torch.from_numpy(p[cls == 0][:500]), dt, False)
+    assert one is None                                        # a single class and no ordering asked for: rows as drawn
+
+
 def test_shard_bounds_cover_the_rows_exactly():
     from smartpy_amd.distributed import shard_bounds, shard_counts
     for n in (0, 1, 7, 8, 9, 100000, 1000000):
