@@ -301,6 +301,13 @@ struct FastModel {
         asm("v_fma_f64 %0, %0, %1, %2" : "+v"(y) : "v"(a), "v"(x));
     }
 
+    // sum += y; y = y * a + x -- as one unit, so that the scheduler cannot move the update ahead of the sum and then
+    // keep y's old value alive in a second register (a v_mov_b64 per step on the loop's back-edge)
+    __device__ static void sum_then_fma_in_place(double &sum, double &y, double a, double x)
+    {
+        asm("v_add_f64 %0, %0, %1\n\tv_fma_f64 %1, %1, %2, %3" : "+v"(sum), "+v"(y) : "v"(a), "v"(x));
+    }
+
 
     // wet branch of structure.py:359-399 for the lanes that are active
     __device__ __forceinline__ void wet_lanes(double ex)
@@ -527,11 +534,16 @@ struct FastModel {
         if (USE_UP && MERGE && !STIFF && kBalanceSums) {
             // the common case spelled out so that the river's old value is used up before it is updated in place (the
             // general form below keeps it in a second register and pays a v_mov_b64 per step for it)
-            acc += u_riv;
             q_out = u_riv;
             q_gw = cq_g * u_sgw; // (these two: raw reports only -- dead code in the kernels of summary reports)
             q_in = fma(cq_s, u_ove, fma(cq_f, u_int, q_gw));
-            fma_in_place(u_riv, om_ar, fma(car_s, u_ove, fma(car_f, u_int, car_g * u_sgw)));
+            const double y = fma(car_s, u_ove, fma(car_f, u_int, car_g * u_sgw));
+            if (kExits) { // the kernel with exits needs the two welded together (-1.4 %), the straight-line one is
+                sum_then_fma_in_place(acc, u_riv, om_ar, y); // better off scheduling them itself (welded: +0.9 %)
+            } else {
+                acc += u_riv;
+                fma_in_place(u_riv, om_ar, y);
+            }
             return;
         }
         if (MERGE) {
