@@ -523,24 +523,21 @@ struct FastModel {
     // River reservoir, outflow sums and the three running sums of the caller.  Called from inside BOTH branches of
     // the step: these ~10 instructions are independent of the soil layers, and placed in the same basic block as
     // the serial fill / evaporation chains they fill the issue slots those chains leave empty.
-    // USE_UP: take the river's old value before updating it in place (below) -- worth 1.4 % to the interval engine's
-    // straight-line wet steps, and -0.6 % to the step loop, which therefore opts out (same-box A/B)
-    template <bool USE_UP = true>
     __device__ __forceinline__ void route_and_sum(double &acc, double &num, double &den)
     {
         // outflows of this step are the reservoir states at its start (structure.py:427, :487)
         double q_r = u_riv;
         double u_new;
-        if (USE_UP && MERGE && !STIFF && kBalanceSums) {
+        if (MERGE && !STIFF && kBalanceSums) {
             // the common case spelled out so that the river's old value is used up before it is updated in place (the
             // general form below keeps it in a second register and pays a v_mov_b64 per step for it)
             q_out = u_riv;
             q_gw = cq_g * u_sgw; // (these two: raw reports only -- dead code in the kernels of summary reports)
             q_in = fma(cq_s, u_ove, fma(cq_f, u_int, q_gw));
             const double y = fma(car_s, u_ove, fma(car_f, u_int, car_g * u_sgw));
-            if (kExits) { // the kernel with exits needs the two welded together (-1.4 %), the straight-line one is
-                sum_then_fma_in_place(acc, u_riv, om_ar, y); // better off scheduling them itself (welded: +0.9 %)
-            } else {
+            if (kExits) { // the kernels with branches in the step (exits; the step loop) need the two welded together
+                sum_then_fma_in_place(acc, u_riv, om_ar, y); // (-1.4 %, -2.3 %); the straight-line interval kernel is
+            } else {                                         // better off scheduling them itself (welded: +0.9 %)
                 acc += u_riv;
                 fma_in_place(u_riv, om_ar, y);
             }
@@ -697,7 +694,7 @@ struct FastModel {
     __device__ __forceinline__ void step_lazy(double ex, unsigned long long wet, bool calm, double &acc, double &num,
                                               double &den)
     {
-        route_and_sum<false>(acc, num, den);
+        route_and_sum(acc, num, den);
         pend += fmax(-ex, 0.0);
         // (the zeros of x_s and x_f as values the compiler cannot see through: a calm step then finds them where the
         // dry lanes' zeros are, instead of in a block of its own that sets them again, and the filling code falls
