@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SMART_AMD_ABI_VERSION 3
+#define SMART_AMD_ABI_VERSION 4
 
 /* report_type, as structure.py:65-70 maps report='summary' / 'raw' */
 #define SMART_REPORT_SUMMARY 1
@@ -73,7 +73,10 @@ extern "C" {
 #define SMART_PLAN_CLASS_GUARD 0x04      /* S, C or Z outside those ranges: the leak guards (:383,390,397) matter  */
 #define SMART_PLAN_CLASS_ILLCOND 0x08    /* delta_sec / (RK*3600) > 2 (the river): run in the literal arithmetic   */
 #define SMART_PLAN_FORCING_PIECEWISE 0x10 /* a catchment whose forcing is constant within every report interval    */
-#define SMART_PLAN_FORCING_VARYING 0x20   /* a catchment whose forcing is not                                      */
+#define SMART_PLAN_FORCING_VARYING 0x20   /* a catchment whose forcing varies from step to step                    */
+#define SMART_PLAN_FORCING_RUNS 0x80      /* a catchment whose forcing is constant over runs of k steps, k >= 2 a  */
+                                          /* divisor of the report gap smaller than it (6-hourly data in an hourly  */
+                                          /* run with daily reports, timeframe.py:167-186): interval engine per run */
 #define SMART_PLAN_ROWS_ORDERED 0x40       /* set by the caller (not by smart_plan_ensemble): neighbouring rows behave    */
                                            /* alike -- ordered by T, then by S*Z, as smartpy_amd/engine.py does when no   */
                                            /* discharge matrix is stored.  Wave-uniform early exits then pay off sooner.  */

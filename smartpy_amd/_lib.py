@@ -13,10 +13,10 @@ LIB_PATH = os.environ.get('SMART_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libsm
 
 REPORT_SUMMARY, REPORT_RAW = 1, 2
 MATH_LITERAL, MATH_FAST = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 PLAN_VALID = 0x100
 PLAN_CLASS_BITS = {0: 0x01, 1: 0x02, 2: 0x04, 3: 0x08}     # regular, stiff, guard, ill-conditioned
-PLAN_FORCING_PIECEWISE, PLAN_FORCING_VARYING = 0x10, 0x20
+PLAN_FORCING_PIECEWISE, PLAN_FORCING_VARYING, PLAN_FORCING_RUNS = 0x10, 0x20, 0x80
 PLAN_ROWS_ORDERED = 0x40
 STATUS_SLICE_TIMEOUT, STATUS_STALE_PLAN = 0x1, 0x2
 

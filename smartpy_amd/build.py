@@ -21,6 +21,7 @@ UNITS = {
     # arithmetic (missing observations are tested on their bit pattern), which spares the sNaN-quieting
     # `v_max_f64 x, x, x` hipcc otherwise puts in front of fmin / fmax (-1.2 % kernel time, A/B measured)
     'smart_fast_intervals.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
+    'smart_fast_runs.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
     'smart_fast_steps.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
     'smart_fast_guarded.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
     'smart_capi.hip': [],

@@ -181,19 +181,17 @@ __global__ __launch_bounds__(WX *WR *kWave) void smart_objfn_matrix(long N, long
 }
 
 // ---- small kernels around the launch -------------------------------------------------------------------------
-// The piecewise-constant question (interval engine or step loop?) is answered once per catchment, by the whole chip,
-// before the ensemble kernels start.  not_pc[c] is zeroed by smart_workspace_reset; any step that differs from the
-// first step of its report interval sets it.
-__global__ void smart_forcing_scan(const double2 *__restrict__ forcing, long T, long gap, int *not_pc)
+// What kind of forcing (constant over the report interval, over shorter runs, varying; sane values) is answered once
+// per catchment, by the whole chip, before the ensemble kernels start.  fflags[c] is zeroed by smart_workspace_reset;
+// see forcing_flags_of_step (smart_device.h) for the bits.
+__global__ void smart_forcing_scan(KArgs a, const double2 *__restrict__ forcing)
 {
-    const double2 *__restrict__ f = forcing + (long)blockIdx.y * T;
-    bool same = true;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (long)gridDim.x * blockDim.x) {
-        const double2 v = f[t], h = f[(t / gap) * gap];
-        same = same && same_bits(v.x, h.x) && same_bits(v.y, h.y);
-    }
-    if (__builtin_amdgcn_ballot_w64(!same) != 0 && (threadIdx.x & (kWave - 1)) == 0)
-        __hip_atomic_store(not_pc + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double2 *__restrict__ f = forcing + (long)blockIdx.y * a.T;
+    int bad = 0;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < a.T; t += (long)gridDim.x * blockDim.x)
+        bad |= forcing_flags_of_step(a, f, t);
+    if (bad)
+        __hip_atomic_fetch_or(a.fflags + blockIdx.y, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Zeroes the header (status word, tickets), the forcing flags and the slice counters.  A kernel rather than
@@ -218,12 +216,17 @@ __global__ __launch_bounds__(kWave) void smart_classify_rows(KArgs a)
         __hip_atomic_fetch_or(a.hdr + kHdrPlan, 1 << cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void smart_classify_forcing(const int *not_pc, long n_catch, int *hdr)
+__global__ void smart_classify_forcing(KArgs a, int *hdr)
 {
     const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_catch)
-        __hip_atomic_fetch_or(hdr + kHdrPlan, not_pc[c] ? SMART_PLAN_FORCING_VARYING : SMART_PLAN_FORCING_PIECEWISE,
+    if (c < a.n_catch) {
+        const int kind = forcing_kind(a, a.fflags[c]);
+        __hip_atomic_fetch_or(hdr + kHdrPlan,
+                              kind == kForcingIntervals ? SMART_PLAN_FORCING_PIECEWISE
+                                                        : (kind == kForcingRuns ? SMART_PLAN_FORCING_RUNS
+                                                                                : SMART_PLAN_FORCING_VARYING),
                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- per-device context: what the library caches about a device, and the streams a multi-kernel launch forks onto
@@ -261,12 +264,15 @@ static const void *fast_kernel(FastKernel k)
         return f;
     if (const void *f = fast_kernel_steps(k))
         return f;
+    if (const void *f = fast_kernel_runs(k))
+        return f;
     return fast_kernel_guarded(k);
 }
 
 static const char *const kFastKernelNames[kNumFastKernels] = {
     "smart_fast_intervals_exits", "smart_fast_intervals", "smart_fast_intervals_states", "smart_fast_steps",
-    "smart_fast_steps_states", "smart_fast_plain", "smart_fast_stiff", "smart_fast_guard", "smart_fast_illcond"};
+    "smart_fast_steps_states", "smart_fast_plain", "smart_fast_stiff", "smart_fast_guard", "smart_fast_illcond",
+    "smart_fast_runs_exits", "smart_fast_runs", "smart_fast_runs_states"};
 
 // dynamic LDS that lets exactly `per_cu` workgroups of kernel k be resident on a CU (0: no such size); d->mu held
 static size_t lds_for_residency(DeviceCtx *d, FastKernel k, int per_cu)
@@ -402,7 +408,7 @@ static int plan_time_slices(const SmartEnsemble *e, int n_simd, int *per_simd, d
 
 // the pieces of e->workspace
 struct Workspace {
-    int *hdr = nullptr, *not_pc = nullptr;
+    int *hdr = nullptr, *fflags = nullptr;
     double *stats = nullptr;
     char *slices = nullptr;
     size_t slice_room = 0;
@@ -416,7 +422,7 @@ static Workspace carve(const SmartEnsemble *e)
         return w;
     char *base = (char *)e->workspace;
     w.hdr = (int *)base;
-    w.not_pc = w.hdr + kHdrInts;
+    w.fflags = w.hdr + kHdrInts;
     if ((size_t)e->workspace_bytes >= hb + sb) {
         w.stats = sb ? (double *)(base + hb) : nullptr;
         w.slices = base + hb + sb;
@@ -456,7 +462,15 @@ static KArgs kernel_args(const SmartEnsemble *e, const Workspace &w)
     a.n_blocks = (a.N + kWave - 1) / kWave;
     a.seg_blocks = a.n_blocks * a.n_catch;
     a.hdr = w.hdr;
-    a.not_pc = nullptr;
+    a.fflags = nullptr;
+    // the run lengths the forcing is tested for: divisors of the report gap, largest first, down to 2
+    if (a.report_type == SMART_REPORT_SUMMARY && a.gap >= 2 && a.gap <= 0x7fffffff)
+        for (long d = a.gap; d >= 2 && a.n_div < kMaxDiv; --d)
+            if (a.gap % d == 0) {
+                a.div[a.n_div++] = (int)d;
+                if (d > 4096 && a.n_div >= 2)
+                    d = d / 2 + 1; // (a gap in the thousands: no need to walk every candidate down from gap / 2)
+            }
     return a;
 }
 
@@ -467,10 +481,11 @@ static void reset_workspace(const Workspace &w, long n_catch, int *flags, long n
                        n_flags);
 }
 
-static void scan_forcing(const SmartEnsemble *e, const Workspace &w, hipStream_t s)
+static void scan_forcing(const SmartEnsemble *e, KArgs a, const Workspace &w, hipStream_t s)
 {
-    hipLaunchKernelGGL(smart_forcing_scan, dim3(64, (unsigned)e->n_catchments), dim3(256), 0, s,
-                       reinterpret_cast<const double2 *>(e->forcing), (long)e->n_steps, (long)e->report_gap, w.not_pc);
+    a.fflags = w.fflags;
+    hipLaunchKernelGGL(smart_forcing_scan, dim3(64, (unsigned)e->n_catchments), dim3(256), 0, s, a,
+                       reinterpret_cast<const double2 *>(e->forcing));
 }
 
 struct Launch {
@@ -501,7 +516,7 @@ static int decide(const SmartEnsemble *e, const DeviceCtx *d, const Workspace &w
 {
     Decision &x = *out;
     x.intervals = e->report_type == SMART_REPORT_SUMMARY && e->report_gap >= 2; // the merged summary kernels apply
-    const int plan = (e->plan & SMART_PLAN_VALID) ? e->plan : 0x3f;
+    const int plan = (e->plan & SMART_PLAN_VALID) ? e->plan : (0x3f | SMART_PLAN_FORCING_RUNS);
     x.n_seg = plan_time_slices(e, d->n_simd, &x.per_simd, &x.load);
     // the hand-over buffer of a time-sliced launch sits behind the observation statistics in the caller's workspace;
     // a workspace without room for it means a plain launch
@@ -521,6 +536,10 @@ static int decide(const SmartEnsemble *e, const DeviceCtx *d, const Workspace &w
             if (plan & SMART_PLAN_FORCING_PIECEWISE) {
                 x.todo[x.n_todo++] = {e->final_vars ? kIntervalsStates : (x.exits ? kIntervalsExits : kIntervals), true};
                 x.pc_mask |= 1;
+            }
+            if (plan & SMART_PLAN_FORCING_RUNS) {
+                x.todo[x.n_todo++] = {e->final_vars ? kRunsStates : (x.exits ? kRunsExits : kRuns), true};
+                x.pc_mask |= 4;
             }
             if (plan & SMART_PLAN_FORCING_VARYING) {
                 x.todo[x.n_todo++] = {e->final_vars ? kStepsStates : kSteps, true};
@@ -587,8 +606,8 @@ static int run(const SmartEnsemble *e)
     if (w.hdr) {
         reset_workspace(w, e->n_catchments, a_sliced.seg_flag, n_seg > 1 ? a.seg_blocks : 0, s);
         if (x.intervals && (x.class_mask & SMART_PLAN_CLASS_REGULAR)) {
-            scan_forcing(e, w, s);
-            a.not_pc = a_sliced.not_pc = w.not_pc;
+            scan_forcing(e, a, w, s);
+            a.fflags = a_sliced.fflags = w.fflags;
         }
     }
 
@@ -697,15 +716,16 @@ static int make_plan(const SmartEnsemble *e, int32_t *plan)
     reset_workspace(w, e->n_catchments, nullptr, 0, s);
     hipLaunchKernelGGL(smart_classify_rows, dim3((unsigned)a.n_blocks, (unsigned)e->n_catchments), dim3(kWave), 0, s, a);
     if (e->report_type == SMART_REPORT_SUMMARY && e->report_gap >= 2) {
-        scan_forcing(e, w, s);
+        scan_forcing(e, a, w, s);
+        a.fflags = w.fflags;
         hipLaunchKernelGGL(smart_classify_forcing, dim3((unsigned)((e->n_catchments + 255) / 256)), dim3(256), 0, s,
-                           w.not_pc, (long)e->n_catchments, w.hdr);
+                           a, w.hdr);
     }
     HIP_TRY(hipGetLastError());
     int bits = 0;
     HIP_TRY(hipMemcpyAsync(&bits, w.hdr + kHdrPlan, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *plan = SMART_PLAN_VALID | (bits & 0x3f);
+    *plan = SMART_PLAN_VALID | (bits & (0x3f | SMART_PLAN_FORCING_RUNS));
     return SMART_OK;
 }
 

@@ -11,7 +11,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace smart {
+
+constexpr int kMaxDiv = 12;
+constexpr int kForcingInsane = 1 << 30; // some value of the catchment's forcing is negative, -0, infinite or NaN
 
 struct KArgs {
     long N, T, W, gap, R, first_len; // first_len: steps in report interval 0 (raw mode with T % gap != 0)
@@ -36,10 +41,14 @@ struct KArgs {
     // which kernels this call launches (include/smart_amd.h, SMART_PLAN_*): a workgroup that meets a block nobody will
     // run (a stale plan) leaves SMART_STATUS_STALE_PLAN in the status word instead of a silent hole in the outputs
     int class_mask = 0xf;     // bit c: the kernel of arithmetic class c (wave_class) has been launched
-    int pc_mask = 0x3;        // bit 0: the interval engine (piecewise-constant forcing), bit 1: the step loop
+    int pc_mask = 0x7;        // bit 0: the interval engine (forcing constant over each report interval), bit 1: the
+                              // step loop, bit 2: the run engine (constant over runs of k steps, k a divisor of the gap)
     // workspace header (null without a workspace: no status word, no time slices, every wavefront scans the forcing)
     int *hdr = nullptr;       // [kHdrInts]: status word, ticket counters of the sliced kernels
-    int *not_pc = nullptr;    // [C]: forcing of catchment c is NOT piecewise constant over the report interval
+    int *fflags = nullptr;    // [C]: forcing flags of catchment c (forcing_flags_of_step below), from smart_forcing_scan
+    // run lengths a catchment's forcing is tested for: the divisors of the report gap, largest first (div[0] = gap)
+    int n_div = 0;
+    int div[kMaxDiv] = {};
     // time-sliced launch (n_seg > 1): see "time-sliced launch" below
     int n_seg = 1;            // workgroups per block of 64 samples, each advancing one slice of the time axis
     long n_catch = 1;         // C
@@ -65,6 +74,9 @@ __device__ __forceinline__ void raise_status(const KArgs &a, int bit)
 
 #ifndef SMART_NT_STORE
 #define SMART_NT_STORE 0
+#endif
+#ifndef SMART_STEP_ARMS
+#define SMART_STEP_ARMS 1 // the step loop of sub-daily forcing as three asm arms (0: the compiled step_lazy of round 2)
 #endif
 
 constexpr int kWave = 64;
@@ -250,6 +262,42 @@ __device__ __forceinline__ void time_loop_lazy(Model &m, const double2 *__restri
         const double ex = m.excess(v.x, v.y);
         m.step_lazy(ex, __builtin_amdgcn_ballot_w64(ex >= 0.0), calm(v), acc, num, den);
     }
+}
+
+// The walk of the instruction-level step loop (Model::step_arms: one of three asm arms per step, picked on the scalar
+// unit from the step's own forcing).  Same double-buffered scalar loads; the loop counter is 32 bits wide (there is no
+// 64-bit scalar less-than: hipcc went through a vector compare for it).
+template <bool QUICK, class Model, class ChunkEnd>
+__device__ __forceinline__ void time_loop_arms(Model &m, const double2 *__restrict__ f, long n, double &acc,
+                                               ChunkEnd &&chunk_end)
+{
+    const int n_chunks = (int)(n / kChunk);
+    double2 cur[kChunk], nxt[kChunk];
+    if (n_chunks > 0) {
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            cur[j] = f[j];
+        // wait for the first chunk HERE: left pending into the loop, its s_waitcnt lands at the top of the body, behind
+        // the request for the next chunk -- and then waits for that one too, every iteration
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            asm volatile("" ::"s"(cur[j].x), "s"(cur[j].y));
+    }
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int pre = (ch + 1 < n_chunks ? ch + 1 : ch) * kChunk; // last chunk: harmless re-load of itself
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            nxt[j] = f[pre + j];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            m.template step_arms<QUICK>(cur[j], acc);
+        chunk_end();
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            cur[j] = nxt[j];
+    }
+    for (long t = (long)n_chunks * kChunk; t < n; ++t)
+        m.template step_arms<QUICK>(f[t], acc);
 }
 
 // ---- pieces shared by the two launch bodies below ------------------------------------------------------------
@@ -482,21 +530,64 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
 // ---- piecewise-constant forcing ------------------------------------------------------------------------------
 // Is the forcing of every report interval one value repeated `gap` times?  (Hourly steps disaggregated from daily
 // data: timeframe.py:167-186 splits each daily value equally over its 24 steps -- the reference's shipped example,
-// its own regression test and the synthetic benchmark forcing all have this shape.)  Every wavefront answers the
-// question for itself before the time loop: 64 lanes x 4 steps per iteration, bit-pattern compares against the first
-// step of the interval, ~0.1 ms for ten years of hourly steps.
-__device__ __forceinline__ bool forcing_is_piecewise_constant(const double2 *__restrict__ f, long T, long gap)
+// its own regression test and the synthetic benchmark forcing all have this shape.)  Or at least constant over runs
+// of k steps, k a divisor of the gap (6-hourly data in an hourly run with daily reports, the same pipeline)?  And is
+// every value finite and >= +0 (the shortcuts of FastModel::step_arms)?  One int of flags per catchment:
+//   bit i (i < n_div)   the forcing is NOT constant over the aligned runs of div[i] steps (div[0] = gap, descending)
+//   kForcingInsane      some value is negative, -0, infinite or NaN
+// A run of d steps is constant iff no step t with t % d != 0 differs from its predecessor: one compare per step, the
+// remainders only where the forcing changes.  smart_forcing_scan answers for the whole launch (a.fflags); without a
+// workspace every wavefront scans for itself (~0.1 ms for ten years of hourly steps).
+__device__ __forceinline__ int forcing_flags_of_step(const KArgs &a, const double2 *__restrict__ f, long t)
 {
-    bool same = true;
-    for (long t0 = (long)threadIdx.x * 4; t0 < T; t0 += kWave * 4) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long t = t0 + j < T ? t0 + j : T - 1;
-            const double2 v = f[t], h = f[(t / gap) * gap];
-            same = same && same_bits(v.x, h.x) && same_bits(v.y, h.y);
+    const double2 v = f[t];
+    int bad = 0;
+    const unsigned long long top = 0x7ff0000000000000ull; // sign clear and exponent below all ones <=> bits < top
+    if (__builtin_bit_cast(unsigned long long, v.x) >= top || __builtin_bit_cast(unsigned long long, v.y) >= top)
+        bad |= kForcingInsane;
+    if (t > 0) {
+        const double2 u = f[t - 1];
+        if (!(same_bits(v.x, u.x) && same_bits(v.y, u.y))) {
+            for (int i = 0; i < a.n_div; ++i)
+                if (t % a.div[i] != 0)
+                    bad |= 1 << i;
         }
     }
-    return __builtin_amdgcn_ballot_w64(!same) == 0;
+    return bad;
+}
+
+__device__ __forceinline__ int scan_forcing_wave(const KArgs &a, const double2 *__restrict__ f)
+{
+    int bad = 0;
+    for (long t = threadIdx.x; t < a.T; t += kWave)
+        bad |= forcing_flags_of_step(a, f, t);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        bad |= __shfl_xor(bad, off, kWave);
+    return __builtin_amdgcn_readfirstlane(bad);
+}
+
+__device__ __forceinline__ int forcing_flags(const KArgs &a, const double2 *__restrict__ forcing, long c)
+{
+    return a.fflags ? a.fflags[c] : scan_forcing_wave(a, forcing + c * a.T);
+}
+
+// steps per run of constant forcing: the largest tested divisor of the gap that holds; 1 = the forcing varies
+__device__ __forceinline__ long run_length(const KArgs &a, int flags)
+{
+    for (int i = 0; i < a.n_div; ++i)
+        if (!((flags >> i) & 1))
+            return a.div[i];
+    return 1;
+}
+
+// forcing kinds of the merged summary kernels
+constexpr int kForcingVarying = 0, kForcingIntervals = 1, kForcingRuns = 2;
+
+__device__ __forceinline__ int forcing_kind(const KArgs &a, int flags)
+{
+    const long k = run_length(a, flags);
+    return k == a.gap ? kForcingIntervals : (k >= 2 ? kForcingRuns : kForcingVarying);
 }
 
 // Walk the report intervals of a piecewise-constant forcing: one (rain, peva) pair per interval, fetched with scalar
@@ -631,30 +722,34 @@ __device__ __forceinline__ void publish_slice(const KArgs &a, long slot, int seg
 //                   with `gap` times the demand;
 //   * wet lanes -> `gap` wet steps back to back, no compare and no branch per step.
 // Any other forcing: the step loop of run_ensemble(), cut at the same report-interval boundaries.
-template <class Model, bool PIECEWISE>
+// FORCING: kForcingIntervals, kForcingRuns (the same engine over runs of `run_len` steps, run_len a divisor of the gap:
+// gap / run_len runs make a report interval, whose mean accumulates across them) or kForcingVarying.
+template <class Model, int FORCING>
 __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double2 *__restrict__ forcing,
                                                     const double *__restrict__ obs_all,
                                                     const double *__restrict__ ws_all, long block, long catchment,
-                                                    int seg)
+                                                    int seg, int fflags)
 {
-    constexpr bool piecewise = PIECEWISE; // a template parameter: the two sides share no live value
+    constexpr bool piecewise = FORCING != kForcingVarying; // a template parameter: the sides share no live value
+    constexpr bool runs = FORCING == kForcingRuns;
     const LaneCtx x = lane_ctx(a, block, catchment);
     const long slot = catchment * a.n_blocks + block; // this block's place in seg_state / seg_flag
     Model m;
     init_model(a, x, m);
-    if constexpr (piecewise)
-        m.setup_intervals(a.gap);
-    const double2 *__restrict__ f = forcing + x.c * a.T;
     const long gap = a.gap;
+    const long run_len = runs ? run_length(a, fflags) : gap; // steps advanced at a time by the interval engine
+    if constexpr (piecewise)
+        m.setup_intervals(run_len);
+    const double2 *__restrict__ f = forcing + x.c * a.T;
 
     // A per-lane if / else: a wavefront whose lanes all fall on one side skips the other (s_cbranch_execz); in a mixed
     // wavefront each side runs under its lanes' mask.  Either way a lane's arithmetic depends on its own sample only.
     auto interval = [&](const double2 v, double &acc, double &num, double &den) {
         const double ex = m.excess(v.x, v.y);
         if (ex < 0.0) {
-            m.dry_interval(ex, gap, acc);
+            m.dry_interval(ex, run_len, acc);
         } else {
-            m.wet_interval(ex, gap, acc, num, den);
+            m.wet_interval(ex, run_len, acc, num, den);
         }
     };
 
@@ -724,7 +819,27 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     const double inv_gap = 1.0 / (double)gap;
     const bool starts_run = ra == 0 && (rb > 0 || last);
-    if constexpr (piecewise) {
+    if constexpr (runs) {
+        // `per` runs make a report interval; the walk is over runs, the report falls on every per-th of them
+        const long per = gap / run_len;
+        interval_loop(f, wa * per, wb * per, run_len, [&](long, const double2 v) { interval(v, s0, s1, s2); });
+        if (starts_run)
+            m.begin_run();
+        long j = 0, r = ra;
+        double acc = 0.0;
+        interval_loop(f, ra * per, rb * per, run_len, [&](long, const double2 v) {
+            if (Model::kSplit && j == 0 && r == a.R - 1)
+                park_state();
+            interval(v, acc, num, den);
+            if (++j == per) {
+                rep.emit(a, x, r, acc * inv_gap);
+                q_out_total += acc;
+                acc = 0.0;
+                j = 0;
+                ++r;
+            }
+        });
+    } else if constexpr (piecewise) {
         interval_loop(f, wa, wb, gap, [&](long, const double2 v) { interval(v, s0, s1, s2); });
         if (starts_run)
             m.begin_run();
@@ -749,22 +864,11 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
             });
         }
     } else {
-        // the step loop with deferred evaporation (Model::step_lazy); the demand a slice has not yet taken from the
-        // layers travels in the hand-over, so that a sliced run composes exactly like a whole one
+        // the step loop with deferred evaporation; the demand a slice has not yet taken from the layers travels in the
+        // hand-over, so that a sliced run composes exactly like a whole one
         m.begin_lazy(seg > 0 ? hand[15 * kWave] : 0.0);
-        // no rain and no evaporation in this step (forcing is wave-uniform: scalar unit); never when a layer may be
-        // above its capacity (Model::zero_ok)
-        const unsigned long long not_ok = m.zero_ok ? 0ull : ~0ull;
-        auto calm = [not_ok](const double2 v) {
-            return (__builtin_bit_cast(unsigned long long, v.x) | __builtin_bit_cast(unsigned long long, v.y) | not_ok) == 0;
-        };
-        time_loop_lazy(m, f + wa * gap, (wb - wa) * gap, calm, s0, s1, s2, [] {});
-        if (starts_run)
-            m.begin_run();
         long k = 0, r = ra;
         double acc = 0.0;
-        if (Model::kSplit && ra == a.R - 1 && rb > ra)
-            park_state();
         auto report = [&]() { // end of report interval r (wave-uniform)
             rep.emit(a, x, r, acc * inv_gap);
             ++r;
@@ -774,6 +878,61 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
             if (Model::kSplit && r == a.R - 1)
                 park_state();
         };
+#if SMART_STEP_ARMS
+        // The three asm arms of FastModel::step_arms.  The shortcuts of the dry and the calm arm need forcing without
+        // negative or non-finite values (smart_forcing_scan) and no layer above capacity: `quick`.
+        // ONE instance of the loop serves the warm-up and the run (and, for report gaps that are not a multiple of the
+        // chunk, one interval at a time): the walk is over PIECES of the time axis -- piece 0 the warm-up, then either
+        // the whole run with the report test on chunk boundaries, or an interval per piece with the report behind it.
+        // (Three inlined copies of the loop -- warm-up, run, run with a test per step -- cost 30 VGPRs at their joins.)
+        const bool quick = m.zero_ok && !(fflags & kForcingInsane);
+        const bool aligned = gap % kChunk == 0;
+        const long n_run = rb - ra;
+        const long n_pieces = 1 + (aligned ? (n_run > 0 ? 1 : 0) : n_run);
+        auto walk = [&](auto quick_tag) {
+            constexpr bool Q = decltype(quick_tag)::value;
+#pragma nounroll
+            for (long piece = 0; piece < n_pieces; ++piece) {
+                const bool run = piece > 0;
+                const double2 *__restrict__ p = run ? f + (ra + (aligned ? 0 : piece - 1)) * gap : f + wa * gap;
+                const long n = run ? (aligned ? n_run * gap : gap) : (wb - wa) * gap;
+                if (piece == 1) {
+                    acc = 0.0; // (the warm-up's sum)
+                    if (starts_run)
+                        m.begin_run();
+                    if (Model::kSplit && ra == a.R - 1)
+                        park_state();
+                }
+                const bool by_chunk = run && aligned;
+                time_loop_arms<Q>(m, p, n, acc, [&]() {
+                    if (by_chunk) {
+                        k += kChunk;
+                        if (__builtin_expect(k == gap, 0))
+                            report();
+                    }
+                });
+                if (run && !aligned)
+                    report();
+            }
+        };
+        if (quick)
+            walk(std::true_type{});
+        else
+            walk(std::false_type{});
+        if (n_pieces == 1 && starts_run)
+            m.begin_run();
+#else
+        // no rain and no evaporation in this step (forcing is wave-uniform: scalar unit); never when a layer may be
+        // above its capacity (Model::zero_ok)
+        const unsigned long long not_ok = m.zero_ok ? 0ull : ~0ull;
+        auto calm = [not_ok](const double2 v) {
+            return (__builtin_bit_cast(unsigned long long, v.x) | __builtin_bit_cast(unsigned long long, v.y) | not_ok) == 0;
+        };
+        time_loop_lazy(m, f + wa * gap, (wb - wa) * gap, calm, s0, s1, s2, [] {});
+        if (starts_run)
+            m.begin_run();
+        if (Model::kSplit && ra == a.R - 1 && rb > ra)
+            park_state();
         if (gap % kChunk == 0) { // intervals end on chunk boundaries: one test per chunk of steps, not per step
             time_loop_lazy(m, f + ra * gap, (rb - ra) * gap, calm, acc, num, den, [&]() {
                 k += kChunk;
@@ -790,6 +949,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                     report();
             }
         }
+#endif
         if (last)
             m.flush_pending(); // the final state vector wants the layers as the reference leaves them
     }

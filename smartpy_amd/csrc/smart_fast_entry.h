@@ -11,12 +11,14 @@
 //   smart_fast_intervals_exits   class 0, summary, gap >= 2, piecewise-constant forcing          interval engine, early exits
 //   smart_fast_intervals         same, for launches with <= 2 blocks of 64 samples per SIMD    interval engine, straight-line
 //   smart_fast_intervals_states  same, final state vector asked for                              interval engine, SPLIT
+//   smart_fast_runs(_exits)      same as the two above for forcing constant over runs of k steps,  interval engine over runs
+//   smart_fast_runs_states       k >= 2 a divisor of the gap (e.g. 6-hourly data, hourly steps)     ... SPLIT
 //   smart_fast_steps             class 0, summary, gap >= 2, forcing varying inside the interval step loop, merged
 //   smart_fast_steps_states      same, final state vector asked for                              step loop, SPLIT
 //   smart_fast_plain             class 0, raw reports or gap 1                                   step loop
 //   smart_fast_stiff             class 1: some k * 3600 < dt (clamps, 95 % rule reachable)        step loop, STIFF
 //   smart_fast_guard             class 2: S outside [0, 0.5], C < 0 or Z <= 0                     step loop, GUARD
-//   smart_fast_illcond           class 3: some dt / (k * 3600) > 2                                literal model
+//   smart_fast_illcond           class 3: dt / (RK * 3600) > 2 (the river only)                   literal model
 #pragma once
 
 #include "smart_fast_model.h"
@@ -33,11 +35,14 @@ enum FastKernel : int {
     kStiff,
     kGuard,
     kIllCond,
+    kRunsExits,
+    kRuns,
+    kRunsStates,
     kNumFastKernels
 };
 
 // ticket counters of the two families of time-sliced kernels (workspace header, claim_work)
-constexpr int kTicketIntervals = 0, kTicketSteps = 1;
+constexpr int kTicketIntervals = 0, kTicketSteps = 1, kTicketRuns = 2;
 
 // Do this block's 64 rows belong to the kernel of class CLS?  A block whose class has no kernel in this call (the
 // caller's plan is stale) is reported through the status word by whichever kernel meets it first.
@@ -53,26 +58,32 @@ __device__ __forceinline__ bool block_is_mine(const KArgs &a, const Work &w)
 }
 
 // Class-0 summary runs: is this catchment's forcing the kind this kernel takes?  Answered by smart_forcing_scan
-// before the launch (a.not_pc); without a workspace every wavefront scans the forcing itself.
-template <bool PIECEWISE>
-__device__ __forceinline__ bool forcing_is_mine(const KArgs &a, const double2 *__restrict__ forcing, const Work &w)
+// before the launch (a.fflags); without a workspace every wavefront scans the forcing itself.
+template <int FORCING>
+__device__ __forceinline__ bool forcing_is_mine(const KArgs &a, int fflags, const Work &w)
 {
-    const bool pc = a.not_pc ? a.not_pc[w.c] == 0 : forcing_is_piecewise_constant(forcing + w.c * a.T, a.T, a.gap);
-    if (pc == PIECEWISE)
+    const int kind = forcing_kind(a, fflags);
+    if (kind == FORCING)
         return true;
-    if (w.seg == 0 && !((a.pc_mask >> (pc ? 0 : 1)) & 1))
+    // pc_mask: bit 0 the interval engine, bit 1 the step loop, bit 2 the run engine
+    const int bit = kind == kForcingIntervals ? 0 : (kind == kForcingVarying ? 1 : 2);
+    if (w.seg == 0 && !((a.pc_mask >> bit) & 1))
         raise_status(a, kStatusStalePlan);
     return false;
 }
 
-template <class Model, bool PIECEWISE>
+template <class Model, int FORCING>
 __device__ __forceinline__ void merged_kernel(const KArgs &a, const double2 *__restrict__ forcing,
                                               const double *__restrict__ obs, const double *__restrict__ ws)
 {
-    const Work w = claim_work(a, PIECEWISE ? kTicketIntervals : kTicketSteps);
-    if (!block_is_mine<0>(a, w) || !forcing_is_mine<PIECEWISE>(a, forcing, w))
+    const Work w = claim_work(a, FORCING == kForcingIntervals ? kTicketIntervals
+                                                               : (FORCING == kForcingVarying ? kTicketSteps : kTicketRuns));
+    if (!block_is_mine<0>(a, w))
         return;
-    run_ensemble_merged<Model, PIECEWISE>(a, forcing, obs, ws, w.block, w.c, w.seg);
+    const int fflags = forcing_flags(a, forcing, w.c);
+    if (!forcing_is_mine<FORCING>(a, fflags, w))
+        return;
+    run_ensemble_merged<Model, FORCING>(a, forcing, obs, ws, w.block, w.c, w.seg, fflags);
 }
 
 #define SMART_FAST_KERNEL(name)                                                                                        \
@@ -83,5 +94,6 @@ __device__ __forceinline__ void merged_kernel(const KArgs &a, const double2 *__r
 const void *fast_kernel_intervals(FastKernel k);
 const void *fast_kernel_steps(FastKernel k);
 const void *fast_kernel_guarded(FastKernel k);
+const void *fast_kernel_runs(FastKernel k);
 
 } // namespace smart

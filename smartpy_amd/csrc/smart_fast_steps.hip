@@ -4,9 +4,9 @@
 
 namespace smart {
 
-SMART_FAST_KERNEL(smart_fast_steps) { merged_kernel<FastModel<false, false, true>, false>(a, forcing, obs, ws); }
+SMART_FAST_KERNEL(smart_fast_steps) { merged_kernel<FastModel<false, false, true>, kForcingVarying>(a, forcing, obs, ws); }
 
-SMART_FAST_KERNEL(smart_fast_steps_states) { merged_kernel<FastModel<false, false, true, true, true>, false>(a, forcing, obs, ws); }
+SMART_FAST_KERNEL(smart_fast_steps_states) { merged_kernel<FastModel<false, false, true, true, true>, kForcingVarying>(a, forcing, obs, ws); }
 
 // raw reports / gap 1: the merged form when only discharge and the groundwater ratio are asked for, the five
 // reservoirs carried separately when the caller wants the final state vector

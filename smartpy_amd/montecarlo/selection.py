@@ -67,12 +67,28 @@ def check_shapes(params, fns, values, kinds, what):
 
 def best_rows(sort_fn, constrained, nb_best):
     """Indices (into the unconstrained sample) of the nb_best LARGEST values of sort_fn among the rows where
-    `constrained` is true, in ascending order of the value -- best.py:287 `argsort()[-nb_best:]`."""
+    `constrained` is true, in ascending order of the value -- best.py:287 `argsort()[-nb_best:]`.
+
+    Equal keys: the reference calls numpy's default argsort, an unstable sort whose order among equal keys is a detail
+    of the numpy build (KAT-12: the ten best by a GW flag of zeros and ones come back as rows 16, 15, 14, 12, ... --
+    neither ascending nor descending row order).  On the host this function makes the very same call.  On a device
+    tensor the top-k is a stable sort there -- unless keys tie inside the selection or across its edge, the one case
+    where the sort's inner order shows: then the constrained keys (4 bytes per row) are sorted on the host by the same
+    numpy call, so that a second stage built from a finished run picks the rows the one built from its database
+    file picks."""
     if _is_torch(sort_fn):
         import torch
         idx = torch.nonzero(constrained, as_tuple=False)[:, 0]
-        order = torch.argsort(sort_fn[idx], stable=True)
-        return idx[order][-nb_best:]
+        keys = sort_fn[idx]
+        order = torch.argsort(keys, stable=True)
+        picked = order[-nb_best:] if nb_best > 0 else order[:0]
+        edge = keys[order[-nb_best - 1:]] if 0 < nb_best < order.numel() else keys[picked]
+        tied = ((edge[1:] == edge[:-1]) | (torch.isnan(edge[1:]) & torch.isnan(edge[:-1]))).any() \
+            if edge.numel() > 1 else False
+        if bool(tied):
+            host = np.argsort(keys.cpu().numpy())[-nb_best:]
+            picked = torch.from_numpy(host).to(idx.device)
+        return idx[picked]
     idx = np.nonzero(constrained)[0]
     return idx[np.argsort(sort_fn[idx])][-nb_best:]
 
@@ -114,6 +130,7 @@ class SecondStage(object):
         self.sampling_run_file = '{}{}.SMART.lhs{}'.format(self.model.out_f, catchment,
                                                            '.nc' if self.out_format == 'netcdf' else '')
         self._device_obj_fns = self._device_rows = None
+        self._stored_params = self._stored_obj_fns = self._host_sample = None
         if sampling is None:
             self.sampled_params, self.sampled_obj_fns = self._get_sampled_sets_from_file(
                 self.sampling_run_file, self.param_names, self.obj_fn_names, decompression_csv)
@@ -124,12 +141,36 @@ class SecondStage(object):
             raise Exception("The sampling run handed to {} does not hold the same objective "
                             "functions.".format(type(self).__name__))
         import torch
-        self._device_obj_fns = sampling.device_obj_fns.to(torch.float32)     # the precision the database keeps
+        # The objective functions as the database hands them to the file-based constructors: float32, printed
+        # '%.6e', parsed back (7 significant digits -- not a float32 round trip).  The conditions are evaluated on
+        # exactly these numbers, uploaded again (4 bytes x 8 per sample), so that a threshold that falls between a
+        # value and its printed form, or two values that only tie in print, select the same rows either way.
+        device = sampling.device_obj_fns.device
+        self._stored_obj_fns = as_stored(sampling.obj_fns)
+        self._device_obj_fns = torch.from_numpy(self._stored_obj_fns).to(device)
         self._device_rows = sampling.device_sample if sampling.device_sample is not None \
-            else torch.from_numpy(sampling._sample).to(self._device_obj_fns.device)
-        # the host views the file-based path fills: read lazily, most callers never look at them
-        self.sampled_params = as_stored(sampling._sample)
-        self.sampled_obj_fns = as_stored(sampling.obj_fns)
+            else torch.from_numpy(sampling._sample).to(device)
+        self._host_sample = sampling._sample
+        self._stored_params = None       # the [N, 10] host view is made when somebody looks at it
+
+    @property
+    def sampled_obj_fns(self):
+        return self._stored_obj_fns
+
+    @sampled_obj_fns.setter
+    def sampled_obj_fns(self, value):
+        self._stored_obj_fns = value
+
+    @property
+    def sampled_params(self):
+        """float32 [N, 10]: what _get_sampled_sets_from_file returns for the sampling run's database."""
+        if self._stored_params is None and getattr(self, '_host_sample', None) is not None:
+            self._stored_params = as_stored(self._host_sample)
+        return self._stored_params
+
+    @sampled_params.setter
+    def sampled_params(self, value):
+        self._stored_params = value
 
     def _rows_as_stored(self, which):
         """Parameter rows picked on the device (boolean mask or index tensor) -> float32 host matrix with the

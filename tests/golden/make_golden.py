@@ -188,7 +188,165 @@ def api_surface():
     print('api_surface.json', sum(len(v) for v in out.values()), 'names')
 
 
+def montecarlo_vectors():
+    """KAT-12: the conditioning rules of the second-stage classes, straight from the reference's static methods
+    GLUE._get_behavioural_sets (glue.py:222-289) and Best._get_best_sets (best.py:221-287) on a float32 matrix with
+    ties, values that sit exactly on thresholds and a NaN row.  KAT-13: the bytes of a sampling database written by
+    the reference's own MonteCarlo._init_db + save (montecarlo.py:122-127, 211-231), with and without the simulated
+    series, and what its _get_sampled_sets_from_file (:233-262) reads -- from its own file and from a file written
+    by this repository's database.SamplingCsv."""
+    import json
+    from smartpy.montecarlo.glue import GLUE
+    from smartpy.montecarlo.best import Best
+    from smartpy.montecarlo.montecarlo import MonteCarlo
+
+    rng = np.random.default_rng(1212)
+    n = 48
+    params = rng.uniform(0.0, 100.0, (n, 10)).astype(np.float32)
+    params[:, 0] = np.arange(n, dtype=np.float32)                 # column 0 names the row: outputs -> indices
+    f32 = np.float32
+    fns = np.empty((n, 8), dtype=np.float32)
+    fns[:, 0] = rng.choice(np.array([0.1, 0.5, 0.7, np.nextafter(f32(0.7), f32(1)), 0.9], dtype=np.float32), n)  # NSE
+    fns[:, 1] = rng.uniform(-0.5, 1.0, n)                         # KGE, continuous
+    fns[:, 2] = rng.uniform(0.0, 1.0, n)
+    fns[:, 3] = rng.uniform(0.5, 1.5, n)
+    fns[:, 4] = np.round(rng.uniform(0.5, 1.5, n), 1)             # KGEb on a 0.1 grid: ties
+    fns[:, 5] = rng.uniform(-40.0, 40.0, n)                       # PBias
+    fns[:, 6] = rng.gamma(2.0, 2.0, n)                            # RMSE
+    fns[:, 7] = rng.integers(0, 2, n)                             # GW flag: two values only
+    fns[7, :] = np.nan                                            # a row no comparison accepts
+    fns[11, 5] = f32(10.0)                                        # exactly on the thresholds used below
+    fns[12, 5] = f32(-10.0)
+
+    # both matrices as a sampling database hands them over: float32 -> '%.6e' -> float32 (montecarlo.py:225-231, :262),
+    # so that the same vectors also serve the constructors that take their sample from a finished run
+    def stored(m):
+        return np.array([[f32('%.6e' % v) for v in row] for row in m], dtype=np.float32)
+    fns[fns[:, 0] == np.nextafter(f32(0.7), f32(1)), 0] = f32(0.700001)      # a neighbour of 0.7 that survives the text
+    params, fns = stored(params), stored(fns)
+    assert np.array_equal(stored(params), params) and np.array_equal(stored(fns), fns, equal_nan=True)
+
+    def rows_of(out):
+        return [int(v) for v in out[:, 0]]
+
+    glue_cases = []
+    for cols, kinds, vals in [
+        ([0], ['min'], [(0.7,)]),
+        ([0], ['equal'], [(0.7,)]),                               # float32(0.7) == 0.7 under the array's dtype
+        ([0], ['max'], [(0.5,)]),
+        ([5], ['inside'], [(-10.0, 10.0)]),
+        ([5], ['outside'], [(-10.0, 10.0)]),                      # glue.py:277 as written: no value passes
+        ([0, 5, 7], ['min', 'inside', 'equal'], [(0.5,), (-25.0, 25.0), (1.0,)]),
+        ([1, 6], ['min', 'max'], [(0.3,), (3.5,)]),
+        ([1], ['min'], [(5.0,)]),                                 # nobody: an empty [0, 10] matrix
+        ([7], ['equal'], [(0.0,)]),
+    ]:
+        out = GLUE._get_behavioural_sets(params, fns[:, cols], vals, kinds)
+        glue_cases.append({'columns': cols, 'kinds': kinds, 'values': [list(v) for v in vals], 'rows': rows_of(out),
+                           'shape': list(out.shape), 'dtype': str(out.dtype)})
+
+    best_cases = []
+    for cols, kinds, vals, target, nb in [
+        ([], [], [], 1, 5),                                       # continuous target: no ties anywhere
+        ([], [], [], 1, 48),                                      # all of them (the NaN row sorts last)
+        ([5], ['inside'], [(-25.0, 25.0)], 1, 7),
+        ([7], ['equal'], [(1.0,)], 6, 4),                         # RMSE as target: the LARGEST four, as written
+        ([], [], [], 0, 6),                                       # NSE on five levels: ties inside the selection
+        ([], [], [], 7, 10),                                      # GW flag as target: ties across the cut
+        ([0], ['min'], [(0.7,)], 4, 3),                           # 0.1 grid
+    ]:
+        out = Best._get_best_sets(params, fns[:, cols], vals, kinds, fns[:, [target]], nb)
+        rows = rows_of(out)
+        # is the answer independent of how a sort orders equal keys?  (the reference calls numpy's default argsort,
+        # an unstable introsort / SIMD sort whose tie order is an implementation detail of the numpy build and CPU)
+        mask = np.ones(n, dtype=bool)
+        for c, k, v in zip(cols, kinds, vals):
+            col = fns[:, c]
+            mask &= {'min': lambda: col >= v[0], 'max': lambda: col <= v[0], 'equal': lambda: col == v[0],
+                     'inside': lambda: (col >= v[0]) & (col <= v[1])}[k]()
+        keys = fns[mask, target]
+        srt = np.sort(keys)                                       # NaN last, like argsort
+        tail = srt[-nb:]
+        ambiguous = bool(len(np.unique(tail[~np.isnan(tail)])) + int(np.isnan(tail).sum()) < len(tail)
+                         or (len(srt) > nb and (srt[-nb - 1] == tail[0] or
+                                                (np.isnan(srt[-nb - 1]) and np.isnan(tail[0])))))
+        best_cases.append({'columns': cols, 'kinds': kinds, 'values': [list(v) for v in vals], 'target': target,
+                           'nb_best': nb, 'rows': rows, 'keys': [repr(float(fns[r, target])) for r in rows],
+                           'ambiguous': ambiguous,
+                           'rows_if_stable': [int(v) for v in
+                                              params[mask][np.argsort(keys, kind='stable')][-nb:][:, 0]]})
+
+    errors = []
+    for label, call in [
+        ('glue_equal_two', lambda: GLUE._get_behavioural_sets(params, fns[:, [0]], [(0.1, 0.2)], ['equal'])),
+        ('glue_inside_order', lambda: GLUE._get_behavioural_sets(params, fns[:, [0]], [(0.9, 0.2)], ['inside'])),
+        ('glue_kind', lambda: GLUE._get_behavioural_sets(params, fns[:, [0]], [(0.9,)], ['above'])),
+        ('glue_dims', lambda: GLUE._get_behavioural_sets(params, fns[:, [0, 1]], [(0.9,)], ['min'])),
+        ('glue_1d', lambda: GLUE._get_behavioural_sets(params, fns[:, 0], [(0.9,)], ['min'])),
+        ('best_too_many', lambda: Best._get_best_sets(params, fns[:, []], [], [], fns[:, [1]], 49)),
+        ('best_too_many_constrained', lambda: Best._get_best_sets(params, fns[:, [0]], [(0.9,)], ['min'],
+                                                                  fns[:, [1]], 40)),
+        ('best_sizes', lambda: Best._get_best_sets(params, fns[:, []], [], [], fns[:20, [1]], 4)),
+    ]:
+        try:
+            call()
+            errors.append({'case': label, 'message': None})
+        except Exception as e:
+            errors.append({'case': label, 'message': str(e)})
+
+    save('kat12_selection.npz', params=params, obj_fns=fns)
+    with open(os.path.join(OUT, 'kat12_selection.json'), 'w') as fh:
+        json.dump({'numpy': np.__version__, 'glue': glue_cases, 'best': best_cases, 'errors': errors}, fh, indent=1)
+
+    # ---- KAT-13 ---------------------------------------------------------------------------------------------
+    names_obj = ['NSE', 'KGE', 'KGEc', 'KGEa', 'KGEb', 'PBias', 'RMSE', 'GW']
+    stamps = [datetime(2008, 1, 1, 9) + timedelta(days=k) for k in range(6)]
+    rng = np.random.default_rng(1313)
+    obj = rng.uniform(-1.0, 1.0, (5, 8))
+    obj[0] = [1.0 / 3.0, 1e-10, -2.5e8, 0.0, 123456.789, 9.9999995e-1, 5e-324, 1.0]    # ties of '%.6e', tiny, huge
+    obj[1, :3] = [np.nan, np.inf, -np.inf]
+    obj[2, 0] = 0.30000001192092896                                                    # a float32 exactly
+    par = rng.uniform(0.0, 1000.0, (5, 10))
+    par[3] = [1.0, 0.0, 0.25, 0.5, 1e-3, 105.25734595830215, 46.81961454361724, 315.5490902162102,
+              1066.7332319333473, 10.640277777777778]
+    sim = rng.gamma(2.0, 3.0, (5, 6))
+    out13 = {'obj_fns': obj, 'params': par, 'sims': sim,
+             'stamps': np.array([s.strftime('%Y-%m-%d %H:%M:%S') for s in stamps])}
+    tmp = tempfile.mkdtemp(prefix='smart_db_')
+
+    class _Model(object):
+        flow = OrderedDict((s, 0.0) for s in stamps)
+
+    for tag, save_sim in (('nosim', False), ('sim', True)):
+        mc = MonteCarlo.__new__(MonteCarlo)
+        mc.out_format, mc.save_sim, mc.model = 'csv', save_sim, _Model()
+        mc.obj_fn_names, mc.param_names = names_obj, NAMES
+        mc.db_file = os.path.join(tmp, 'ref_%s.SMART.lhs' % tag)
+        mc._init_db()
+        for k in range(5):
+            mc.save(obj[k].tolist(), par[k], [sim[k]])
+        mc.database.close()
+        with open(mc.db_file, 'rb') as fh:
+            out13['bytes_' + tag] = np.frombuffer(fh.read(), dtype=np.uint8)
+        p_ref, o_ref = mc._get_sampled_sets_from_file(mc.db_file, NAMES, names_obj, False)
+        out13['ref_reads_ref_params_' + tag], out13['ref_reads_ref_objfns_' + tag] = p_ref, o_ref
+        # ... and from a file written by this repository's writer (host-only code of the library: no GPU involved)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+        from smartpy_amd.montecarlo.database import SamplingCsv
+        ours = SamplingCsv(os.path.join(tmp, 'ours_%s.SMART.lhs' % tag), names_obj, NAMES)
+        ours.create(5, stamps if save_sim else None)
+        ours.write_table(obj, par, sim if save_sim else None)
+        ours.close()
+        p_o, o_o = mc._get_sampled_sets_from_file(ours.path, NAMES, names_obj, False)
+        out13['ref_reads_ours_params_' + tag], out13['ref_reads_ours_objfns_' + tag] = p_o, o_o
+    shutil.rmtree(tmp)
+    save('kat13_database.npz', **out13)
+
+
 def main():
+    if '--only-montecarlo' in sys.argv:
+        montecarlo_vectors()
+        return
     scratch = tempfile.mkdtemp(prefix='smart_golden_')
     shutil.copytree(os.path.join(REF, 'tests', 'data'), os.path.join(scratch, 'data'))
     root = os.path.join(scratch, 'data') + os.sep
@@ -200,6 +358,7 @@ def main():
     resampling_vectors(root)
     dict_helper_vectors(root)
     api_surface()
+    montecarlo_vectors()
     if '--only-resampling' in sys.argv:
         shutil.rmtree(scratch)
         return

@@ -146,6 +146,51 @@ def test_monte_carlo_pipeline_lhs_glue_best_total(root, example):
     assert np.allclose(like[:7], want[0, :7], rtol=1e-9, atol=1e-12) and like[7] == want[0, 7]
 
 
+def test_second_stages_on_the_device_pick_the_references_rows(root):
+    """KAT-12 through the constructors: a finished sampling run whose 48 parameter rows and objective functions are
+    the fixture's matrices, handed to GLUE / Best as `sampling=` (mask, count and top-n on the GPU) and, through its
+    database file, to the file-based constructors.  Expected rows: what the REFERENCE's _get_behavioural_sets /
+    _get_best_sets returned for the same matrices (tests/golden/make_golden.py).  Where equal keys leave the order
+    to numpy's unstable sort, both constructors must still agree with each other row for row."""
+    import json
+    import torch
+    from smartpy_amd.montecarlo import LHS, GLUE, Best
+    z = load_golden('kat12_selection.npz')
+    with open(os.path.join(GOLDEN, 'kat12_selection.json')) as fh:
+        cases = json.load(fh)
+    params, fns = z['params'], z['obj_fns']
+    _settings(root, 'Catchment.sampling.sttngs', '01/01/2007', '31/12/2007', 180)
+    lhs = LHS('Catchment', root, 'csv', 'csv', 48, settings_filename='Catchment.sampling.sttngs')
+    assert lhs.obj_fn_names[-1] == 'GW'
+    lhs._set_sample(params.astype(np.float64))
+    lhs.obj_fns = fns.astype(np.float64)
+    lhs.device_obj_fns = torch.from_numpy(lhs.obj_fns).cuda()
+    db = lhs._open_database()                       # the file the file-based constructors read
+    db.write_table(lhs.obj_fns, lhs._sample)
+    lhs._finish_database(db, None)
+    names = lhs.obj_fn_names
+    kw = dict(settings_filename='Catchment.sampling.sttngs')
+    for c in cases['glue']:
+        cond = {names[col]: (kind, tuple(val)) for col, kind, val in zip(c['columns'], c['kinds'], c['values'])}
+        dev = GLUE('Catchment', root, 'csv', 'csv', conditioning=cond, sampling=lhs, **kw)
+        fil = GLUE('Catchment', root, 'csv', 'csv', conditioning=cond, **kw)
+        assert dev._device_obj_fns.is_cuda
+        assert [int(v) for v in dev.behavioural_params[:, 0]] == c['rows'], c
+        assert np.array_equal(dev.behavioural_params, fil.behavioural_params) and \
+            dev.behavioural_params.dtype == np.float32
+    for c in cases['best']:
+        con = {names[col]: (kind, tuple(val)) for col, kind, val in zip(c['columns'], c['kinds'], c['values'])}
+        args = dict(target=names[c['target']], nb_best=c['nb_best'], constraining=con, **kw)
+        dev = Best('Catchment', root, 'csv', 'csv', sampling=lhs, **args)
+        fil = Best('Catchment', root, 'csv', 'csv', **args)
+        assert np.array_equal(dev.best_params, fil.best_params), c           # ties included
+        rows = [int(v) for v in dev.best_params[:, 0]]
+        if not c['ambiguous']:
+            assert rows == c['rows'], c
+        else:
+            assert [repr(float(fns[r, c['target']])) for r in rows] == c['keys'] and len(set(rows)) == len(rows), c
+
+
 def test_second_stages_from_the_device_and_device_sampling(root, example):
     """(f1) GLUE / Best handed the finished LHS run itself (`sampling=`): the behavioural mask, its count and the
     top-n rows are evaluated on the GPU over the objective functions the launch left there, and select exactly the

@@ -29,6 +29,12 @@ if os.path.exists(args_file):
         n_warm = int(words[words.index('--warmup') + 1])
 
 
+def dominant_first(kernels):
+    """the time-loop kernels of the call, the one with the largest total time in the plain kernel trace first"""
+    total = {r['kernel']: r['total_ms'] for r in out.get('kernel_stats', [])}
+    return sorted(kernels, key=lambda k: -total.get(k, 0.0))
+
+
 def timed(values):
     """the per-dispatch values of the timed steps (the warm-up dispatches dropped, when there are enough left)"""
     return values[n_warm:] if len(values) > n_warm else values
@@ -75,6 +81,7 @@ if trace:
 
 # ---- PMC passes ------------------------------------------------------------------------------------
 pmc = defaultdict(lambda: defaultdict(list))
+clock = defaultdict(list)
 allrows = []
 order = {}
 for path in glob.glob(os.path.join(src, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
@@ -89,6 +96,9 @@ for row in allrows:
     if is_main(row['Kernel_Name']) and int(row['Grid_Size']) != big:
         continue
     pmc[row['Kernel_Name'].split('(')[0]][row['Counter_Name']].append((int(row['Dispatch_Id']), float(row['Counter_Value'])))
+    if row['Counter_Name'] == 'GRBM_GUI_ACTIVE':     # the dispatch's own duration in the pass that counted its cycles
+        secs = (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e9
+        clock[row['Kernel_Name'].split('(')[0]].append((int(row['Dispatch_Id']), float(row['Counter_Value']) / 8.0 / secs))
 if pmc:
     lines += ['## PMC counters (one `--pmc` pass each; value = mean per dispatch)', '', '| kernel | counter | mean per dispatch | dispatches |', '|---|---|---|---|']
     out['pmc'] = {}
@@ -100,9 +110,12 @@ if pmc:
             out['pmc'][k][c] = sum(v) / len(v)
             lines.append('| `%s` | %s | %.6g | %d |' % (k[:60], c, sum(v) / len(v), len(v)))
     lines.append('')
-    main = [k for k in pmc if is_main(k)]
+    main = dominant_first([k for k in pmc if is_main(k)])
     if main:
-        c = out['pmc'][main[0]]
+        # a call may run several time-loop kernels side by side (a daily ensemble: plain + stiff + illcond); its HBM
+        # traffic is the sum over them, everything else is reported per kernel
+        c = {n: sum(out['pmc'][k].get(n, 0.0) for k in main) for n in ('FETCH_SIZE', 'WRITE_SIZE')
+             if all(n in out['pmc'][k] for k in main)}
         if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
             # MI355X_MICROARCH.md, HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests
             # as 64 B for wide coalesced streaming reads (x2).  This kernel's reads are scalar loads + 8-B/lane rows,
@@ -120,34 +133,38 @@ hash_file = os.path.join(src, 'source_hash.txt')
 if os.path.exists(hash_file):
     out['source_hash'] = open(hash_file).read().strip()
     lines += ['kernel sources at profile time: sha256[:16] = `%s` (bench.kernel_source_hash)' % out['source_hash'], '']
-main = [k for k in out.get('pmc', {}) if is_main(k)]
-if main and 'GRBM_GUI_ACTIVE' in out['pmc'][main[0]] and 'full_size_dispatch_ms' in out:
-    # GRBM_GUI_ACTIVE counts busy cycles of every XCD (8); over the kernel's duration in its own PMC pass that is the
-    # engine clock the chip actually held under this load
-    durs = []
-    for path in glob.glob(os.path.join(src, 'pmc_SQ_WAIT_ANY', '**', '*kernel_trace.csv'), recursive=True):
-        with open(path) as f:
-            rows = [r for r in csv.DictReader(f) if is_main(r['Kernel_Name'])]
-        gmax = max(int(r['Grid_Size_X']) for r in rows)
-        rows.sort(key=lambda r: int(r['Start_Timestamp']))
-        durs += timed([(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e9 for r in rows if int(r['Grid_Size_X']) == gmax])
-    if durs:
-        out['held_clock_hz'] = out['pmc'][main[0]]['GRBM_GUI_ACTIVE'] / 8 / (sum(durs) / len(durs))
-        c0 = out['pmc'][main[0]]
-        lines += ['## clock held during the kernel', '',
-                  '- GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same pass (%.4f ms) = %.3f GHz' % (
-                      sum(durs) / len(durs) * 1e3, out['held_clock_hz'] / 1e9)]
-        if 'SQ_INSTS_VALU' in c0:
-            lines += ['- fp64 issue-slot fraction at that clock: SQ_INSTS_VALU x 4 cycles / (1,024 SIMDs x '
-                      'GRBM_GUI_ACTIVE / 8) = %.3f' % (c0['SQ_INSTS_VALU'] * 4.0 / (128 * c0['GRBM_GUI_ACTIVE'])),
-                      '- vector instructions per wave-step: see DESIGN.md 4.1 (SQ_INSTS_VALU / (blocks x steps))']
-        lines += ['']
+main = dominant_first([k for k in out.get('pmc', {}) if is_main(k)])
+if main and clock:
+    # GRBM_GUI_ACTIVE counts busy cycles of every XCD (8); over the duration of THE SAME dispatch in the pass that
+    # counted them, that is the engine clock the chip held.  Per kernel: under --pmc the dispatches of a call run one
+    # after the other, so each kernel's counters and duration are its own (round 2 divided one kernel's cycles by the
+    # duration of another that runs beside it in a normal launch, and printed 4.2 GHz).
+    out['per_kernel'] = {}
+    lines += ['## clock held and issue-slot fraction, per time-loop kernel', '',
+              '| kernel | GRBM_GUI_ACTIVE / 8 / own duration | SQ_INSTS_VALU x 4 / (1,024 SIMDs x GRBM_GUI_ACTIVE / 8) | SALU per VALU |',
+              '|---|---|---|---|']
+    for k in main:
+        c0 = out['pmc'][k]
+        hz = [x[1] for x in sorted(clock.get(k, []))]
+        hz = timed(hz)
+        rec = {'held_clock_hz': sum(hz) / len(hz) if hz else None}
+        if 'SQ_INSTS_VALU' in c0 and 'GRBM_GUI_ACTIVE' in c0:
+            rec['issue_frac_at_held_clock'] = c0['SQ_INSTS_VALU'] * 4.0 / (128 * c0['GRBM_GUI_ACTIVE'])
+        if 'SQ_INSTS_VALU' in c0 and 'SQ_INSTS_SALU' in c0 and c0['SQ_INSTS_VALU'] > 0:
+            rec['salu_per_valu'] = c0['SQ_INSTS_SALU'] / c0['SQ_INSTS_VALU']
+        out['per_kernel'][k] = rec
+        lines.append('| `%s` | %s | %s | %s |' % (
+            k[:60], '%.3f GHz' % (rec['held_clock_hz'] / 1e9) if rec['held_clock_hz'] else '-',
+            '%.3f' % rec['issue_frac_at_held_clock'] if 'issue_frac_at_held_clock' in rec else '-',
+            '%.3f' % rec['salu_per_valu'] if 'salu_per_valu' in rec else '-'))
+    out['held_clock_hz'] = out['per_kernel'][main[0]]['held_clock_hz']
+    lines += ['', '(dominant kernel of the call: `%s`)' % main[0], '']
 if workload and main and 'hbm_bytes_per_launch' in out:
     tpath = os.path.join(os.path.dirname(dst) or '.', 'traffic_latest.json')
     table = json.load(open(tpath)) if os.path.exists(tpath) else {}
     if 'workloads' not in table:
         table = {'workloads': {}}
-    c = out['pmc'][main[0]]
+    c = out['pmc'][main[0]]        # the dominant kernel (largest total time)
     table['workloads'][workload] = {
         'kernel': main[0], 'source_hash': out.get('source_hash'),
         'hbm_bytes_per_launch': out['hbm_bytes_per_launch'],
