@@ -78,6 +78,24 @@ def hourly_varying_forcing(base, seed=3):
     return out
 
 
+def six_hourly_forcing(base, seed=4):
+    """The same daily totals as four 6-hour values per day (rain in about half of the blocks, PE by the sun's share
+    of each block), each spread equally over its six hourly steps -- what the reference's pipeline makes of 6-hourly
+    input files in an hourly run (timeframe.py:167-186).  Constant over runs of six steps, not over the report
+    interval: the run engine (smart_fast_runs)."""
+    rng = np.random.default_rng(seed)
+    days = base.shape[0] // 24
+    wts = rng.random((days, 4)) * (rng.random((days, 4)) < 0.5)
+    wts[wts.sum(1) == 0, 0] = 1.0
+    wts /= wts.sum(1, keepdims=True)
+    out = base.copy()
+    out[:, 0] = np.repeat((base[::24, 0][:, None] * 24 * wts).ravel() / 6, 6)
+    day = np.maximum(0.0, np.sin(np.pi * (np.arange(24) - 5) / 14)).reshape(4, 6).sum(1)
+    day /= day.sum()
+    out[:, 1] = np.repeat((base[::24, 1][:, None] * 24 * day[None, :]).ravel() / 6, 6)
+    return out
+
+
 def wet_fraction(forcing, n_warm, t_lo=0.9, t_hi=1.1):
     """Realised fraction of executed sample-steps on the wet branch (rain * T - peva >= 0, T ~ U[t_lo, t_hi])."""
     f = np.concatenate([forcing[:n_warm], forcing])
@@ -176,6 +194,24 @@ def timed_steps(step, n_steps, n_warmup, device):
     return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev])), res
 
 
+def rank_evidence(device, launch_ms):
+    """Who took part: backend, and per rank the device it ran on and the mean HIP-event time of its own steps --
+    gathered once, after the timed loop.  A line that says n_gpus = 8 then shows eight devices and eight timings."""
+    import torch.distributed as dist
+    props = torch.cuda.get_device_properties(device)
+    mine = {'rank': sdist.rank_world()[0], 'device': '%s #%d' % (props.name, device.index),
+            'uuid': str(getattr(props, 'uuid', '')), 'pci_bus_id': int(getattr(props, 'pci_bus_id', -1)),
+            'host': os.uname().nodename, 'pid': os.getpid(), 'launch_ms': launch_ms}
+    if not sdist.is_distributed():
+        return {'backend': None, 'world_size': 1, 'devices': [mine['device']], 'launch_ms_per_rank': [launch_ms],
+                'ranks': [mine]}
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    return {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+            'devices': [r['device'] for r in everyone], 'launch_ms_per_rank': [r['launch_ms'] for r in everyone],
+            'ranks': everyone}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -186,7 +222,8 @@ def main():
     ap.add_argument('--math', default='fast', choices=['fast', 'literal'])
     ap.add_argument('--no-discharge', action='store_true', help='do not write the [R, N] discharge matrix')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip cpu_baseline and the in-run parity check')
-    ap.add_argument('--no-flat', action='store_true', help='skip the flat_forcing leg')
+    ap.add_argument('--no-flat', action='store_true', help='skip the flat_forcing / runs_of_6 / objectives_only legs')
+    ap.add_argument('--no-strong', action='store_true', help='skip the strong_1e6 leg (config 4 beside config 3)')
     args = ap.parse_args()
 
     rank, world, device = sdist.init()
@@ -250,8 +287,31 @@ def main():
         blocks_local = math.ceil(n_per / 64) * job.n_local
 
     elapsed, launch_ms, res = timed_steps(job.step, args.steps, args.warmup, device)
-    job.verify()                                         # status word of the last launch: no slice timed out
+    again = job.verify()                 # status word of the last launch; a repeated launch is gathered afresh
+    res = res if again is None else again
     assert bool(torch.isfinite(res[..., :7]).all())
+    ranks = rank_evidence(device, launch_ms)
+
+    # config 4's strong-scaled figure in the same line (SURVEY.md 7.3-3 asks for both series from the driver's runs):
+    # 1e6 samples IN TOTAL, cut by rows over the ranks, objective functions only, one all-gather
+    strong = None
+    if cfg == 3 and not args.no_strong and args.math == 'fast':
+        n_total = 1000000
+        p_all = latin_hypercube(n_total, ranges, seed=2718)
+        lo, hi = sdist.shard_bounds(n_total, world, rank)
+        sjob = sdist.ShardedEnsemble(torch.from_numpy(p_all).to(device), d_forcing, AREA, dt, W, gap, axis='samples',
+                                     obs=obs, gw_obs=GW_OBS, **dict(kw, want_discharge=False))
+        s_steps = max(2, args.steps // 4)
+        s_elapsed, s_ms, s_res = timed_steps(sjob.step, s_steps, 1, device)
+        s_again = sjob.verify()
+        assert bool(torch.isfinite((s_res if s_again is None else s_again)[..., :7]).all())
+        strong = {'what': 'configs[3]: 1e6-sample LHS ensemble in total, sample-sharded over the %d GPU(s), gather of '
+                          '[N, 9]; discharge not stored' % world,
+                  'value': n_total * (W + T) * s_steps / s_elapsed, 'unit': 'sample-timesteps/s', 'scaling': 'strong',
+                  'ms_per_step': s_elapsed / s_steps * 1e3, 'steps': s_steps, 'runs_total': n_total,
+                  'runs_per_gpu': hi - lo, 'kernel': sjob.prepared.describe(),
+                  'launch_ms_per_rank': rank_evidence(device, s_ms)['launch_ms_per_rank']}
+        del sjob, p_all
 
     if rank == 0:
         steps_per_run = W + T
@@ -311,6 +371,7 @@ def main():
                        'runs_total': n_runs_total, 'runs_per_gpu': n_local, 'n_steps': T, 'n_warm': W,
                        'math_mode': args.math, 'wet_fraction': w, 'parallelism': shard},
             'per_gpu': value / world,
+            'ranks': ranks,
             # the same rate counting the simulated steps only (the warm-up replays W of them)
             'value_without_warmup': n_runs_total * T * args.steps / elapsed,
             'roofline': roofline,
@@ -327,6 +388,20 @@ def main():
                 'kernel': flat.describe(), 'launch_ms': f_ms, 'value': units_per_launch / (f_ms * 1e-3),
                 'unit': 'sample-timesteps/s', 'wet_fraction': wet_fraction(vary, W)}
             del flat
+        if strong is not None:
+            line['strong_1e6'] = strong
+        if world == 1 and cfg == 3 and not args.no_flat and args.math == 'fast':
+            # 6-hourly data in the hourly run: forcing constant over runs of six steps (the run engine)
+            six = six_hourly_forcing(forcing)
+            runs = engine.prepare_ensemble(d_params, six, AREA, dt, W, gap, obs=obs, gw_obs=GW_OBS, **kw)
+            r_elapsed, r_ms, _ = timed_steps(runs.launch, max(2, args.steps // 2), 1, device)
+            runs.verify()
+            line['runs_of_6'] = {
+                'what': 'same runs, daily totals as four 6-hour values spread equally over their six steps (6-hourly '
+                        'input files in an hourly run, timeframe.py:167-186): the interval engine over runs of 6 steps',
+                'kernel': runs.describe(), 'launch_ms': r_ms, 'value': units_per_launch / (r_ms * 1e-3),
+                'unit': 'sample-timesteps/s', 'wet_fraction': wet_fraction(six, W)}
+            del runs
         if world == 1 and cfg == 3 and store and not args.no_flat and args.math == 'fast':
             # the same runs the way MonteCarlo.run() launches them by default (save_sim=False): objective functions and
             # groundwater ratios only, no discharge matrix -- which lets the engine order the rows
@@ -340,10 +415,9 @@ def main():
                 'kernel': lean.describe(), 'launch_ms': l_ms, 'value': units_per_launch / (l_ms * 1e-3),
                 'unit': 'sample-timesteps/s'}
             del lean
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
+            # rank 0's host cores and rank 0's GPU, whatever the world size (the other ranks wait at the barrier below)
             line['cpu_baseline'], line['parity'] = cpu_baseline_and_parity(forcing, W, gap, dt, device)
-        elif not args.no_cpu_baseline:
-            line['cpu_baseline'] = line['parity'] = None
         print(json.dumps(line), flush=True)
         if line.get('parity') and not line['parity']['ok']:
             raise SystemExit('bench.py: in-run parity check failed: %r' % (line['parity'],))

@@ -403,7 +403,11 @@ static int plan_time_slices(const SmartEnsemble *e, int n_simd, int *per_simd, d
     // unsliced launch is under 2 % of it while the hand-over buffer (11 KB per block) starts to count
     if (blocks <= n_simd || blocks > 48L * n_simd)
         return 1;
-    return (int)(n_all / 64 < 16 ? n_all / 64 : 16);
+    // with ten or more blocks per SIMD eight slices even the launch out as well as sixteen (tools/ab_slices.sh: 1e6
+    // samples, 64 x 1e4) and halve the hand-over traffic, which is all the HBM traffic of a launch that stores no
+    // discharge matrix (6.2 GB -> 3 GB per launch at 1e6 samples)
+    const long want = blocks >= 10L * n_simd ? 8 : 16;
+    return (int)(n_all / 64 < want ? n_all / 64 : want);
 }
 
 // the pieces of e->workspace

@@ -75,6 +75,9 @@ __device__ __forceinline__ void raise_status(const KArgs &a, int bit)
 #ifndef SMART_NT_STORE
 #define SMART_NT_STORE 0
 #endif
+#ifndef SMART_CHUNK_THREADED
+#define SMART_CHUNK_THREADED 1 // the four steps of a chunk as one threaded asm (0: four single-step asms; A/B builds)
+#endif
 #ifndef SMART_STEP_ARMS
 #define SMART_STEP_ARMS 1 // the step loop of sub-daily forcing as three asm arms (0: the compiled step_lazy of round 2)
 #endif
@@ -288,9 +291,14 @@ __device__ __forceinline__ void time_loop_arms(Model &m, const double2 *__restri
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
             nxt[j] = f[pre + j];
+#if SMART_CHUNK_THREADED
+        static_assert(kChunk == 4, "SMART_A_CHUNK threads four steps");
+        m.template chunk_arms<QUICK>(cur, acc);
+#else
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
             m.template step_arms<QUICK>(cur[j], acc);
+#endif
         chunk_end();
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
@@ -298,6 +306,68 @@ __device__ __forceinline__ void time_loop_arms(Model &m, const double2 *__restri
     }
     for (long t = (long)n_chunks * kChunk; t < n; ++t)
         m.template step_arms<QUICK>(f[t], acc);
+}
+
+// A stretch of `n_iv` whole report intervals of `gap` steps, walked by the arm loop; interval_end() after each.
+// A lone wavefront issues ONE instruction of any kind per turn of its SIMD (every fourth cycle): a scalar instruction
+// or a branch costs it what a vector instruction costs, so the glue around the chunks counts -- the round-2 shape (one
+// flat loop over chunks, the report test on chunk boundaries, an index clamped for the prefetch) spent 6.5 scalar
+// instructions per STEP on it.  Here the chunk loop's own counter doubles as the interval counter, the prefetch
+// address is a pointer that is only ever incremented, and nothing is clamped: the stretch streams through all its
+// intervals but -- when it ends where the catchment's forcing ends -- the last one, which the clamped loop above
+// takes (a prefetch must never read past the array).
+template <bool QUICK, class Model, class IntervalEnd>
+__device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restrict__ f, long n_iv, long gap,
+                                              bool ends_at_array_end, double &acc, IntervalEnd &&interval_end)
+{
+    const int cpi = (int)(gap / kChunk);
+    long n_stream = 0;
+#if SMART_CHUNK_THREADED
+    if (gap % (2 * kChunk) == 0 && n_iv > 0) // (an even number of chunks per interval: the two buffers swap roles)
+        n_stream = ends_at_array_end ? n_iv - 1 : n_iv;
+#endif
+    if (n_stream > 0) {
+        double2 cur[kChunk], nxt[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            cur[j] = f[j];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            asm volatile("" ::"s"(cur[j].x), "s"(cur[j].y)); // wait here, not behind the first prefetch (see above)
+        const double2 *__restrict__ p = f;
+        // s_waitcnt for a chunk HERE: scalar loads return out of order, so the only wait there is waits for everything
+        // in flight -- it has to come before the next request goes out, not behind it
+        auto arrived = [](const double2(&c)[kChunk]) {
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j)
+                asm volatile("" ::"s"(c[j].x), "s"(c[j].y));
+        };
+        // Two chunks per turn, the two buffers swapping roles: no copy from one to the other (the clamped loop above
+        // pays 8 scalar moves a chunk for that).  Every half turn: wait for the chunk at hand, request the next one
+        // into the other buffer, run the chunk.  11 scalar instructions per 8 steps.
+        for (long iv = 0; iv < n_stream; ++iv) {
+#pragma nounroll
+            for (int c = 0; c < cpi; c += 2) {
+                arrived(cur);
+                p += kChunk;
+#pragma unroll
+                for (int j = 0; j < kChunk; ++j)
+                    nxt[j] = p[j];
+                m.template chunk_arms<QUICK>(cur, acc);
+                arrived(nxt);
+                p += kChunk;
+#pragma unroll
+                for (int j = 0; j < kChunk; ++j)
+                    cur[j] = p[j];
+                m.template chunk_arms<QUICK>(nxt, acc);
+            }
+            interval_end();
+        }
+    }
+    for (long iv = n_stream; iv < n_iv; ++iv) {
+        time_loop_arms<QUICK>(m, f + iv * gap, gap, acc, [] {});
+        interval_end();
+    }
 }
 
 // ---- pieces shared by the two launch bodies below ------------------------------------------------------------
@@ -868,6 +938,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         // hand-over, so that a sliced run composes exactly like a whole one
         m.begin_lazy(seg > 0 ? hand[15 * kWave] : 0.0);
         long k = 0, r = ra;
+        (void)k;
         double acc = 0.0;
         auto report = [&]() { // end of report interval r (wave-uniform)
             rep.emit(a, x, r, acc * inv_gap);
@@ -881,46 +952,32 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
 #if SMART_STEP_ARMS
         // The three asm arms of FastModel::step_arms.  The shortcuts of the dry and the calm arm need forcing without
         // negative or non-finite values (smart_forcing_scan) and no layer above capacity: `quick`.
-        // ONE instance of the loop serves the warm-up and the run (and, for report gaps that are not a multiple of the
-        // chunk, one interval at a time): the walk is over PIECES of the time axis -- piece 0 the warm-up, then either
-        // the whole run with the report test on chunk boundaries, or an interval per piece with the report behind it.
-        // (Three inlined copies of the loop -- warm-up, run, run with a test per step -- cost 30 VGPRs at their joins.)
+        // ONE instance of the loop serves the warm-up and the run: the walk is over two stretches of whole report
+        // intervals (three inlined copies of the loop -- warm-up, run, run with a test per step -- cost 30 VGPRs at
+        // their joins).
         const bool quick = m.zero_ok && !(fflags & kForcingInsane);
-        const bool aligned = gap % kChunk == 0;
-        const long n_run = rb - ra;
-        const long n_pieces = 1 + (aligned ? (n_run > 0 ? 1 : 0) : n_run);
         auto walk = [&](auto quick_tag) {
             constexpr bool Q = decltype(quick_tag)::value;
 #pragma nounroll
-            for (long piece = 0; piece < n_pieces; ++piece) {
-                const bool run = piece > 0;
-                const double2 *__restrict__ p = run ? f + (ra + (aligned ? 0 : piece - 1)) * gap : f + wa * gap;
-                const long n = run ? (aligned ? n_run * gap : gap) : (wb - wa) * gap;
-                if (piece == 1) {
+            for (int stretch = 0; stretch < 2; ++stretch) { // the warm-up intervals, then the report intervals
+                const long i0 = stretch ? ra : wa, i1 = stretch ? rb : wb;
+                if (stretch == 1) {
                     acc = 0.0; // (the warm-up's sum)
                     if (starts_run)
                         m.begin_run();
-                    if (Model::kSplit && ra == a.R - 1)
+                    if (Model::kSplit && ra == a.R - 1 && rb > ra)
                         park_state();
                 }
-                const bool by_chunk = run && aligned;
-                time_loop_arms<Q>(m, p, n, acc, [&]() {
-                    if (by_chunk) {
-                        k += kChunk;
-                        if (__builtin_expect(k == gap, 0))
-                            report();
-                    }
+                arm_intervals<Q>(m, f + i0 * gap, i1 - i0, gap, i1 * gap == a.T, acc, [&]() {
+                    if (stretch == 1)
+                        report();
                 });
-                if (run && !aligned)
-                    report();
             }
         };
         if (quick)
             walk(std::true_type{});
         else
             walk(std::false_type{});
-        if (n_pieces == 1 && starts_run)
-            m.begin_run();
 #else
         // no rain and no evaporation in this step (forcing is wave-uniform: scalar unit); never when a layer may be
         // above its capacity (Model::zero_ok)

@@ -1,0 +1,254 @@
+// smart_fast_arms.h -- the step loop of sub-daily forcing at the instruction level: the TEXT of the gfx950 code, as
+// string macros that FastModel::step_arms / run_chunks (smart_fast_model.h) put into `asm` statements.
+//
+// step_lazy() (smart_fast_model.h) is ONE body for every kind of step, built around a predicated region; hipcc pays
+// for every other shape with register copies at the joins.  The forcing of a step is wave-uniform,
+// so what a step needs is known on the scalar unit before any vector work:
+//   rain == 0, peva > 0   DRY   every lane is on the dry side (ex = -peva whatever T is): route, add the demand to
+//                               `pend`, drain the reservoirs -- 9 vector instructions, no compare, no EXEC change;
+//   rain == 0, peva == 0  CALM  every lane is wet with zero excess: route, the three leak passes, reservoirs -- 51
+//                               instructions, no EXEC change, no filling;
+//   rain > 0              RAIN  the general step: excess per lane, wet lanes under EXEC, filling, leaks -- 84.
+// The deferred evaporation cascade (FastModel::flush_pending) is due in the calm and the rain arm when a wet lane has
+// a demand pending -- read from `pend` itself (lanes with something pending are exactly the lanes with pend > 0; the
+// lane mask step_lazy() carries says the same, but an SGPR pair that lives across `asm` statements is taken for
+// divergent by hipcc's uniformity analysis and refused).  It is due on one step in twelve and sits OUT OF LINE, in
+// the shadow of an unconditional branch, so that the usual step falls through.
+//
+// Operands pin every state to its register for good: arms meet without a copy.  The arithmetic is that of
+// step_lazy(), operation for operation (same operand order, same contractions): outputs are bit-identical
+// (tools/debug/steps_bits.py against a -DSMART_STEP_ARMS=0 build; profiles/r03_steps_bits.txt).
+// The shortcuts of the dry and the calm arm hold for forcing whose values are all finite and >= +0
+// (smart_forcing_scan) and waves with no layer above capacity (zero_ok): QUICK.  Any other wave takes the rain arm
+// for every step, which is step_lazy() without the calm shortcut.
+//
+// Two shapes:
+//   SMART_A_STEP      one step: dispatch, three arms (report gaps that are not a multiple of the chunk, tails);
+//   SMART_A_CHUNK     the four steps of a chunk (one 64-byte line of forcing), THREADED: the three arms are laid out
+//                     as three lanes of four steps each, and every arm ends with the dispatch of the NEXT step, whose
+//                     fall-through is the same lane -- a step of the kind of its predecessor (two in three) costs no
+//                     taken branch at all, any other exactly one.  A lone wave pays ~60 cycles for a taken branch
+//                     (profiles/r01_microbench_valu_salu_branch.txt), a dry step is 36 cycles of vector work.
+//
+// Manual hazards (gfx950; inline asm is opaque to hipcc's hazard recogniser): no vector instruction reads an SGPR
+// within two instructions of the v_cmp that wrote it (masks are read by scalar instructions, ten instructions
+// later); v_cmp -> s_cbranch_vccz/nz is interlocked; scalar loads are waited for with s_waitcnt lgkmcnt(0) before
+// their destinations are read.
+#pragma once
+
+// ---- pieces ---------------------------------------------------------------------------------------------------
+#define SMART_A_ROUTE                                                                                                  \
+    "v_mul_f64 %[t0], %[cg], %[yg]\n\t"                                                                                \
+    "v_fma_f64 %[t0], %[cf], %[yf], %[t0]\n\t"                                                                         \
+    "v_fma_f64 %[t0], %[cs], %[ys], %[t0]\n\t"                                                                         \
+    "v_add_f64 %[acc], %[acc], %[riv]\n\t"                                                                             \
+    "v_fma_f64 %[riv], %[riv], %[oma], %[t0]\n\t"
+// deferred evaporation cascade over the active lanes (flush_pending): t = d - l; l = max(-t, 0); d = max(C t, 0)
+#define SMART_A_CASCADE                                                                                                \
+    "v_add_f64 %[l0], %[pend], -%[l0]\n\t"                                                                             \
+    "v_mul_f64 %[t0], %[pc], %[l0]\n\t"                                                                                \
+    "v_max_f64 %[t0], %[t0], 0\n\t"                                                                                    \
+    "v_cmp_lt_f64 vcc, 0, %[t0]\n\t"                                                                                   \
+    "s_cbranch_vccz 2f\n\t"                                                                                            \
+    "v_add_f64 %[l1], %[t0], -%[l1]\n\t"                                                                               \
+    "v_mul_f64 %[t0], %[pc], %[l1]\n\t"                                                                                \
+    "v_max_f64 %[t0], %[t0], 0\n\t"                                                                                    \
+    "v_cmp_lt_f64 vcc, 0, %[t0]\n\t"                                                                                   \
+    "s_cbranch_vccz 1f\n\t"                                                                                            \
+    "v_add_f64 %[t0], %[t0], -%[l2]\n\t"                                                                               \
+    "v_max_f64 %[l2], -%[t0], 0\n\t"                                                                                   \
+    "v_mul_f64 %[t0], %[pc], %[t0]\n\t"                                                                                \
+    "v_max_f64 %[t0], %[t0], 0\n\t"                                                                                    \
+    "v_add_f64 %[t0], %[t0], -%[l3]\n\t"                                                                               \
+    "v_max_f64 %[l3], -%[t0], 0\n\t"                                                                                   \
+    "v_mul_f64 %[t0], %[pc], %[t0]\n\t"                                                                                \
+    "v_max_f64 %[t0], %[t0], 0\n\t"                                                                                    \
+    "v_add_f64 %[t0], %[t0], -%[l4]\n\t"                                                                               \
+    "v_max_f64 %[l4], -%[t0], 0\n\t"                                                                                   \
+    "v_mul_f64 %[t0], %[pc], %[t0]\n\t"                                                                                \
+    "v_max_f64 %[t0], %[t0], 0\n\t"                                                                                    \
+    "v_add_f64 %[l5], %[t0], -%[l5]\n\t"                                                                               \
+    "v_max_f64 %[l5], -%[l5], 0\n\t"                                                                                   \
+    "1:\n\t"                                                                                                           \
+    "v_max_f64 %[l1], -%[l1], 0\n\t"                                                                                   \
+    "2:\n\t"                                                                                                           \
+    "v_max_f64 %[l0], -%[l0], 0\n\t"                                                                                   \
+    "v_mov_b64 %[pend], 0\n\t"                                                                                         \
+    "v_add_f64 %[tot], %[l0], %[l1]\n\t"                                                                               \
+    "v_add_f64 %[t0], %[l2], %[l3]\n\t"                                                                                \
+    "v_add_f64 %[tot], %[tot], %[t0]\n\t"                                                                              \
+    "v_add_f64 %[t0], %[l4], %[l5]\n\t"                                                                                \
+    "v_add_f64 %[tot], %[tot], %[t0]\n\t"
+// top-down filling (structure.py:363-377): ex_in in xf, the saturation excess ends in t1
+#define SMART_A_FILL1(l, src)                                                                                          \
+    "v_add_f64 %[t1], %[" l "], %[" src "]\n\t"                                                                        \
+    "v_min_f64 %[" l "], %[t1], %[z]\n\t"                                                                              \
+    "v_add_f64 %[t1], %[t1], -%[" l "]\n\t"
+#define SMART_A_FILL                                                                                                   \
+    "v_mul_f64 %[eh], %[hz], %[ex]\n\t"                                                                                \
+    "v_fma_f64 %[xf], -%[eh], %[tot], %[ex]\n\t" SMART_A_FILL1("l0", "xf") SMART_A_FILL1("l1", "t1")                   \
+        SMART_A_FILL1("l2", "t1") SMART_A_FILL1("l3", "t1") SMART_A_FILL1("l4", "t1") SMART_A_FILL1("l5", "t1")        \
+            "v_mul_f64 %[xs], %[eh], %[tot]\n\t"                                                                       \
+            "v_fma_f64 %[xf], -%[pd], %[t1], %[xf]\n\t"                                                                \
+            "v_fma_f64 %[xs], %[pd], %[t1], %[xs]\n\t"
+// s', s'^2 and s'^3 live in the registers of three temporaries that are dead by the time the leaks start (the excess,
+// e_h and the routing / cascade temporary): 6 VGPRs less
+#define SMART_S1 "ex"
+#define SMART_P2 "eh"
+#define SMART_P3 "t0"
+#define SMART_A_LEAK(l, p) "v_fma_f64 %[" l "], -%[" l "], %[" p "], %[" l "]\n\t"
+#define SMART_A_LSUM(dst)                                                                                              \
+    "v_add_f64 %[" dst "], %[l1], %[l0]\n\t"                                                                           \
+    "v_add_f64 %[t1], %[l3], %[l2]\n\t"                                                                                \
+    "v_add_f64 %[" dst "], %[t1], %[" dst "]\n\t"                                                                      \
+    "v_add_f64 %[t1], %[l5], %[l4]\n\t"                                                                                \
+    "v_add_f64 %[" dst "], %[t1], %[" dst "]\n\t"
+// the three leak passes (structure.py:381-399); `deep`: the SPLIT models' sum of what the third pass takes
+#define SMART_A_LEAKS(deep)                                                                                            \
+    "v_mul_f64 %[" SMART_S1 "], %[sz], %[tot]\n\t"                                                                     \
+    "v_mul_f64 %[" SMART_P2 "], %[" SMART_S1 "], %[" SMART_S1 "]\n\t"                                                  \
+    "v_mul_f64 %[" SMART_P3 "], %[" SMART_S1 "], %[" SMART_P2 "]\n\t"                                                  \
+    "v_mul_f64 %[p4], %[" SMART_P2 "], %[" SMART_P2 "]\n\t"                                                            \
+    "v_mul_f64 %[p5], %[" SMART_S1 "], %[p4]\n\t"                                                                      \
+    "v_mul_f64 %[p6], %[" SMART_P3 "], %[" SMART_P3 "]\n\t" SMART_A_LEAK("l0", SMART_S1) SMART_A_LEAK("l1", SMART_P2)  \
+        SMART_A_LEAK("l2", SMART_P3) SMART_A_LEAK("l3", "p4") SMART_A_LEAK("l4", "p5") SMART_A_LEAK("l5", "p6")        \
+            SMART_A_LSUM("ai") SMART_A_LEAK("l0", SMART_S1) "v_mul_f64 %[t1], %[" SMART_S1 "], -0.5\n\t"               \
+                                                            "v_fma_f64 %[l1], %[l1], %[t1], %[l1]\n\t"                 \
+                                                            "v_mul_f64 %[t1], %[" SMART_S1 "], %[k3]\n\t"              \
+                                                            "v_fma_f64 %[l2], %[l2], %[t1], %[l2]\n\t"                 \
+                                                            "v_ldexp_f64 %[t1], -%[" SMART_S1 "], -2\n\t"              \
+                                                            "v_fma_f64 %[l3], %[l3], %[t1], %[l3]\n\t"                 \
+                                                            "v_mul_f64 %[t1], %[" SMART_S1 "], %[k5]\n\t"              \
+                                                            "v_fma_f64 %[l4], %[l4], %[t1], %[l4]\n\t"                 \
+                                                            "v_mul_f64 %[t1], %[" SMART_S1 "], %[k6]\n\t"              \
+                                                            "v_fma_f64 %[l5], %[l5], %[t1], %[l5]\n\t" deep            \
+                SMART_A_LEAK("l0", "p6") SMART_A_LEAK("l1", "p5") SMART_A_LEAK("l2", "p4")                             \
+                    SMART_A_LEAK("l3", SMART_P3) SMART_A_LEAK("l4", SMART_P2) SMART_A_LEAK("l5", SMART_S1)
+#define SMART_A_DEEP                                                                                                   \
+    "v_mul_f64 %[dp], %[l0], %[p6]\n\t"                                                                                \
+    "v_fma_f64 %[dp], %[l1], %[p5], %[dp]\n\t"                                                                         \
+    "v_fma_f64 %[dp], %[l2], %[p4], %[dp]\n\t"                                                                         \
+    "v_fma_f64 %[dp], %[l3], %[" SMART_P3 "], %[dp]\n\t"                                                               \
+    "v_fma_f64 %[dp], %[l4], %[" SMART_P2 "], %[dp]\n\t"                                                               \
+    "v_fma_f64 %[dp], %[l5], %[" SMART_S1 "], %[dp]\n\t"
+#define SMART_A_TOT_XG SMART_A_LSUM("tot") "v_add_f64 %[xg], %[ai], -%[tot]\n\t"
+
+// ---- the three arms.  pe / rn: names of the SGPR operands that hold the step's forcing; casc: the hook of the
+// deferred cascade (SMART_A_CASC_*); deep / split / zeros / drain: what the SPLIT models add ("" otherwise)
+#define SMART_A_DRY(pe, split)                                                                                         \
+    SMART_A_ROUTE "v_add_f64 %[pend], %[pend], %[" pe "]\n\t"                                                          \
+                  "v_fma_f64 %[ys], %[ys], %[ds], 0\n\t"                                                               \
+                  "v_fma_f64 %[yf], %[yf], %[df], 0\n\t"                                                               \
+                  "v_fma_f64 %[yg], %[yg], %[dg], 0\n\t" split
+#define SMART_A_DRY_SPLIT                                                                                              \
+    "v_fma_f64 %[yd], %[yd], %[ds], 0\n\t"                                                                             \
+    "v_fma_f64 %[ydg], %[ydg], %[dg], 0\n\t"
+#define SMART_A_CALM(casc, deep, split)                                                                                \
+    "v_cmp_lt_f64 vcc, 0, %[pend]\n\t" SMART_A_ROUTE casc SMART_A_LEAKS(deep) "v_add_f64 %[xf], %[tot], -%[ai]\n\t"    \
+        SMART_A_TOT_XG "v_fma_f64 %[ys], %[ys], %[ds], 0\n\t"                                                          \
+                       "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                                      \
+                       "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                                      \
+                       "v_add_f64 %[xgs], %[xgs], %[xg]\n\t" split
+#define SMART_A_CALM_SPLIT                                                                                             \
+    "v_fma_f64 %[yd], %[yd], %[ds], 0\n\t"                                                                             \
+    "v_fma_f64 %[ydg], %[ydg], %[dg], %[dp]\n\t"
+#define SMART_A_RAIN(rn, pe, casc, zeros, drain, deep, split)                                                          \
+    "v_mov_b64 %[t1], %[" pe "]\n\t"                                                                                   \
+    "v_fma_f64 %[ex], %[" rn "], %[pt], -%[t1]\n\t"                                                                    \
+    "v_cmp_le_f64 %[wm], 0, %[ex]\n\t"                                                                                 \
+    "v_cmp_lt_f64 %[tmp], 0, %[pend]\n\t" SMART_A_ROUTE "v_max_f64 %[t1], -%[ex], 0\n\t"                               \
+                                                        "v_add_f64 %[pend], %[pend], %[t1]\n\t"                        \
+                                                        "v_mov_b64 %[xs], 0\n\t"                                       \
+                                                        "v_mov_b64 %[xf], 0\n\t"                                       \
+                                                        "v_mov_b64 %[xg], 0\n\t" zeros                                 \
+                                                        "s_and_saveexec_b64 %[sv], %[wm]\n\t"                          \
+                                                        "s_cbranch_execz 8f\n\t"                                       \
+                                                        "s_and_b64 %[tmp], %[tmp], %[wm]\n\t" casc SMART_A_FILL drain  \
+        SMART_A_LEAKS(deep) "v_add_f64 %[t1], %[tot], -%[ai]\n\t"                                                      \
+                            "v_add_f64 %[xf], %[xf], %[t1]\n\t" SMART_A_TOT_XG "8:\n\t"                                \
+                            "s_or_b64 exec, exec, %[sv]\n\t"                                                           \
+                            "v_fma_f64 %[ys], %[ys], %[ds], %[xs]\n\t"                                                 \
+                            "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                                 \
+                            "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                                 \
+                            "v_add_f64 %[xgs], %[xgs], %[xg]\n\t" split
+#define SMART_A_RAIN_ZEROS_SPLIT "v_mov_b64 %[xd], 0\n\tv_mov_b64 %[dp], 0\n\t"
+#define SMART_A_RAIN_DRAIN_SPLIT "v_mul_f64 %[xd], %[pd], %[t1]\n\t"
+#define SMART_A_RAIN_SPLIT                                                                                             \
+    "v_fma_f64 %[yd], %[yd], %[ds], %[xd]\n\t"                                                                         \
+    "v_fma_f64 %[ydg], %[ydg], %[dg], %[dp]\n\t"
+// the cascade hook of an arm and its out-of-line block; `id`: digits that make the two labels unique in the asm.
+// SMART_ARM_OOL 0 keeps the cascade in line, skipped by a taken branch when it is not due (A/B: tools/gpu_r03_*.sh)
+#ifndef SMART_ARM_OOL
+#define SMART_ARM_OOL 1
+#endif
+#if SMART_ARM_OOL
+#define SMART_A_CASC_CALM(id) "s_cbranch_vccnz 3" id "0f\n\t3" id "1:\n\t"
+#define SMART_A_CASC_CALM_OOL(id) "3" id "0:\n\t" SMART_A_CASCADE "s_branch 3" id "1b\n\t"
+#define SMART_A_CASC_RAIN(id) "s_cbranch_scc1 4" id "0f\n\t4" id "1:\n\t"
+#define SMART_A_CASC_RAIN_OOL(id) "4" id "0:\n\t" SMART_A_CASCADE "s_branch 4" id "1b\n\t"
+#else
+#define SMART_A_CASC_CALM(id) "s_cbranch_vccz 3" id "1f\n\t" SMART_A_CASCADE "3" id "1:\n\t"
+#define SMART_A_CASC_CALM_OOL(id) ""
+#define SMART_A_CASC_RAIN(id) "s_cbranch_scc0 4" id "1f\n\t" SMART_A_CASCADE "4" id "1:\n\t"
+#define SMART_A_CASC_RAIN_OOL(id) ""
+#endif
+
+// ---- one step ---------------------------------------------------------------------------------------------------
+// dispatch, calm arm (entered by falling through), rain arm, dry arm (left by falling through): one taken branch per
+// calm or dry step, two per rain step
+#define SMART_A_STEP(deep, calm_split, zeros, drain, rain_split, dry_split)                                            \
+    "s_cmp_eq_u64 %[rn0], 0\n\t"                                                                                       \
+    "s_cbranch_scc0 5f\n\t"                                                                                            \
+    "s_cmp_eq_u64 %[pe0], 0\n\t"                                                                                       \
+    "s_cbranch_scc0 7f\n\t" SMART_A_CALM(SMART_A_CASC_CALM("9"), deep, calm_split) "s_branch 9f\n\t"                   \
+        SMART_A_CASC_CALM_OOL("9") "5:\n\t" SMART_A_RAIN("rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros, drain, deep,     \
+                                                         rain_split) "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL("9")      \
+                                   "7:\n\t" SMART_A_DRY("pe0", dry_split) "9:\n\t"
+// the rain arm alone (waves that may not take the shortcuts)
+#define SMART_A_STEP_RAIN(deep, zeros, drain, rain_split)                                                              \
+    SMART_A_RAIN("rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros, drain, deep, rain_split)                                 \
+    "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL("9") "9:\n\t"
+
+// ---- a chunk of four steps, threaded ---------------------------------------------------------------------------
+// Three lanes of four arms each, calm / rain / dry.  A lane's step j ends with the dispatch of step j + 1, whose
+// fall-through is the same lane; after step 3 the calm and the rain lane jump to the end of the chunk, the dry lane
+// (laid out last: the most frequent kind) falls out of it.  The out-of-line cascades sit behind those two jumps.
+// Labels: 10j / 11j / 12j = calm / dry / rain arm of step j; 130 = end of chunk.
+// Operands beyond the arms': rn0..rn3, pe0..pe3 = the forcing of the four steps.
+#define SMART_A_NEXT_FROM_CALM(j)                                                                                      \
+    "s_cmp_eq_u64 %[rn" j "], 0\n\t"                                                                                   \
+    "s_cbranch_scc0 12" j "f\n\t"                                                                                      \
+    "s_cmp_eq_u64 %[pe" j "], 0\n\t"                                                                                   \
+    "s_cbranch_scc0 11" j "f\n\t"
+#define SMART_A_NEXT_FROM_RAIN(j)                                                                                      \
+    "s_or_b64 %[tmp], %[rn" j "], %[pe" j "]\n\t"                                                                      \
+    "s_cbranch_scc0 10" j "b\n\t"                                                                                      \
+    "s_cmp_eq_u64 %[rn" j "], 0\n\t"                                                                                   \
+    "s_cbranch_scc1 11" j "f\n\t"
+#define SMART_A_NEXT_FROM_DRY(j)                                                                                       \
+    "s_cmp_eq_u64 %[rn" j "], 0\n\t"                                                                                   \
+    "s_cbranch_scc0 12" j "b\n\t"                                                                                      \
+    "s_cmp_eq_u64 %[pe" j "], 0\n\t"                                                                                   \
+    "s_cbranch_scc1 10" j "b\n\t"
+#define SMART_A_CALM_J(j, deep, split) "10" j ":\n\t" SMART_A_CALM(SMART_A_CASC_CALM(j), deep, split)
+#define SMART_A_DRY_J(j, split) "11" j ":\n\t" SMART_A_DRY("pe" j, split)
+#define SMART_A_RAIN_J(j, zeros, drain, deep, split)                                                                   \
+    "12" j ":\n\t" SMART_A_RAIN("rn" j, "pe" j, SMART_A_CASC_RAIN(j), zeros, drain, deep, split)
+#define SMART_A_CHUNK(deep, calm_split, zeros, drain, rain_split, dry_split)                                           \
+    SMART_A_NEXT_FROM_CALM("0") SMART_A_CALM_J("0", deep, calm_split) SMART_A_NEXT_FROM_CALM("1")                      \
+    SMART_A_CALM_J("1", deep, calm_split) SMART_A_NEXT_FROM_CALM("2") SMART_A_CALM_J("2", deep, calm_split)            \
+    SMART_A_NEXT_FROM_CALM("3") SMART_A_CALM_J("3", deep, calm_split) "s_branch 130f\n\t"                              \
+    SMART_A_CASC_CALM_OOL("0") SMART_A_CASC_CALM_OOL("1") SMART_A_CASC_CALM_OOL("2") SMART_A_CASC_CALM_OOL("3")        \
+    SMART_A_RAIN_J("0", zeros, drain, deep, rain_split) SMART_A_NEXT_FROM_RAIN("1")                                    \
+    SMART_A_RAIN_J("1", zeros, drain, deep, rain_split) SMART_A_NEXT_FROM_RAIN("2")                                    \
+    SMART_A_RAIN_J("2", zeros, drain, deep, rain_split) SMART_A_NEXT_FROM_RAIN("3")                                    \
+    SMART_A_RAIN_J("3", zeros, drain, deep, rain_split) "s_branch 130f\n\t"                                            \
+    SMART_A_CASC_RAIN_OOL("0") SMART_A_CASC_RAIN_OOL("1") SMART_A_CASC_RAIN_OOL("2") SMART_A_CASC_RAIN_OOL("3")        \
+    SMART_A_DRY_J("0", dry_split) SMART_A_NEXT_FROM_DRY("1") SMART_A_DRY_J("1", dry_split) SMART_A_NEXT_FROM_DRY("2")  \
+    SMART_A_DRY_J("2", dry_split) SMART_A_NEXT_FROM_DRY("3") SMART_A_DRY_J("3", dry_split) "130:\n\t"
+// not QUICK: the rain arm four times
+#define SMART_A_CHUNK_RAIN(deep, zeros, drain, rain_split)                                                             \
+    SMART_A_RAIN_J("0", zeros, drain, deep, rain_split) SMART_A_RAIN_J("1", zeros, drain, deep, rain_split)            \
+    SMART_A_RAIN_J("2", zeros, drain, deep, rain_split) SMART_A_RAIN_J("3", zeros, drain, deep, rain_split)            \
+    "s_branch 130f\n\t" SMART_A_CASC_RAIN_OOL("0") SMART_A_CASC_RAIN_OOL("1") SMART_A_CASC_RAIN_OOL("2")               \
+    SMART_A_CASC_RAIN_OOL("3") "130:\n\t"

@@ -37,6 +37,7 @@
 #pragma once
 
 #include "smart_device.h"
+#include "smart_fast_arms.h"
 
 #ifndef SMART_FAST_EARLY_EXIT
 #define SMART_FAST_EARLY_EXIT 1
@@ -763,251 +764,90 @@ struct FastModel {
         xg_sum += x_g;
     }
 
-    // ---- the step loop at the instruction level: three arms, picked on the scalar unit -----------------------------
-    // step_lazy() above is ONE body for every kind of step, built around a predicated region; hipcc pays for every
-    // other shape with register copies at the joins.  The forcing of a step is wave-uniform, so what a
-    // step needs is known on the scalar unit before any vector work:
-    //   rain == 0, peva > 0   DRY   every lane is on the dry side (ex = -peva whatever T is): route, add the demand to
-    //                               `pend`, drain the reservoirs -- 9 vector instructions, no compare, no EXEC change;
-    //   rain == 0, peva == 0  CALM  every lane is wet with zero excess: route, (deferred cascade), the three leak
-    //                               passes, reservoirs -- 50 instructions, no compare, no EXEC change, no filling;
-    //   rain > 0              RAIN  the general step: excess per lane, wet lanes under EXEC, cascade when a wet lane
-    //                               has a demand pending, filling, leaks -- 83 instructions.
-    // Whether the deferred cascade is due is read from `pend` itself (lanes with something pending are exactly the
-    // lanes with pend > 0: the lane mask step_lazy() carries for this says the same, but an SGPR pair that lives
-    // across `asm` statements is taken for divergent by hipcc's uniformity analysis and refused).
-    // Each arm is one `asm` whose operands pin every state to its register for good: the arms meet without a single
-    // copy, the exits of the cascade and the EXEC region are local labels inside the arm.  The arithmetic is that of
-    // step_lazy(), operation for operation (same operand order, same contractions): outputs are bit-identical
-    // (tests/test_gpu_parity.py::test_step_arms_match_the_compiled_step; SMART_STEP_ARMS=0 builds the old loop).
-    // Only for forcing whose values are all finite and >= +0 (smart_forcing_scan) and waves with no layer above
-    // capacity (zero_ok); any other wave takes the RAIN arm for every step, which is step_lazy() without the calm
-    // shortcut.
-    //
-    // Manual hazards (gfx950, inline asm is opaque to the hazard recogniser): no vector instruction reads an SGPR
-    // within two instructions of the v_cmp that wrote it (the wet mask is first read by s_and_saveexec, a scalar
-    // instruction, ten instructions later); v_cmp -> s_cbranch_vccz is interlocked.
-#define SMART_A_ROUTE                                                                                                  \
-    "v_mul_f64 %[t0], %[cg], %[yg]\n\t"                                                                                \
-    "v_fma_f64 %[t0], %[cf], %[yf], %[t0]\n\t"                                                                         \
-    "v_fma_f64 %[t0], %[cs], %[ys], %[t0]\n\t"                                                                         \
-    "v_add_f64 %[acc], %[acc], %[riv]\n\t"                                                                             \
-    "v_fma_f64 %[riv], %[riv], %[oma], %[t0]\n\t"
-    // deferred evaporation cascade over the active lanes (flush_pending): t = d - l; l = max(-t, 0); d = max(C t, 0)
-#define SMART_A_CASCADE                                                                                                \
-    "v_add_f64 %[l0], %[pend], -%[l0]\n\t"                                                                             \
-    "v_mul_f64 %[t0], %[pc], %[l0]\n\t"                                                                                \
-    "v_max_f64 %[t0], %[t0], 0\n\t"                                                                                    \
-    "v_cmp_lt_f64 vcc, 0, %[t0]\n\t"                                                                                   \
-    "s_cbranch_vccz 2f\n\t"                                                                                            \
-    "v_add_f64 %[l1], %[t0], -%[l1]\n\t"                                                                               \
-    "v_mul_f64 %[t0], %[pc], %[l1]\n\t"                                                                                \
-    "v_max_f64 %[t0], %[t0], 0\n\t"                                                                                    \
-    "v_cmp_lt_f64 vcc, 0, %[t0]\n\t"                                                                                   \
-    "s_cbranch_vccz 1f\n\t"                                                                                            \
-    "v_add_f64 %[t0], %[t0], -%[l2]\n\t"                                                                               \
-    "v_max_f64 %[l2], -%[t0], 0\n\t"                                                                                   \
-    "v_mul_f64 %[t0], %[pc], %[t0]\n\t"                                                                                \
-    "v_max_f64 %[t0], %[t0], 0\n\t"                                                                                    \
-    "v_add_f64 %[t0], %[t0], -%[l3]\n\t"                                                                               \
-    "v_max_f64 %[l3], -%[t0], 0\n\t"                                                                                   \
-    "v_mul_f64 %[t0], %[pc], %[t0]\n\t"                                                                                \
-    "v_max_f64 %[t0], %[t0], 0\n\t"                                                                                    \
-    "v_add_f64 %[t0], %[t0], -%[l4]\n\t"                                                                               \
-    "v_max_f64 %[l4], -%[t0], 0\n\t"                                                                                   \
-    "v_mul_f64 %[t0], %[pc], %[t0]\n\t"                                                                                \
-    "v_max_f64 %[t0], %[t0], 0\n\t"                                                                                    \
-    "v_add_f64 %[l5], %[t0], -%[l5]\n\t"                                                                               \
-    "v_max_f64 %[l5], -%[l5], 0\n\t"                                                                                   \
-    "1:\n\t"                                                                                                           \
-    "v_max_f64 %[l1], -%[l1], 0\n\t"                                                                                   \
-    "2:\n\t"                                                                                                           \
-    "v_max_f64 %[l0], -%[l0], 0\n\t"                                                                                   \
-    "v_mov_b64 %[pend], 0\n\t"                                                                                         \
-    "v_add_f64 %[tot], %[l0], %[l1]\n\t"                                                                               \
-    "v_add_f64 %[t0], %[l2], %[l3]\n\t"                                                                                \
-    "v_add_f64 %[tot], %[tot], %[t0]\n\t"                                                                              \
-    "v_add_f64 %[t0], %[l4], %[l5]\n\t"                                                                                \
-    "v_add_f64 %[tot], %[tot], %[t0]\n\t"
-    // top-down filling (structure.py:363-377): ex_in in xf, the saturation excess ends in t1
-#define SMART_A_FILL1(l, src)                                                                                          \
-    "v_add_f64 %[t1], %[" l "], %[" src "]\n\t"                                                                        \
-    "v_min_f64 %[" l "], %[t1], %[z]\n\t"                                                                              \
-    "v_add_f64 %[t1], %[t1], -%[" l "]\n\t"
-#define SMART_A_FILL                                                                                                   \
-    "v_mul_f64 %[eh], %[hz], %[ex]\n\t"                                                                                \
-    "v_fma_f64 %[xf], -%[eh], %[tot], %[ex]\n\t"                                                                       \
-    SMART_A_FILL1("l0", "xf") SMART_A_FILL1("l1", "t1") SMART_A_FILL1("l2", "t1") SMART_A_FILL1("l3", "t1")            \
-    SMART_A_FILL1("l4", "t1") SMART_A_FILL1("l5", "t1")                                                                \
-    "v_mul_f64 %[xs], %[eh], %[tot]\n\t"                                                                               \
-    "v_fma_f64 %[xf], -%[pd], %[t1], %[xf]\n\t"                                                                        \
-    "v_fma_f64 %[xs], %[pd], %[t1], %[xs]\n\t"
-#define SMART_A_LEAK(l, p) "v_fma_f64 %[" l "], -%[" l "], %[" p "], %[" l "]\n\t"
-#define SMART_A_LSUM(dst)                                                                                              \
-    "v_add_f64 %[" dst "], %[l1], %[l0]\n\t"                                                                           \
-    "v_add_f64 %[t1], %[l3], %[l2]\n\t"                                                                                \
-    "v_add_f64 %[" dst "], %[t1], %[" dst "]\n\t"                                                                      \
-    "v_add_f64 %[t1], %[l5], %[l4]\n\t"                                                                                \
-    "v_add_f64 %[" dst "], %[t1], %[" dst "]\n\t"
-    // the three leak passes (structure.py:381-399), `deep`: the SPLIT models' sum of the third pass; ends with
-    // t1 = tot - (sum after the first pass), tot = the layer sum after the step, xg = what the groundwater gets
-#define SMART_A_LEAKS(deep)                                                                                            \
-    "v_mul_f64 %[" S1 "], %[sz], %[tot]\n\t"                                                                               \
-    "v_mul_f64 %[" P2 "], %[" S1 "], %[" S1 "]\n\t"                                                                                \
-    "v_mul_f64 %[" P3 "], %[" S1 "], %[" P2 "]\n\t"                                                                                \
-    "v_mul_f64 %[p4], %[" P2 "], %[" P2 "]\n\t"                                                                                \
-    "v_mul_f64 %[p5], %[" S1 "], %[p4]\n\t"                                                                                \
-    "v_mul_f64 %[p6], %[" P3 "], %[" P3 "]\n\t"                                                                                \
-    SMART_A_LEAK("l0", S1) SMART_A_LEAK("l1", P2) SMART_A_LEAK("l2", P3) SMART_A_LEAK("l3", "p4")                \
-    SMART_A_LEAK("l4", "p5") SMART_A_LEAK("l5", "p6")                                                                  \
-    SMART_A_LSUM("ai")                                                                                                 \
-    SMART_A_LEAK("l0", S1)                                                                                           \
-    "v_mul_f64 %[t1], %[" S1 "], -0.5\n\t"                                                                                 \
-    "v_fma_f64 %[l1], %[l1], %[t1], %[l1]\n\t"                                                                         \
-    "v_mul_f64 %[t1], %[" S1 "], %[k3]\n\t"                                                                                \
-    "v_fma_f64 %[l2], %[l2], %[t1], %[l2]\n\t"                                                                         \
-    "v_ldexp_f64 %[t1], -%[" S1 "], -2\n\t"                                                                                \
-    "v_fma_f64 %[l3], %[l3], %[t1], %[l3]\n\t"                                                                         \
-    "v_mul_f64 %[t1], %[" S1 "], %[k5]\n\t"                                                                                \
-    "v_fma_f64 %[l4], %[l4], %[t1], %[l4]\n\t"                                                                         \
-    "v_mul_f64 %[t1], %[" S1 "], %[k6]\n\t"                                                                                \
-    "v_fma_f64 %[l5], %[l5], %[t1], %[l5]\n\t"                                                                         \
-    deep                                                                                                               \
-    SMART_A_LEAK("l0", "p6") SMART_A_LEAK("l1", "p5") SMART_A_LEAK("l2", "p4") SMART_A_LEAK("l3", P3)                \
-    SMART_A_LEAK("l4", P2) SMART_A_LEAK("l5", S1)
-#define SMART_A_DEEP                                                                                                   \
-    "v_mul_f64 %[dp], %[l0], %[p6]\n\t"                                                                                \
-    "v_fma_f64 %[dp], %[l1], %[p5], %[dp]\n\t"                                                                         \
-    "v_fma_f64 %[dp], %[l2], %[p4], %[dp]\n\t"                                                                         \
-    "v_fma_f64 %[dp], %[l3], %[" P3 "], %[dp]\n\t"                                                                         \
-    "v_fma_f64 %[dp], %[l4], %[" P2 "], %[dp]\n\t"                                                                         \
-    "v_fma_f64 %[dp], %[l5], %[" S1 "], %[dp]\n\t"
-#define SMART_A_TOT_XG                                                                                                 \
-    SMART_A_LSUM("tot")                                                                                                \
-    "v_add_f64 %[xg], %[ai], -%[tot]\n\t"
-#define SMART_ARM_LAYERS [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), [l4] "+v"(l4), [l5] "+v"(l5)
-#define SMART_ARM_ROUTED                                                                                               \
-    [ys] "+v"(u_ove), [yf] "+v"(u_int), [yg] "+v"(u_sgw), [riv] "+v"(u_riv), [acc] "+v"(acc)
-#define SMART_ARM_ROUTE_K [cs] "v"(car_s), [cf] "v"(car_f), [cg] "v"(car_g), [oma] "v"(om_ar)
-#define SMART_ARM_DECAYS [ds] "v"(dec_s), [df] "v"(dec_f), [dg] "v"(dec_g)
-    // s', s'^2 and s'^3 live in the registers of three temporaries that are dead by the time the leaks start (the
-    // excess, e_h and the routing / cascade temporary): 6 VGPRs less
-#define S1 "ex"
-#define P2 "eh"
-#define P3 "t0"
-#define SMART_ARM_POWERS [p4] "=&v"(w_p4), [p5] "=&v"(w_p5), [p6] "=&v"(w_p6), [ai] "=&v"(w_ai)
-#define SMART_ARM_THIRDS [k3] "s"(-(1.0 / 3.0)), [k5] "s"(-0.2), [k6] "s"(-(1.0 / 6.0))
+    // ---- the step loop at the instruction level (smart_fast_arms.h has the text and the story) ----------------------
+#define SMART_ARM_STATES                                                                                               \
+    [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), [l4] "+v"(l4), [l5] "+v"(l5), [ys] "+v"(u_ove),       \
+        [yf] "+v"(u_int), [yg] "+v"(u_sgw), [riv] "+v"(u_riv), [acc] "+v"(acc), [tot] "+v"(tot_c), [pend] "+v"(pend),  \
+        [xgs] "+v"(xg_sum)
+#define SMART_ARM_TEMPS                                                                                                \
+    [t0] "=&v"(t0), [t1] "=&v"(t1), [ex] "=&v"(ex), [eh] "=&v"(eh), [xs] "=&v"(xs), [xf] "=&v"(xf), [xg] "=&v"(xg),   \
+        [p4] "=&v"(w_p4), [p5] "=&v"(w_p5), [p6] "=&v"(w_p6), [ai] "=&v"(w_ai), [wm] "=&s"(wm), [sv] "=&s"(sv),       \
+        [tmp] "=&s"(tmp)
+#define SMART_ARM_SPLIT [yd] "+v"(u_dra), [ydg] "+v"(u_dgw), [xd] "=&v"(xd), [dp] "=&v"(dp)
+#define SMART_ARM_CONSTS                                                                                               \
+    [cs] "v"(car_s), [cf] "v"(car_f), [cg] "v"(car_g), [oma] "v"(om_ar), [ds] "v"(dec_s), [df] "v"(dec_f),            \
+        [dg] "v"(dec_g), [sz] "v"(sz), [hz] "v"(hz), [z] "v"(z), [pd] "v"(pD), [pc] "v"(pC), [pt] "v"(pT),            \
+        [k3] "s"(-(1.0 / 3.0)), [k5] "s"(-0.2), [k6] "s"(-(1.0 / 6.0))
+#define SMART_ARM_LOCALS                                                                                               \
+    double t0, t1, ex, eh, xs, xf, xg, w_p4, w_p5, w_p6, w_ai;                                                         \
+    unsigned long long wm, sv, tmp
 
-#define SMART_A_DRY(split)                                                                                             \
-    SMART_A_ROUTE "v_add_f64 %[pend], %[pend], %[pe]\n\t"                                                              \
-                  "v_fma_f64 %[ys], %[ys], %[ds], 0\n\t"                                                               \
-                  "v_fma_f64 %[yf], %[yf], %[df], 0\n\t"                                                               \
-                  "v_fma_f64 %[yg], %[yg], %[dg], 0\n\t" split
-#define SMART_A_DRY_SPLIT                                                                                              \
-    "v_fma_f64 %[yd], %[yd], %[ds], 0\n\t"                                                                             \
-    "v_fma_f64 %[ydg], %[ydg], %[dg], 0\n\t"
-    // The deferred cascade is due on one step in twelve: it sits out of line, behind the arm's closing branch, so that
-    // the usual step falls through (SMART_ARM_OOL 0: in line, skipped by a taken branch -- 16.5 against ... ms)
-#ifndef SMART_ARM_OOL
-#define SMART_ARM_OOL 1
-#endif
-#if SMART_ARM_OOL
-#define SMART_A_CASC_CALM "s_cbranch_vccnz 30f\n\t31:\n\t"
-#define SMART_A_CASC_CALM_OOL "30:\n\t" SMART_A_CASCADE "s_branch 31b\n\t"
-#define SMART_A_CASC_RAIN "s_cbranch_scc1 32f\n\t33:\n\t"
-#define SMART_A_CASC_RAIN_OOL "32:\n\t" SMART_A_CASCADE "s_branch 33b\n\t"
-#else
-#define SMART_A_CASC_CALM "s_cbranch_vccz 3f\n\t" SMART_A_CASCADE "3:\n\t"
-#define SMART_A_CASC_CALM_OOL ""
-#define SMART_A_CASC_RAIN "s_cbranch_scc0 3f\n\t" SMART_A_CASCADE "3:\n\t"
-#define SMART_A_CASC_RAIN_OOL ""
-#endif
-#define SMART_A_CALM(deep, split)                                                                                      \
-    "v_cmp_lt_f64 vcc, 0, %[pend]\n\t" SMART_A_ROUTE SMART_A_CASC_CALM SMART_A_LEAKS(deep)                              \
-                  "v_add_f64 %[xf], %[tot], -%[ai]\n\t" SMART_A_TOT_XG "v_fma_f64 %[ys], %[ys], %[ds], 0\n\t"          \
-                  "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                                           \
-                  "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                                           \
-                  "v_add_f64 %[xgs], %[xgs], %[xg]\n\t" split
-#define SMART_A_CALM_SPLIT                                                                                             \
-    "v_fma_f64 %[yd], %[yd], %[ds], 0\n\t"                                                                             \
-    "v_fma_f64 %[ydg], %[ydg], %[dg], %[dp]\n\t"
-#define SMART_A_RAIN(zeros, drain, deep, split)                                                                        \
-    "v_mov_b64 %[t1], %[pe]\n\t"                                                                                       \
-    "v_fma_f64 %[ex], %[rain], %[pt], -%[t1]\n\t"                                                                      \
-    "v_cmp_le_f64 %[wm], 0, %[ex]\n\t"                                                                                 \
-    "v_cmp_lt_f64 %[tmp], 0, %[pend]\n\t" SMART_A_ROUTE "v_max_f64 %[t1], -%[ex], 0\n\t"                               \
-    "v_add_f64 %[pend], %[pend], %[t1]\n\t"                                                                            \
-    "v_mov_b64 %[xs], 0\n\t"                                                                                           \
-    "v_mov_b64 %[xf], 0\n\t"                                                                                           \
-    "v_mov_b64 %[xg], 0\n\t" zeros "s_and_saveexec_b64 %[sv], %[wm]\n\t"                                               \
-    "s_cbranch_execz 8f\n\t"                                                                                           \
-    "s_and_b64 %[tmp], %[tmp], %[wm]\n\t"                                                                              \
-    SMART_A_CASC_RAIN SMART_A_FILL drain SMART_A_LEAKS(deep)                                                           \
-    "v_add_f64 %[t1], %[tot], -%[ai]\n\t"                                                                              \
-    "v_add_f64 %[xf], %[xf], %[t1]\n\t" SMART_A_TOT_XG "8:\n\t"                                                        \
-    "s_or_b64 exec, exec, %[sv]\n\t"                                                                                   \
-    "v_fma_f64 %[ys], %[ys], %[ds], %[xs]\n\t"                                                                         \
-    "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                                                         \
-    "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                                                         \
-    "v_add_f64 %[xgs], %[xgs], %[xg]\n\t" split
-#define SMART_A_RAIN_ZEROS_SPLIT "v_mov_b64 %[xd], 0\n\tv_mov_b64 %[dp], 0\n\t"
-#define SMART_A_RAIN_DRAIN_SPLIT "v_mul_f64 %[xd], %[pd], %[t1]\n\t"
-#define SMART_A_RAIN_SPLIT                                                                                             \
-    "v_fma_f64 %[yd], %[yd], %[ds], %[xd]\n\t"                                                                         \
-    "v_fma_f64 %[ydg], %[ydg], %[dg], %[dp]\n\t"
-    // the step: which arm is a scalar decision on the step's own forcing.  Laid out so that the cheap dry arm leaves by
-    // falling through and the calm arm is entered by falling through: one taken branch per dry or calm step, two per
-    // rain step.
-#define SMART_A_STEP(calm, rain, dry)                                                                                  \
-    "s_cmp_eq_u64 %[rain], 0\n\t"                                                                                      \
-    "s_cbranch_scc0 5f\n\t"                                                                                            \
-    "s_cmp_eq_u64 %[pe], 0\n\t"                                                                                        \
-    "s_cbranch_scc0 7f\n\t" calm "s_branch 9f\n\t" SMART_A_CASC_CALM_OOL "5:\n\t" rain                                \
-    "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL "7:\n\t" dry "9:\n\t"
-    // the rain arm alone (waves that may not take the shortcuts)
-#define SMART_A_STEP_RAIN(rain) rain "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL "9:\n\t"
-#define SMART_ARM_OUT                                                                                                  \
-    SMART_ARM_LAYERS, SMART_ARM_ROUTED, [tot] "+v"(tot_c), [pend] "+v"(pend), [xgs] "+v"(xg_sum),                      \
-        [t0] "=&v"(t0), [t1] "=&v"(t1), [ex] "=&v"(ex), [eh] "=&v"(eh), [xs] "=&v"(xs),          \
-        [xf] "=&v"(xf), [xg] "=&v"(xg), SMART_ARM_POWERS, [wm] "=&s"(wm), [sv] "=&s"(sv), [tmp] "=&s"(tmp)
-#define SMART_ARM_OUT_SPLIT [yd] "+v"(u_dra), [ydg] "+v"(u_dgw), [xd] "=&v"(xd), [dp] "=&v"(dp)
-#define SMART_ARM_IN                                                                                                   \
-    SMART_ARM_ROUTE_K, SMART_ARM_DECAYS, SMART_ARM_THIRDS, [sz] "v"(sz), [hz] "v"(hz), [z] "v"(z), [pd] "v"(pD),       \
-        [pc] "v"(pC), [pt] "v"(pT), [rain] "s"(v.x), [pe] "s"(v.y)
-
-    // One step.  QUICK: the forcing is sane and no layer of this wave is above capacity -- the three-arm dispatch;
-    // otherwise the rain arm for every step.
+    // One step.  QUICK: the forcing is sane and no layer of this wave is above capacity -- dispatch over the three
+    // arms; otherwise the rain arm.
     template <bool QUICK>
     __device__ __forceinline__ void step_arms(const double2 v, double &acc)
     {
-        double t0, t1, ex, eh, xs, xf, xg, w_p4, w_p5, w_p6, w_ai;
-        unsigned long long wm, sv, tmp;
+        SMART_ARM_LOCALS;
         if constexpr (SPLIT) {
             double xd, dp;
             if constexpr (QUICK)
-                asm volatile(SMART_A_STEP(SMART_A_CALM(SMART_A_DEEP, SMART_A_CALM_SPLIT),
-                                          SMART_A_RAIN(SMART_A_RAIN_ZEROS_SPLIT, SMART_A_RAIN_DRAIN_SPLIT, SMART_A_DEEP,
-                                                       SMART_A_RAIN_SPLIT),
-                                          SMART_A_DRY(SMART_A_DRY_SPLIT))
-                             : SMART_ARM_OUT, SMART_ARM_OUT_SPLIT
-                             : SMART_ARM_IN
+                asm volatile(SMART_A_STEP(SMART_A_DEEP, SMART_A_CALM_SPLIT, SMART_A_RAIN_ZEROS_SPLIT,
+                                          SMART_A_RAIN_DRAIN_SPLIT, SMART_A_RAIN_SPLIT, SMART_A_DRY_SPLIT)
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_SPLIT
+                             : SMART_ARM_CONSTS, [rn0] "s"(v.x), [pe0] "s"(v.y)
                              : "vcc", "scc");
             else
-                asm volatile(SMART_A_STEP_RAIN(SMART_A_RAIN(SMART_A_RAIN_ZEROS_SPLIT, SMART_A_RAIN_DRAIN_SPLIT,
-                                                            SMART_A_DEEP, SMART_A_RAIN_SPLIT))
-                             : SMART_ARM_OUT, SMART_ARM_OUT_SPLIT
-                             : SMART_ARM_IN
+                asm volatile(SMART_A_STEP_RAIN(SMART_A_DEEP, SMART_A_RAIN_ZEROS_SPLIT, SMART_A_RAIN_DRAIN_SPLIT,
+                                               SMART_A_RAIN_SPLIT)
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_SPLIT
+                             : SMART_ARM_CONSTS, [rn0] "s"(v.x), [pe0] "s"(v.y)
                              : "vcc", "scc");
         } else {
             if constexpr (QUICK)
-                asm volatile(SMART_A_STEP(SMART_A_CALM("", ""), SMART_A_RAIN("", "", "", ""), SMART_A_DRY(""))
-                             : SMART_ARM_OUT
-                             : SMART_ARM_IN
+                asm volatile(SMART_A_STEP("", "", "", "", "", "")
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS
+                             : SMART_ARM_CONSTS, [rn0] "s"(v.x), [pe0] "s"(v.y)
                              : "vcc", "scc");
             else
-                asm volatile(SMART_A_STEP_RAIN(SMART_A_RAIN("", "", "", ""))
-                             : SMART_ARM_OUT
-                             : SMART_ARM_IN
+                asm volatile(SMART_A_STEP_RAIN("", "", "", "")
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS
+                             : SMART_ARM_CONSTS, [rn0] "s"(v.x), [pe0] "s"(v.y)
+                             : "vcc", "scc");
+        }
+    }
+
+    // The four steps of a chunk, threaded (SMART_A_CHUNK).
+#define SMART_ARM_CHUNK_IN                                                                                             \
+    [rn0] "s"(c[0].x), [pe0] "s"(c[0].y), [rn1] "s"(c[1].x), [pe1] "s"(c[1].y), [rn2] "s"(c[2].x), [pe2] "s"(c[2].y), \
+        [rn3] "s"(c[3].x), [pe3] "s"(c[3].y)
+    template <bool QUICK>
+    __device__ __forceinline__ void chunk_arms(const double2 (&c)[4], double &acc)
+    {
+        SMART_ARM_LOCALS;
+        if constexpr (SPLIT) {
+            double xd, dp;
+            if constexpr (QUICK)
+                asm volatile(SMART_A_CHUNK(SMART_A_DEEP, SMART_A_CALM_SPLIT, SMART_A_RAIN_ZEROS_SPLIT,
+                                           SMART_A_RAIN_DRAIN_SPLIT, SMART_A_RAIN_SPLIT, SMART_A_DRY_SPLIT)
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_SPLIT
+                             : SMART_ARM_CONSTS, SMART_ARM_CHUNK_IN
+                             : "vcc", "scc");
+            else
+                asm volatile(SMART_A_CHUNK_RAIN(SMART_A_DEEP, SMART_A_RAIN_ZEROS_SPLIT, SMART_A_RAIN_DRAIN_SPLIT,
+                                                SMART_A_RAIN_SPLIT)
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_SPLIT
+                             : SMART_ARM_CONSTS, SMART_ARM_CHUNK_IN
+                             : "vcc", "scc");
+        } else {
+            if constexpr (QUICK)
+                asm volatile(SMART_A_CHUNK("", "", "", "", "", "")
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS
+                             : SMART_ARM_CONSTS, SMART_ARM_CHUNK_IN
+                             : "vcc", "scc");
+            else
+                asm volatile(SMART_A_CHUNK_RAIN("", "", "", "")
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS
+                             : SMART_ARM_CONSTS, SMART_ARM_CHUNK_IN
                              : "vcc", "scc");
         }
     }

@@ -181,7 +181,10 @@ class ShardedEnsemble(object):
             if is_distributed() and not _host_staged() else None
 
     def step(self):
-        out = self._prep.launch()
+        self._prep.enqueue()
+        return self._pack_and_gather(self._prep.result())
+
+    def _pack_and_gather(self, out):
         k = self.n_local
         if k:
             if self.axis == 'samples':
@@ -198,8 +201,14 @@ class ShardedEnsemble(object):
         return gather_rows(self._packed[:per], self.n_total, out=self._gathered)
 
     def verify(self):
-        """Status word of this rank's last launch (engine.PreparedEnsemble.verify)."""
-        return self._prep.verify()
+        """Status word of this rank's last launch (engine.PreparedEnsemble.verify).  When ANY rank had to repeat its
+        launch (a time slice that timed out, a stale plan) the matrix step() gathered holds that rank's NaN rows:
+        every rank then packs and gathers again, and the fresh [N, 9] / [C, N, 9] matrix is returned; None when the
+        matrix already returned by step() stands."""
+        out = self._prep.verify()
+        if max_over_ranks(1.0 if self._prep.repeated else 0.0, self.device) > 0.0:
+            return self._pack_and_gather(out)
+        return None
 
     @property
     def prepared(self):

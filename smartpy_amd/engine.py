@@ -6,6 +6,7 @@ and nothing imports the test oracle.
 """
 import ctypes
 import math
+import threading
 import warnings
 import weakref
 
@@ -139,31 +140,46 @@ class _Memo(object):
     """What has been worked out about a (params, forcing) pair: the variant grouping of the rows and the launch plan
     (which kernels the rows and the forcing need, smart_plan_ensemble).  Entries are tied to the tensor OBJECTS the
     caller passed (weak references) and their in-place version counters, never to addresses: a fresh tensor that
-    happens to reuse a freed address starts from nothing."""
+    happens to reuse a freed address starts from nothing.  One list for the process, guarded by a lock (the C side
+    is thread-aware as well: DeviceCtx::mu)."""
     _entries = []
+    _lock = threading.Lock()
     SIZE = 8
 
     @classmethod
+    def _matches(cls, ent, kind, tensors, key, refs):
+        return (ent[0] == kind and ent[3] == key and len(refs) == len(tensors)
+                and all(r is t for r, t in zip(refs, tensors)))
+
+    @classmethod
     def lookup(cls, kind, tensors, key):
-        alive = []
-        hit = None
-        for ent in cls._entries:
-            refs = [r() for r in ent[1]]
-            if any(t is None for t in refs):
-                continue
-            alive.append(ent)
-            if (ent[0] == kind and ent[3] == key and len(refs) == len(tensors)
-                    and all(r is t for r, t in zip(refs, tensors))
-                    and ent[2] == tuple(t._version for t in tensors)):
-                hit = ent
-        cls._entries[:] = alive
-        return None if hit is None else hit[4]
+        with cls._lock:
+            alive = []
+            hit = None
+            for ent in cls._entries:
+                refs = [r() for r in ent[1]]
+                if any(t is None for t in refs):
+                    continue
+                alive.append(ent)
+                if cls._matches(ent, kind, tensors, key, refs) and ent[2] == tuple(t._version for t in tensors):
+                    hit = ent
+            cls._entries[:] = alive
+            return None if hit is None else hit[4]
 
     @classmethod
     def store(cls, kind, tensors, key, value):
-        cls._entries.append((kind, [weakref.ref(t) for t in tensors], tuple(t._version for t in tensors), key,
-                             (value,)))
-        del cls._entries[:-cls.SIZE]
+        with cls._lock:
+            cls._entries.append((kind, [weakref.ref(t) for t in tensors], tuple(t._version for t in tensors), key,
+                                 (value,)))
+            del cls._entries[:-cls.SIZE]
+
+    @classmethod
+    def forget(cls, kind, tensors, key):
+        """Drop what is remembered about these tensors: it turned out stale without a version bump (a write through
+        ctypes, a foreign kernel, `.data`), and would be handed out again to the next prepare_ensemble()."""
+        with cls._lock:
+            cls._entries[:] = [ent for ent in cls._entries
+                               if not cls._matches(ent, kind, tensors, key, [r() for r in ent[1]])]
 
 
 class PreparedEnsemble(object):
@@ -172,12 +188,24 @@ class PreparedEnsemble(object):
     call (a benchmark, a HIP-graph capture, a calibration loop over observation sets) pays for the set-up once.
     Build one with prepare_ensemble()."""
 
-    def launch(self):
-        """Enqueue on torch's current stream of the device.  Returns the EnsembleResult (views of this object's
-        buffers: the next launch() overwrites them)."""
+    repeated = False    # did the last verify() have to repeat the launch?
+
+    def enqueue(self):
+        """The kernels onto torch's current stream of the device, nothing else: no result object is built, nothing is
+        permuted or copied (launch() = enqueue() + result())."""
         with torch.cuda.device(self.device):
             self._e.stream = torch.cuda.current_stream(self.device).cuda_stream
             _lib.check(_lib.lib().smart_run_ensemble_hip(ctypes.byref(self._e)))
+
+    def launch(self):
+        """Enqueue on torch's current stream of the device.  Returns the EnsembleResult (views of this object's
+        buffers: the next launch() overwrites them)."""
+        self.enqueue()
+        return self._result()
+
+    def result(self):
+        """The EnsembleResult of the last enqueue(): rows back in the caller's order (one permutation of the outputs
+        when the rows were grouped; the stored discharge matrix included)."""
         return self._result()
 
     def status(self):
@@ -201,6 +229,7 @@ class PreparedEnsemble(object):
         unsliced; a plan that no longer matches the inputs -> re-planned and repeated.  Raises if the second launch
         is not clean either.  Returns the result to use."""
         word = self.status()
+        self.repeated = word != 0
         if word == 0:
             return self._result()
         warnings.warn("smartpy_amd: launch status %#x (%s); repeating the launch %s" % (
@@ -213,7 +242,11 @@ class PreparedEnsemble(object):
             ordered = self._e.plan & _lib.PLAN_ROWS_ORDERED
             self._e.plan = 0
             self._e.plan = self._make_plan() | ordered
-        self.launch()
+            if self._memo_of is not None:      # what was remembered about these tensors is what went stale
+                tensors, key = self._memo_of
+                _Memo.forget('fast', tensors, key)
+                _Memo.store('fast', tensors, key, (self._grouping, int(self._e.plan)))
+        self.enqueue()
         word = self.status()
         if word != 0:
             raise SmartEngineError(-6, "smartpy_amd: the repeated launch reports status %#x as well" % word)
@@ -306,6 +339,7 @@ def prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, re
     p = PreparedEnsemble()
     p.device, p.n_samples, p._squeeze = device, N, squeeze
     p._grouping, p._caller_out = None, None
+    p._memo_of = (memo_on, memo_key) if len(memo_on) == 2 and mmode == MATH_FAST else None
     if group_variants and mmode == MATH_FAST and pstride == 0 and N > 64:
         p._grouping = memo[0][0] if memo else _variant_grouping(params, float(delta_sec), sort_rows)
         if p._grouping is not None:
@@ -380,9 +414,11 @@ def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report
                          initial=initial, obs=obs, gw_obs=gw_obs, math_mode=math_mode,
                          want_discharge=want_discharge, want_objfn=want_objfn, want_final=want_final, device=device,
                          discharge_out=discharge_out, group_variants=group_variants, time_slices=time_slices)
-    out = p.launch()
+    p.enqueue()
     if verify and p._ws is not None and p._e.math_mode == MATH_FAST and not torch.cuda.is_current_stream_capturing():
-        out = p.verify()
+        out = p.verify()        # (builds the result once: after the status word has been read)
+    else:
+        out = p.result()
     out._prepared = p       # the result's tensors live in the prepared call's buffers
     return out
 

@@ -176,6 +176,14 @@ class _OraclePrepared(object):
         self.a = (np.asarray(params, float), np.asarray(forcing, float), area_m2, delta_sec, n_warm, report_gap,
                   obs, gw_obs, extra)
 
+    repeated = False
+
+    def enqueue(self):
+        self._last = self.launch()
+
+    def result(self):
+        return self._last
+
     def launch(self):
         from oracle import smart_oracle as so, objfn_oracle
         params, forcing, area, dt, W, gap, obs, gw_obs, extra = self.a
@@ -199,7 +207,27 @@ class _OraclePrepared(object):
         return _OracleResult(None, gws[0] if squeeze else gws, objfn[0] if squeeze else objfn)
 
     def verify(self):
-        return None
+        return self._last
+
+
+class _FlakyPrepared(_OraclePrepared):
+    """... whose first launch on rank 1 comes back poisoned (a time slice that timed out writes NaN), and whose
+    verify() repeats it -- what engine.PreparedEnsemble.verify() does on a non-zero status word."""
+
+    def enqueue(self):
+        _OraclePrepared.enqueue(self)
+        self._poisoned = dist.is_initialized() and dist.get_rank() == 1 and not getattr(self, '_done', False)
+        if self._poisoned:
+            self._last.gw[...] = float('nan')
+            self._last.objfn[...] = float('nan')
+
+    def verify(self):
+        self.repeated = self._poisoned
+        if self._poisoned:
+            self._done = True
+            self._poisoned = False          # the status word read next is that of the repeated, clean launch
+            _OraclePrepared.enqueue(self)
+        return self._last
 
 
 def _sharded_setup():
@@ -242,6 +270,19 @@ def _worker_sharded(rank, world, port, out_dir):
     weak = sdist.ShardedEnsemble(own, forcing[2], areas[2], 3600.0, 240, 24, axis='samples', local_block=True,
                                  obs=obs[2], extra=extra, device='cpu')
     got_w = weak.step()
+    # a launch that one rank had to repeat: step() gathered that rank's NaN rows, verify() gathers again -- on every
+    # rank, the ones whose own launch was clean included
+    engine.prepare_ensemble = _FlakyPrepared
+    flaky = sdist.ShardedEnsemble(params, forcing[1], areas[1], 3600.0, 240, 24, axis='samples', obs=obs[1],
+                                  gw_obs=float(gw_obs[1]), extra=extra, device='cpu')
+    first = flaky.step()
+    again = flaky.verify()
+    if world > 1:
+        assert torch.isnan(first[:, 8]).any() and again is not None and not torch.isnan(again[:, 8]).any()
+        assert torch.equal(again, got_s)
+        assert flaky.verify() is None                   # nothing to repeat the second time
+    else:
+        assert again is None and torch.equal(first, got_s)
     np.savez(os.path.join(out_dir, 'sharded_w%d_r%d.npz' % (world, rank)), c=got_c.numpy(), s=got_s.numpy(),
              w=got_w.numpy())
     if world > 1:

@@ -426,7 +426,7 @@ def test_config4_size_one_million_samples(eng):
     dev_p = torch.from_numpy(params).cuda()
     kw = dict(extra=bench.EXTRA, obs=obs, gw_obs=0.12667, want_discharge=False)
     out = eng.run_ensemble(dev_p, f, bench.AREA, 3600.0, W, 24, **kw)
-    assert 'smart_fast_intervals_exits[16 slices x 15625 blocks' in out._prepared.describe()
+    assert 'smart_fast_intervals_exits[8 slices x 15625 blocks' in out._prepared.describe()
     lo, hi = 3 * 125000, 4 * 125000                                  # rank 3's shard under shard_bounds(1e6, 8, 3)
     part = eng.run_ensemble(dev_p[lo:hi].contiguous(), f, bench.AREA, 3600.0, W, 24, **kw)
     assert torch.equal(part.objfn, out.objfn[lo:hi]) and torch.equal(part.gw, out.gw[lo:hi])
@@ -975,9 +975,10 @@ def test_early_exits_do_not_change_results(eng, example, monkeypatch):
 
 def test_randomized_interval_engine(eng, monkeypatch):
     """45 seeded random set-ups: storms, droughts, exact zeros, gaps 2..48, warm-up or not, forced time slices and
-    exits at random, the final row asked for or not.  Two thirds have forcing that is constant over each report
-    interval (what the interval engine takes); one third spread each interval's totals unevenly over its steps, with
-    calm steps (no rain, no evaporation) in between -- the step loop with deferred evaporation.  Fast mode within
+    exits at random, the final row asked for or not.  Half have forcing that is constant over each report interval
+    (what the interval engine takes); a sixth keep it constant over runs of k steps, k a proper divisor of the gap
+    (the run engine); one third spread each interval's totals unevenly over its steps, with calm steps (no rain, no
+    evaporation) in between -- the step loop with deferred evaporation.  Fast mode within
     tolerance of the reference-exact oracle on well-conditioned rows: discharge, groundwater ratio, objective
     functions, and all 19 values of the final row."""
     def setenv(name, val):
@@ -1003,7 +1004,18 @@ def run_interval_cases(eng, setenv, seed, n_cases):
         peva_iv = np.maximum(0.0, rng.normal(1.5, 1.0, n_rep))
         peva_iv[rng.random(n_rep) < 0.08] = 0.0
         varying = case % 3 == 2
-        if varying:     # the interval's total in a few of its steps, the others calm or evaporation only
+        # constant over runs of k steps, k a proper divisor of the gap (the run engine): every sixth case that can
+        divisors = [k for k in range(2, gap) if gap % k == 0]
+        run_len = int(rng.choice(divisors)) if (case % 6 == 1 and divisors) else 0
+        if run_len:
+            per = gap // run_len
+            w_r = rng.random((n_rep, per)) * (rng.random((n_rep, per)) < 0.5)
+            w_r[w_r.sum(1) == 0, 0] = 1.0
+            w_e = rng.random((n_rep, per)) * (rng.random((n_rep, per)) < 0.7)
+            w_e[w_e.sum(1) == 0, -1] = 1.0
+            rain = np.repeat((rain_iv[:, None] * scale * w_r / w_r.sum(1, keepdims=True)).ravel() / run_len, run_len)
+            peva = np.repeat((peva_iv[:, None] * scale * w_e / w_e.sum(1, keepdims=True)).ravel() / run_len, run_len)
+        elif varying:     # the interval's total in a few of its steps, the others calm or evaporation only
             w_r = rng.random((n_rep, gap)) * (rng.random((n_rep, gap)) < 0.3)
             w_r[w_r.sum(1) == 0, 0] = 1.0
             w_e = rng.random((n_rep, gap)) * (rng.random((n_rep, gap)) < 0.5)
@@ -1027,11 +1039,12 @@ def run_interval_cases(eng, setenv, seed, n_cases):
         fast = eng.run_ensemble(params, forcing_of(rain, peva), area, dt, W, gap, extra=extra, obs=obs, gw_obs=0.2,
                                 want_final=want_final)
         kernels = fast._prepared.describe()
-        if 'smart_fast_intervals' in kernels or 'smart_fast_steps' in kernels:       # some rows are regular ones
-            assert ('smart_fast_steps' in kernels) == varying and ('_states' in kernels) == want_final, kernels
+        if any(k in kernels for k in ('smart_fast_intervals', 'smart_fast_steps', 'smart_fast_runs')):  # regular rows
+            assert ('smart_fast_steps' in kernels) == (varying and not run_len) and \
+                ('smart_fast_runs' in kernels) == bool(run_len) and ('_states' in kernels) == want_final, kernels
         d1, g1, f1 = so.run_batch(area, dt, T, W, rain, peva, params, extra, so.REPORT_SUMMARY, gap, want_final=True)
-        tag = 'seed %d case %d: dt=%g gap=%d T=%d W=%d n=%d extra=%s slices=%r exits=%r final=%r varying=%r' % (
-            seed, case, dt, gap, T, W, n, extra is not None, slices, exits, want_final, varying)
+        tag = 'seed %d case %d: dt=%g gap=%d T=%d W=%d n=%d extra=%s slices=%r exits=%r final=%r varying=%r run=%d' % (
+            seed, case, dt, gap, T, W, n, extra is not None, slices, exits, want_final, varying, run_len)
         good = ~(params[:, 9] * 3600.0 < 0.5 * dt)          # dt / RK <= 2: not the literal model's
         if good.any():
             got = fast.discharge.cpu().numpy()[good]
@@ -1048,6 +1061,50 @@ def run_interval_cases(eng, setenv, seed, n_cases):
             if want_final:
                 assert excess(fast.final_vars.cpu().numpy()[good], f1[good], 1e-8) <= 1.0, tag
     return worst
+
+
+@pytest.mark.parametrize('run_len,shift', [(2, 0), (3, 0), (6, 0), (12, 0), (6, 3), (12, 4), (8, 0)])
+def test_run_length_interval_engine(eng, example, monkeypatch, run_len, shift):
+    """Forcing constant over runs of k hours in an hourly run with daily reports -- what the reference's input pipeline
+    makes of 2-, 3-, 6- or 12-hourly data (timeframe.py:167-186: each value spread equally over the steps it covers;
+    KAT-10's 6-hourly case).  The interval engine advances a run at a time (smart_fast_runs), the report mean
+    accumulates over the 24 / k runs of a day.  `shift`: the data's axis starts `shift` hours after a report boundary,
+    so that the longest run every day is cut into is gcd-like shorter (6-hourly shifted by 3 h -> runs of 3; 12-hourly
+    shifted by 4 h -> 4; 8-hourly data unshifted -> 8).  Against the reference-exact oracle: discharge, groundwater
+    ratio, objective functions, all 19 values of the final row; whole and time-sliced, bit-identical to each other."""
+    rng = np.random.default_rng(100 * run_len + shift)
+    days, warm, gap = 150, 30, 24
+    n_val = days * 24 // run_len + 2
+    rain_v = rng.gamma(0.5, 6.0, n_val) * (rng.random(n_val) < 0.45) / (24 // run_len)
+    peva_v = np.maximum(0.0, rng.normal(1.6, 1.0, n_val)) / (24 // run_len) * (rng.random(n_val) < 0.8)
+    rain = np.repeat(rain_v / run_len, run_len)[shift:shift + days * 24]
+    peva = np.repeat(peva_v / run_len, run_len)[shift:shift + days * 24]
+    expect = int(np.gcd.reduce([run_len, shift, 24])) if shift else run_len
+    n = 200
+    params = lhs_oracle.lhs_params(n, seed=77 + run_len)
+    obs = rng.random(days) * 3
+    obs[rng.random(days) < 0.1] = np.nan
+    want_d, want_g, want_f = so.run_batch(example['area'], 3600.0, days * 24, warm * 24, rain, peva, params, example['extra'],
+                                          so.REPORT_SUMMARY, gap, want_final=True)
+    want_o = objfn_oracle.objective_matrix(want_d, obs, want_g, 0.2)
+    results = []
+    for slices, final in (('1', False), ('7', False), ('1', True), ('5', True)):
+        monkeypatch.setenv('SMART_TIME_SLICES', slices)
+        out = eng.run_ensemble(params, forcing_of(rain, peva), example['area'], 3600.0, warm * 24, gap, extra=example['extra'],
+                               obs=obs, gw_obs=0.2, want_final=final)
+        kern = out._prepared.describe()
+        assert ('smart_fast_runs' in kern) == (expect >= 2) and ('_states' in kern) == final, (kern, expect)
+        got = out.discharge.cpu().numpy()
+        assert excess(got, want_d, REL_FAST) <= 1.0, (run_len, shift, slices, rel(got, want_d))
+        assert excess(out.gw.cpu().numpy(), want_g, 1e-9, top=1.0) <= 1.0
+        fin = np.isfinite(want_o[:, :7]).all(axis=1)
+        assert excess(out.objfn.cpu().numpy()[fin, :7], want_o[fin, :7], 1e-7, top=1.0, top_frac=1e-12) <= 1.0
+        if final:
+            assert excess(out.final_vars.cpu().numpy(), want_f, 1e-8) <= 1.0
+        results.append((final, got, out.gw.cpu().numpy()))
+    # time slices change nothing, and asking for the final row does not change the discharge
+    assert bits_equal(results[0][1], results[1][1]) and bits_equal(results[2][1], results[3][1])
+    assert bits_equal(results[0][1], results[2][1]) and bits_equal(results[0][2], results[1][2])
 
 
 def test_launch_captures_into_a_hip_graph(eng, example):

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp SMART_DIST_BACKEND=gloo
 for args in "--config 3 --samples 30000" "--config 4 --samples 60000" "--config 5 --samples 2000" "--config 2"; do
   echo "== $args"
-  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $(python -c "import socket; s = socket.socket(); s.bind(('127.0.0.1', 0)); print(s.getsockname()[1])") \
      bench.py --gpus 2 --steps 3 --warmup 1 $args 2>&1 | grep '^{' | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Disassemble a kernel of the BUILT library and list its loops, instruction by instruction, with a histogram per basic
+block: what the roofline figures of DESIGN.md / bench.py rest on, checkable from the tree.
+
+    python tools/isa_report.py smart_fast_steps            profiles/r03_isa_steps
+    python tools/isa_report.py smart_fast_intervals        profiles/r03_isa_intervals
+    python tools/isa_report.py smart_fast_intervals_exits  profiles/r03_isa_intervals_exits
+
+Writes <out>.s (the kernel's disassembly from llvm-objdump of the gfx950 code object inside libsmart_amd.so: every
+basic block that belongs to a loop is headed by a `;; ---- block Bn [loops ...]` line with its instruction classes) and
+<out>.json (blocks, loops, class counts: what tools/isa_model.py weighs with the workload's path frequencies).
+
+Instruction classes
+    fp64      v_fma_f64 v_fmac_f64 v_add_f64 v_mul_f64 v_min_f64 v_max_f64 v_ldexp_f64 (the model's arithmetic)
+    vcmp      v_cmp*                 vmov   v_mov* v_cndmask* v_accvgpr*      lane  v_readlane v_writelane v_readfirstlane
+    valu      any other vector ALU   salu   scalar ALU (s_cmp, s_and, s_mov...) branch s_branch s_cbranch*
+    smem      s_load* s_store*       vmem   global_* buffer_* flat_* scratch_*  other  s_waitcnt s_nop s_sleep s_endpgm ...
+SQ_INSTS_VALU counts fp64 + vcmp + vmov + lane + valu.
+"""
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+from collections import Counter
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+FP64 = ('v_fma_f64', 'v_fmac_f64', 'v_add_f64', 'v_mul_f64', 'v_min_f64', 'v_max_f64', 'v_ldexp_f64')
+VALU_CLASSES = ('fp64', 'vcmp', 'vmov', 'lane', 'valu')
+
+
+def classify(op):
+    base = op.replace('_e32', '').replace('_e64', '')
+    if base in FP64:
+        return 'fp64'
+    if base.startswith('v_cmp'):
+        return 'vcmp'
+    if base.startswith(('v_mov', 'v_cndmask', 'v_accvgpr')):
+        return 'vmov'
+    if base.startswith(('v_readlane', 'v_writelane', 'v_readfirstlane')):
+        return 'lane'
+    if base.startswith('v_'):
+        return 'valu'
+    if base.startswith(('s_branch', 's_cbranch')):
+        return 'branch'
+    if base.startswith(('s_load', 's_store', 's_buffer_load', 's_dcache')):
+        return 'smem'
+    if base.startswith(('global_', 'buffer_', 'flat_', 'scratch_', 'ds_')):
+        return 'vmem'
+    if base.startswith(('s_waitcnt', 's_nop', 's_sleep', 's_endpgm', 's_barrier', 's_code_end', 's_setprio', 's_trap')):
+        return 'other'
+    if base.startswith('s_'):
+        return 'salu'
+    return 'other'
+
+
+def code_objects(lib):
+    """the gfx950 code objects bundled in the shared library (llvm-objdump --offloading writes them next to its input:
+    done on a copy in a scratch directory)"""
+    tmp = tempfile.mkdtemp(prefix='smart_isa_')
+    copy = os.path.join(tmp, os.path.basename(lib))
+    shutil.copy(lib, copy)
+    subprocess.run([OBJDUMP, '--offloading', copy], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return tmp, sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if 'gfx950' in f)
+
+
+def disassemble(lib, kernel):
+    tmp, objs = code_objects(lib)
+    try:
+        for obj in objs:
+            text = subprocess.run([OBJDUMP, '-d', obj], check=True, capture_output=True, text=True).stdout
+            m = re.search(r'^([0-9a-f]+) <(_ZN5smart\d+%s[A-Z][^>]*)>:\n(.*?)(?=^\S|\Z)' % re.escape(kernel), text,
+                          re.M | re.S)
+            if m:
+                return int(m.group(1), 16), m.group(2), m.group(3)
+    finally:
+        shutil.rmtree(tmp)
+    raise SystemExit('kernel %s not found in %s' % (kernel, lib))
+
+
+def parse(start, body):
+    insts = []
+    for line in body.split('\n'):
+        m = re.match(r'\s+(\S+)\s*(.*?)\s*//\s*([0-9A-F]+):\s*[0-9A-F ]+(?:<[^+>]+\+0x([0-9a-f]+)>)?\s*$', line)
+        if not m:
+            continue
+        op, args, addr, off = m.group(1), m.group(2), int(m.group(3), 16), m.group(4)
+        target = start + int(off, 16) if off is not None and classify(op) == 'branch' else None
+        insts.append({'addr': addr, 'op': op, 'args': args, 'cls': classify(op), 'target': target})
+    return insts
+
+
+def blocks_and_loops(insts):
+    addr_ix = {x['addr']: i for i, x in enumerate(insts)}
+    leaders = {0}
+    for i, x in enumerate(insts):
+        if x['cls'] == 'branch':
+            if i + 1 < len(insts):
+                leaders.add(i + 1)
+            if x['target'] in addr_ix:
+                leaders.add(addr_ix[x['target']])
+        if x['op'].startswith('s_endpgm') and i + 1 < len(insts):
+            leaders.add(i + 1)
+    order = sorted(leaders)
+    blocks = []
+    for b, lo in enumerate(order):
+        hi = order[b + 1] if b + 1 < len(order) else len(insts)
+        blocks.append({'id': b, 'lo': lo, 'hi': hi})
+    block_of = {}
+    for b in blocks:
+        for i in range(b['lo'], b['hi']):
+            block_of[i] = b['id']
+    # back edges: a branch to an address at or before itself
+    loops = []
+    for i, x in enumerate(insts):
+        if x['cls'] == 'branch' and x['target'] in addr_ix and addr_ix[x['target']] <= i:
+            loops.append({'head': addr_ix[x['target']], 'tail': i})
+    # loops that share a head are one loop (several latches); nest by containment of [head, tail]
+    merged = {}
+    for lp in loops:
+        merged[lp['head']] = max(merged.get(lp['head'], 0), lp['tail'])
+    loops = [{'id': k, 'head': h, 'tail': t} for k, (h, t) in enumerate(sorted(merged.items()))]
+    for b in blocks:
+        b['loops'] = [lp['id'] for lp in loops if lp['head'] <= b['lo'] and b['hi'] - 1 <= lp['tail']]
+        b['hist'] = dict(Counter(insts[i]['cls'] for i in range(b['lo'], b['hi'])))
+        b['ops'] = dict(Counter(insts[i]['op'].replace('_e32', '').replace('_e64', '') for i in range(b['lo'], b['hi'])))
+    for lp in loops:
+        lp['depth'] = sum(1 for o in loops if o['head'] <= lp['head'] and lp['tail'] <= o['tail'])
+        lp['n_insts'] = lp['tail'] - lp['head'] + 1
+        lp['hist'] = dict(Counter(insts[i]['cls'] for i in range(lp['head'], lp['tail'] + 1)))
+    return blocks, loops, block_of
+
+
+def fmt_hist(h):
+    valu = sum(h.get(c, 0) for c in VALU_CLASSES)
+    return 'VALU %d (fp64 %d, vcmp %d, vmov %d, lane %d, other %d) | SALU %d | branch %d | SMEM %d | VMEM %d' % (
+        valu, h.get('fp64', 0), h.get('vcmp', 0), h.get('vmov', 0), h.get('lane', 0), h.get('valu', 0),
+        h.get('salu', 0), h.get('branch', 0), h.get('smem', 0), h.get('vmem', 0))
+
+
+def main():
+    kernel, out = sys.argv[1], sys.argv[2]
+    lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'smartpy_amd', 'csrc', 'libsmart_amd.so')
+    start, symbol, body = disassemble(lib, kernel)
+    insts = parse(start, body)
+    blocks, loops, block_of = blocks_and_loops(insts)
+    lines = ['; %s -- llvm-objdump -d of the gfx950 code object in %s' % (symbol, os.path.relpath(lib, ROOT)),
+             '; %d instructions, %d basic blocks, %d loops (tools/isa_report.py)' % (len(insts), len(blocks), len(loops)),
+             ';']
+    for lp in sorted(loops, key=lambda l: l['head']):
+        lines.append('; loop L%d depth %d: %#x .. %#x, %d instructions: %s' % (
+            lp['id'], lp['depth'], insts[lp['head']]['addr'], insts[lp['tail']]['addr'], lp['n_insts'],
+            fmt_hist(lp['hist'])))
+    lines.append(';')
+    heads = {lp['head']: lp for lp in loops}
+    tails = {}
+    for lp in loops:
+        tails.setdefault(lp['tail'], []).append(lp)
+    for b in blocks:
+        if b['loops']:
+            lines.append(';; ---- block B%d [loops %s] %s' % (b['id'], ','.join('L%d' % k for k in b['loops']),
+                                                              fmt_hist(b['hist'])))
+        for i in range(b['lo'], b['hi']):
+            x = insts[i]
+            if i in heads:
+                lines.append(';; ==== LOOP L%d BEGIN (depth %d)' % (heads[i]['id'], heads[i]['depth']))
+            tgt = ''
+            if x['target'] is not None:
+                j = next((k for k, y in enumerate(insts) if y['addr'] == x['target']), None)
+                tgt = '    ; -> %#x (B%s)' % (x['target'], block_of.get(j, '?'))
+            lines.append('%08x  %-18s %s%s' % (x['addr'], x['op'], x['args'], tgt))
+            for lp in tails.get(i, []):
+                lines.append(';; ==== LOOP L%d END' % lp['id'])
+    with open(out + '.s', 'w') as fh:
+        fh.write('\n'.join(lines) + '\n')
+    with open(out + '.json', 'w') as fh:
+        json.dump({'kernel': symbol, 'n_insts': len(insts),
+                   'blocks': [{k: b[k] for k in ('id', 'loops', 'hist', 'ops')} | {
+                       'addr': insts[b['lo']]['addr'], 'n': b['hi'] - b['lo'],
+                       'ends_with': insts[b['hi'] - 1]['op'],
+                       'target': insts[b['hi'] - 1]['target']} for b in blocks],
+                   'loops': [{k: lp[k] for k in ('id', 'depth', 'n_insts', 'hist')} | {
+                       'head_addr': insts[lp['head']]['addr'], 'tail_addr': insts[lp['tail']]['addr']} for lp in loops]},
+                  fh, indent=1)
+    print('\n'.join(lines[:3 + len(loops) + 1]))
+
+
+if __name__ == '__main__':
+    main()
