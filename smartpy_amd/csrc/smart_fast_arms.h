@@ -84,13 +84,13 @@
     "v_add_f64 %[t1], %[" l "], %[" src "]\n\t"                                                                        \
     "v_min_f64 %[" l "], %[t1], %[z]\n\t"                                                                              \
     "v_add_f64 %[t1], %[t1], -%[" l "]\n\t"
-#define SMART_A_FILL                                                                                                   \
-    "v_mul_f64 %[eh], %[hz], %[ex]\n\t"                                                                                \
+#define SMART_A_FILL_REST                                                                                              \
     "v_fma_f64 %[xf], -%[eh], %[tot], %[ex]\n\t" SMART_A_FILL1("l0", "xf") SMART_A_FILL1("l1", "t1")                   \
         SMART_A_FILL1("l2", "t1") SMART_A_FILL1("l3", "t1") SMART_A_FILL1("l4", "t1") SMART_A_FILL1("l5", "t1")        \
             "v_mul_f64 %[xs], %[eh], %[tot]\n\t"                                                                       \
             "v_fma_f64 %[xf], -%[pd], %[t1], %[xf]\n\t"                                                                \
             "v_fma_f64 %[xs], %[pd], %[t1], %[xs]\n\t"
+#define SMART_A_FILL "v_mul_f64 %[eh], %[hz], %[ex]\n\t" SMART_A_FILL_REST
 // s', s'^2 and s'^3 live in the registers of three temporaries that are dead by the time the leaks start (the excess,
 // e_h and the routing / cascade temporary): 6 VGPRs less
 #define SMART_S1 "ex"
@@ -104,26 +104,27 @@
     "v_add_f64 %[t1], %[l5], %[l4]\n\t"                                                                                \
     "v_add_f64 %[" dst "], %[t1], %[" dst "]\n\t"
 // the three leak passes (structure.py:381-399); `deep`: the SPLIT models' sum of what the third pass takes
-#define SMART_A_LEAKS(deep)                                                                                            \
-    "v_mul_f64 %[" SMART_S1 "], %[sz], %[tot]\n\t"                                                                     \
-    "v_mul_f64 %[" SMART_P2 "], %[" SMART_S1 "], %[" SMART_S1 "]\n\t"                                                  \
-    "v_mul_f64 %[" SMART_P3 "], %[" SMART_S1 "], %[" SMART_P2 "]\n\t"                                                  \
-    "v_mul_f64 %[p4], %[" SMART_P2 "], %[" SMART_P2 "]\n\t"                                                            \
-    "v_mul_f64 %[p5], %[" SMART_S1 "], %[p4]\n\t"                                                                      \
-    "v_mul_f64 %[p6], %[" SMART_P3 "], %[" SMART_P3 "]\n\t" SMART_A_LEAK("l0", SMART_S1) SMART_A_LEAK("l1", SMART_P2)  \
-        SMART_A_LEAK("l2", SMART_P3) SMART_A_LEAK("l3", "p4") SMART_A_LEAK("l4", "p5") SMART_A_LEAK("l5", "p6")        \
-            SMART_A_LSUM("ai") SMART_A_LEAK("l0", SMART_S1) "v_mul_f64 %[t1], %[" SMART_S1 "], -0.5\n\t"               \
+#define SMART_A_LEAKS_(S1, P2, P3, deep)                                                                                            \
+    "v_mul_f64 %[" S1 "], %[sz], %[tot]\n\t"                                                                     \
+    "v_mul_f64 %[" P2 "], %[" S1 "], %[" S1 "]\n\t"                                                  \
+    "v_mul_f64 %[" P3 "], %[" S1 "], %[" P2 "]\n\t"                                                  \
+    "v_mul_f64 %[p4], %[" P2 "], %[" P2 "]\n\t"                                                            \
+    "v_mul_f64 %[p5], %[" S1 "], %[p4]\n\t"                                                                      \
+    "v_mul_f64 %[p6], %[" P3 "], %[" P3 "]\n\t" SMART_A_LEAK("l0", S1) SMART_A_LEAK("l1", P2)  \
+        SMART_A_LEAK("l2", P3) SMART_A_LEAK("l3", "p4") SMART_A_LEAK("l4", "p5") SMART_A_LEAK("l5", "p6")        \
+            SMART_A_LSUM("ai") SMART_A_LEAK("l0", S1) "v_mul_f64 %[t1], %[" S1 "], -0.5\n\t"               \
                                                             "v_fma_f64 %[l1], %[l1], %[t1], %[l1]\n\t"                 \
-                                                            "v_mul_f64 %[t1], %[" SMART_S1 "], %[k3]\n\t"              \
+                                                            "v_mul_f64 %[t1], %[" S1 "], %[k3]\n\t"              \
                                                             "v_fma_f64 %[l2], %[l2], %[t1], %[l2]\n\t"                 \
-                                                            "v_ldexp_f64 %[t1], -%[" SMART_S1 "], -2\n\t"              \
+                                                            "v_ldexp_f64 %[t1], -%[" S1 "], -2\n\t"              \
                                                             "v_fma_f64 %[l3], %[l3], %[t1], %[l3]\n\t"                 \
-                                                            "v_mul_f64 %[t1], %[" SMART_S1 "], %[k5]\n\t"              \
+                                                            "v_mul_f64 %[t1], %[" S1 "], %[k5]\n\t"              \
                                                             "v_fma_f64 %[l4], %[l4], %[t1], %[l4]\n\t"                 \
-                                                            "v_mul_f64 %[t1], %[" SMART_S1 "], %[k6]\n\t"              \
+                                                            "v_mul_f64 %[t1], %[" S1 "], %[k6]\n\t"              \
                                                             "v_fma_f64 %[l5], %[l5], %[t1], %[l5]\n\t" deep            \
                 SMART_A_LEAK("l0", "p6") SMART_A_LEAK("l1", "p5") SMART_A_LEAK("l2", "p4")                             \
-                    SMART_A_LEAK("l3", SMART_P3) SMART_A_LEAK("l4", SMART_P2) SMART_A_LEAK("l5", SMART_S1)
+                    SMART_A_LEAK("l3", P3) SMART_A_LEAK("l4", P2) SMART_A_LEAK("l5", S1)
+#define SMART_A_LEAKS(deep) SMART_A_LEAKS_(SMART_S1, SMART_P2, SMART_P3, deep)
 #define SMART_A_DEEP                                                                                                   \
     "v_mul_f64 %[dp], %[l0], %[p6]\n\t"                                                                                \
     "v_fma_f64 %[dp], %[l1], %[p5], %[dp]\n\t"                                                                         \
@@ -252,3 +253,25 @@
     SMART_A_RAIN_J("2", zeros, drain, deep, rain_split) SMART_A_RAIN_J("3", zeros, drain, deep, rain_split)            \
     "s_branch 130f\n\t" SMART_A_CASC_RAIN_OOL("0") SMART_A_CASC_RAIN_OOL("1") SMART_A_CASC_RAIN_OOL("2")               \
     SMART_A_CASC_RAIN_OOL("3") "130:\n\t"
+
+// ---- the wet interval of the interval engine (FastModel::wet_interval, merged regular variant, no exits) ----------
+// `n` wet steps with one excess, two per turn of the loop: 73 vector instructions a step (5 routing, 22 filling, 34
+// for the three leak passes with their powers, 8 for the layer sum / the balances, 4 reservoirs) and 1.5 scalar ones.
+// hipcc's own loop over the same arithmetic carries 5 to 8 more per step (a 64-bit counter, a constant rebuilt in
+// every turn, s_waitcnt's for loads that were long in) -- and a lone wavefront issues ONE instruction of any kind
+// per turn of its SIMD.  s', s'^2, s'^3 in registers of their own here: `ex` and `eh` live across the steps.
+#define SMART_A_WET_STEP                                                                                               \
+    SMART_A_ROUTE SMART_A_FILL_REST SMART_A_LEAKS_("s1", "p2", "p3", "") "v_add_f64 %[t1], %[tot], -%[ai]\n\t"         \
+                                                                         "v_add_f64 %[xf], %[xf], %[t1]\n\t"           \
+        SMART_A_TOT_XG "v_fma_f64 %[ys], %[ys], %[ds], %[xs]\n\t"                                                      \
+                       "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                                      \
+                       "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                                      \
+                       "v_add_f64 %[xgs], %[xgs], %[xg]\n\t"
+#define SMART_A_WET_INTERVAL                                                                                           \
+    "s_add_i32 %[cnt], %[n], 1\n\t"                                                                                    \
+    "s_lshr_b32 %[cnt], %[cnt], 1\n\t"                                                                                 \
+    "s_bitcmp1_b32 %[n], 0\n\t"                                                                                        \
+    "s_cbranch_scc1 6f\n\t"                                                                                            \
+    "5:\n\t" SMART_A_WET_STEP "6:\n\t" SMART_A_WET_STEP "s_add_i32 %[cnt], %[cnt], -1\n\t"                            \
+    "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 5b\n\t"

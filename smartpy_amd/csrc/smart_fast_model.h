@@ -464,10 +464,34 @@ struct FastModel {
             xg_sum += xg;
     }
 
+    // the straight-line kernel of low loads (smart_fast_intervals, smart_fast_runs) runs its wet intervals as an asm loop
+#ifndef SMART_WET_ASM
+#define SMART_WET_ASM 1
+#endif
+    static constexpr bool kWetAsm = SMART_WET_ASM && kLeakBalance && !kExits && !SPLIT && SMART_FAST_BALANCE_SUMS && !STIFF;
+
     // `n` wet steps with the same rain excess: the layer sum is handed from step to step
     __device__ __forceinline__ void wet_interval(double ex, long n, double &acc, double &num, double &den)
     {
-        if (kLeakBalance) {
+        if constexpr (kWetAsm) {
+            // the whole interval as one asm loop (smart_fast_arms.h: SMART_A_WET_INTERVAL), the arithmetic of
+            // route_and_sum() + wet_balance() below, operation for operation
+            const double e_h = ex * hz;
+            double tot = layer_sum();
+            double t0, t1, xs, xf, xg, w_s1, w_p2, w_p3, w_p4, w_p5, w_p6, w_ai;
+            int cnt;
+            asm volatile(SMART_A_WET_INTERVAL
+                         : [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), [l4] "+v"(l4), [l5] "+v"(l5),
+                           [ys] "+v"(u_ove), [yf] "+v"(u_int), [yg] "+v"(u_sgw), [riv] "+v"(u_riv), [acc] "+v"(acc),
+                           [tot] "+v"(tot), [xgs] "+v"(xg_sum), [t0] "=&v"(t0), [t1] "=&v"(t1), [xs] "=&v"(xs),
+                           [xf] "=&v"(xf), [xg] "=&v"(xg), [s1] "=&v"(w_s1), [p2] "=&v"(w_p2), [p3] "=&v"(w_p3),
+                           [p4] "=&v"(w_p4), [p5] "=&v"(w_p5), [p6] "=&v"(w_p6), [ai] "=&v"(w_ai), [cnt] "=&s"(cnt)
+                         : [cs] "v"(car_s), [cf] "v"(car_f), [cg] "v"(car_g), [oma] "v"(om_ar), [ds] "v"(dec_s),
+                           [df] "v"(dec_f), [dg] "v"(dec_g), [sz] "v"(sz), [z] "v"(z), [pd] "v"(pD), [ex] "v"(ex),
+                           [eh] "v"(e_h), [k3] "s"(-(1.0 / 3.0)), [k5] "s"(-0.2), [k6] "s"(-(1.0 / 6.0)),
+                           [n] "s"((int)n)
+                         : "scc");
+        } else if (kLeakBalance) {
             const double e_h = ex * hz;
             double tot = layer_sum();
             // unrolled: a taken branch costs a wavefront that has its SIMD (nearly) to itself about as much as a

@@ -1,5 +1,5 @@
-"""Outputs of the step-loop kernels (forcing that varies inside the report interval) on a fixed set of seeded set-ups,
-for comparing two builds of the library bit for bit:
+"""Outputs of the merged summary kernels (step loop, interval engine, run engine) on a fixed set of seeded set-ups, for
+comparing two builds of the library bit for bit:
 
     SMART_AMD_LIB=.../libsmart_amd_oldsteps.so python tools/debug/steps_bits.py dump a.npz
     python tools/debug/steps_bits.py dump b.npz
@@ -30,6 +30,16 @@ def cases():
         out.append(dict(name='bench_%d_%d_%s_%d' % (n, days, slices or 'w', final), forcing=vary[:days * 24].copy(),
                         params=latin_hypercube(n, ranges, seed=n), dt=3600.0, W=120 * 24, gap=24, slices=slices,
                         final=final, initial=None))
+    # the interval engine and the run engine (forcing constant over the report interval / over runs of 6 and 3 steps):
+    # their wet intervals are an asm loop as well (SMART_WET_ASM)
+    six = bench.six_hourly_forcing(base)
+    three = np.repeat(bench.hourly_varying_forcing(base)[::3], 3, axis=0)[:base.shape[0]]
+    for tag, forcing in (('iv', base), ('runs6', six), ('runs3', three)):
+        for n, days, slices, final, exits in [(257, 400, '', False, '0'), (1000, 600, '4', False, '0'),
+                                              (300, 365, '', False, '1'), (200, 365, '3', True, '')]:
+            out.append(dict(name='%s_%d_%d_%s_%d_%s' % (tag, n, days, slices or 'w', final, exits or 'd'),
+                            forcing=forcing[:days * 24].copy(), params=latin_hypercube(n, ranges, seed=n + 1),
+                            dt=3600.0, W=96 * 24, gap=24, slices=slices, final=final, initial=None, exits=exits))
     # random set-ups: gaps that are and are not multiples of the chunk, storms, droughts, calm steps, exact zeros
     for case in range(24):
         gap = int(rng.choice([2, 3, 4, 6, 8, 24, 48, 5]))
@@ -70,10 +80,11 @@ def dump(path):
     from smartpy_amd import engine
     res = {}
     for c in cases():
-        if c['slices']:
-            os.environ['SMART_TIME_SLICES'] = c['slices']
-        else:
-            os.environ.pop('SMART_TIME_SLICES', None)
+        for var, val in (('SMART_TIME_SLICES', c['slices']), ('SMART_EXITS', c.get('exits', ''))):
+            if val:
+                os.environ[var] = val
+            else:
+                os.environ.pop(var, None)
         n_rep = c['forcing'].shape[0] // c['gap']
         obs = np.random.default_rng(7).random(n_rep) * 3
         obs[::7] = np.nan
@@ -82,8 +93,8 @@ def dump(path):
                                 gw_obs=0.2, want_final=c['final'])
         torch.cuda.synchronize()
         kern = r._prepared.describe()
-        if 'smart_fast_steps' not in kern:      # (a lone ill-conditioned row: nothing of the step loop to compare)
-            continue
+        if 'smart_fast_steps' not in kern and c['name'].startswith(('bench', 'rnd')):
+            continue                            # (a lone ill-conditioned row: nothing of the step loop to compare)
         res[c['name'] + '/kernel'] = np.array(kern)
         res[c['name'] + '/discharge'] = r.discharge.cpu().numpy()
         res[c['name'] + '/gw'] = r.gw.cpu().numpy()

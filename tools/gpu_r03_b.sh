@@ -2,9 +2,9 @@
 # round 3, second GPU pass: bits of the asm arms against the compiled loop; cascade in line / out of line; PMC of the flat leg
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-( SMART_AMD_LIB=$PWD/smartpy_amd/csrc/libsmart_amd_oldsteps.so timeout 900 python tools/debug/steps_bits.py dump gpurun_out/steps_old.npz
-  timeout 900 python tools/debug/steps_bits.py dump gpurun_out/steps_new.npz
-  python tools/debug/steps_bits.py compare gpurun_out/steps_old.npz gpurun_out/steps_new.npz ) > gpurun_out/steps_bits.log 2>&1
+( SMART_AMD_LIB=$PWD/smartpy_amd/csrc/libsmart_amd_oldsteps.so timeout 900 python tools/debug/steps_bits.py dump /tmp/steps_old.npz
+  timeout 900 python tools/debug/steps_bits.py dump /tmp/steps_new.npz
+  python tools/debug/steps_bits.py compare /tmp/steps_old.npz /tmp/steps_new.npz ) > gpurun_out/steps_bits.log 2>&1
 tail -3 gpurun_out/steps_bits.log
 for rep in 1 2 3; do
   for so in default ool0 oldsteps; do

@@ -13,9 +13,9 @@ for so in default ool0 flatloop; do
   echo -n "1e6 $so: "; python tools/debug/flat_only.py 1000000 3 2>/dev/null | tail -2 | tr '\n' ' '; echo
 done 2>&1 | tee -a gpurun_out/ab_stream.log
 unset SMART_AMD_LIB
-( SMART_AMD_LIB=$PWD/smartpy_amd/csrc/libsmart_amd_oldsteps.so timeout 900 python tools/debug/steps_bits.py dump gpurun_out/steps_old.npz
-  timeout 900 python tools/debug/steps_bits.py dump gpurun_out/steps_new.npz
-  python tools/debug/steps_bits.py compare gpurun_out/steps_old.npz gpurun_out/steps_new.npz ) > gpurun_out/steps_bits.log 2>&1
+( SMART_AMD_LIB=$PWD/smartpy_amd/csrc/libsmart_amd_oldsteps.so timeout 900 python tools/debug/steps_bits.py dump /tmp/steps_old.npz
+  timeout 900 python tools/debug/steps_bits.py dump /tmp/steps_new.npz
+  python tools/debug/steps_bits.py compare /tmp/steps_old.npz /tmp/steps_new.npz ) > gpurun_out/steps_bits.log 2>&1
 tail -2 gpurun_out/steps_bits.log
 timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_d.log 2>&1; tail -3 gpurun_out/pytest_d.log
 mkdir -p gpurun_out/prof_r03_flat_d

@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Instruction counts of the hot loops, from the compiler's own assembly, weighed with the path frequencies of the bench
+workloads -> expected instructions per wave-step, per class, to hold against the PMC counters (SQ_INSTS_VALU /
+SQ_INSTS_SALU of profiles/r03_*.md).  Needs hipcc (cross-compiles without a GPU), no GPU.
+
+    python tools/isa_model.py steps      [profiles/r03_isa_model_steps]        the flat_forcing leg (smart_fast_steps)
+    python tools/isa_model.py intervals  [profiles/r03_isa_model_intervals]    the headline run (smart_fast_intervals)
+
+The hot loops are `asm` statements (smartpy_amd/csrc/smart_fast_arms.h): in hipcc -S output they stand between
+;;#ASMSTART / ;;#ASMEND with their local labels intact, so every arm is delimited by its label (100: calm, 110: dry,
+120: rain arm of step 0, ... 130: end of chunk; 5: / 6: the two copies of the wet step).  The classes are those of
+tools/isa_report.py.  What is NOT in an asm (the glue hipcc writes around the chunks and the intervals) is counted
+from the enclosing loop of the same listing.
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+from collections import Counter
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+import numpy as np                                  # noqa: E402
+from isa_report import classify, VALU_CLASSES       # noqa: E402
+from smartpy_amd import build as b                  # noqa: E402
+
+
+def assembly(unit, kernel):
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, 'k.s')
+        subprocess.run([b.hipcc()] + b.COMMON + b.UNITS[unit] + ['--cuda-device-only', '-S', os.path.join(b.CSRC, unit),
+                                                                 '-o', out], check=True, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    m = re.search(r'^(_ZN5smart\d+%s[A-Z]\S*):.*?\n(.*?)\.end_amdhsa_kernel' % re.escape(kernel), text, re.M | re.S)
+    return m.group(2).split('\n')
+
+
+def insts(lines):
+    """[(label or None, opcode)] of a stretch of assembly"""
+    out = []
+    for ln in lines:
+        ln = ln.split(';')[0].strip()
+        if not ln or ln.startswith('.'):
+            continue
+        m = re.match(r'^(\d+|\.LBB\d+_\d+):$', ln)
+        if m:
+            out.append((m.group(1), None))
+            continue
+        out.append((None, ln.split()[0]))
+    return out
+
+
+def hist(ops):
+    c = Counter(classify(op) for op in ops)
+    c['VALU'] = sum(c.get(k, 0) for k in VALU_CLASSES)
+    c['scalar'] = c.get('salu', 0) + c.get('branch', 0)       # what SQ_INSTS_SALU counts: s_* ALU and branches
+    return c
+
+
+def asm_blocks(lines):
+    """the asm statements of a kernel: [(first line, last line, [(label, op)])]"""
+    out, start = [], None
+    for i, ln in enumerate(lines):
+        if 'ASMSTART' in ln:
+            start = i
+        elif 'ASMEND' in ln and start is not None:
+            body = insts(lines[start + 1:i])
+            if body:
+                out.append((start, i, body))
+            start = None
+    return out
+
+
+def segments(body):
+    """split an asm at its numeric labels -> {label: [ops]}; '' = before the first label"""
+    seg, cur = {'': []}, ''
+    for lab, op in body:
+        if lab is not None:
+            cur = lab
+            seg.setdefault(cur, [])
+        else:
+            seg[cur].append(op)
+    return seg
+
+
+def fmt(c):
+    return 'VALU %3d (fp64 %3d, vcmp %d, vmov %d) scalar %2d (branch %d) smem %d' % (
+        c['VALU'], c.get('fp64', 0), c.get('vcmp', 0), c.get('vmov', 0), c['scalar'], c.get('branch', 0), c.get('smem', 0))
+
+
+# ---- the step loop -------------------------------------------------------------------------------------------------
+def steps_model(out):
+    import bench
+    from smartpy_amd.parameters import Parameters
+    from smartpy_amd.sampling import latin_hypercube
+    lines = assembly('smart_fast_steps.hip', 'smart_fast_steps')
+    blocks = asm_blocks(lines)
+    chunk = [blk for blk in blocks if any(lab == '130' for lab, _ in blk[2]) and any(lab == '100' for lab, _ in blk[2])]
+    assert chunk, 'no threaded chunk asm found'
+    seg = segments(chunk[0][2])
+    arms = {}
+    report = ['# smart_fast_steps: the threaded chunk (smart_fast_arms.h: SMART_A_CHUNK), per arm', '']
+    for j in range(4):
+        for kind, base in (('calm', 100), ('dry', 110), ('rain', 120)):
+            arms[kind, j] = hist(seg[str(base + j)])
+        # the rain arm runs on into '8' (behind the EXEC region) and the cascade hooks' return labels
+    # labels inside an arm (8:, 3j1:, 4j1:) split it further: add the pieces that follow an arm up to the next arm label
+    order = [lab for lab, op in chunk[0][2] if lab is not None]
+    arm_of = {}
+    cur = None
+    for lab in order:
+        if lab in [str(x) for x in range(100, 104)] + [str(x) for x in range(110, 114)] + [str(x) for x in range(120, 124)]:
+            cur = lab
+        elif re.fullmatch(r'[34]\d0', lab) or lab == '130':
+            cur = 'ool' + lab if lab != '130' else None
+        if cur:
+            arm_of[lab] = cur
+    full = {}
+    for lab, ops in seg.items():
+        if lab in arm_of:
+            full.setdefault(arm_of[lab], []).extend(ops)
+    cascade = hist(full.get('ool300', []))
+    names = {'10': 'calm', '11': 'dry', '12': 'rain'}
+    per = {}
+    for lab, ops in sorted(full.items()):
+        if lab.startswith('ool'):
+            continue
+        per[names[lab[:2]], int(lab[2])] = hist(ops)
+        report.append('- arm %s of step %s: %s' % (names[lab[:2]], lab[2], fmt(per[names[lab[:2]], int(lab[2])])))
+    report.append('- the deferred cascade, out of line, all six layers: %s' % fmt(cascade))
+    top = hist(seg[''])
+    report.append('- dispatch at the top of the chunk: %s' % fmt(top))
+    # glue: the ping-pong loop = the innermost compiler loop that holds two chunk asms
+    a, bnd = chunk[0][0], chunk[1][1] if len(chunk) > 1 else chunk[0][1]
+    head = max(i for i in range(a) if re.match(r'^\.LBB\d+_\d+:', lines[i]))
+    tail = next(i for i in range(bnd, len(lines)) if re.match(r'\s+s_cbranch', lines[i]))
+    glue_ops = [op for lab, op in insts(lines[head:chunk[0][0]] + lines[chunk[0][1] + 1:chunk[1][0]] +
+                                        lines[chunk[1][1] + 1:tail + 1]) if op]
+    glue = hist(glue_ops)
+    report.append('- hipcc\'s glue around TWO chunks (pointer, s_load_dwordx16 x2, s_waitcnt, counter, back-edge): %s'
+                  % fmt(glue))
+    report.append('')
+
+    # ---- path frequencies of the flat_forcing leg: 1e5 LHS rows as drawn, 64 per wavefront
+    base = bench.synthetic_forcing(0, True)[0]
+    vary = bench.hourly_varying_forcing(base)
+    f = np.concatenate([vary[:bench.WARM_DAYS * 24], vary])
+    rain, pe = f[:, 0], f[:, 1]
+    T = latin_hypercube(100000, Parameters().ranges, seed=2718)[:, 0]
+    pad = (-len(T)) % 64
+    Tw = np.concatenate([T, np.full(pad, T[-1])]).reshape(-1, 64)
+    n_waves, n_steps = Tw.shape[0], len(rain)
+    kind = np.where(rain > 0, 2, np.where(pe > 0, 1, 0))          # 0 calm 1 dry 2 rain
+    j_of = np.arange(n_steps) % 4
+    # lane state: demand pending since the lane's last wet step
+    pending = np.zeros(Tw.shape, bool)
+    tmin, tmax = Tw.min(1), Tw.max(1)
+    n_casc = n_rain_soil = 0
+    count = Counter()
+    for t in range(n_steps):
+        k = kind[t]
+        if k == 1:
+            pending[:] = True
+        elif k == 0:
+            n_casc += int(pending.any(1).sum())
+            pending[:] = False
+        else:
+            thr = pe[t] / rain[t]
+            wet = Tw >= thr                                   # ex = rain T - pe >= 0
+            any_wet = wet.any(1)
+            n_rain_soil += int(any_wet.sum())
+            n_casc += int((pending & wet).any(1).sum())
+            pending = np.where(wet, False, True)
+    tot = Counter()
+    for t in range(n_steps):
+        arm = per[('calm', 'dry', 'rain')[kind[t]], int(j_of[t])]
+        for c in ('VALU', 'fp64', 'scalar', 'branch', 'smem'):
+            tot[c] += arm[c] * n_waves
+    # rain steps in which no lane of the wave is wet skip the soil half (s_cbranch_execz): subtract it
+    rain_soil = hist(seg['120'][seg['120'].index('s_cbranch_execz') + 1:] + seg.get('401', []))
+    dry_rain = int((kind == 2).sum()) * n_waves - n_rain_soil
+    for c in ('VALU', 'fp64', 'scalar', 'branch'):
+        tot[c] -= rain_soil[c] * dry_rain
+    n_chunks = n_steps // 4
+    for c in ('VALU', 'fp64', 'scalar', 'branch', 'smem'):
+        tot[c] += top[c] * n_chunks * n_waves + glue[c] * (n_chunks // 2) * n_waves
+    ws = n_waves * n_steps
+    lo = {c: tot[c] / ws for c in tot}
+    hi = {c: (tot[c] + cascade[c] * n_casc) / ws for c in tot}
+    first = hist(full.get('ool300', [])[:5])                 # a cascade that ends behind the top layer
+    lo = {c: (tot[c] + first[c] * n_casc) / ws for c in tot}
+    report += ['## flat_forcing leg (1e5 LHS rows as drawn, %d wavefronts x %d steps)' % (n_waves, n_steps), '',
+               '- steps: calm %.3f, dry %.3f, rain %.3f; rain steps whose wave has no wet lane: %.4f of all wave-steps; '
+               'cascades due: %.4f per wave-step' % ((kind == 0).mean(), (kind == 1).mean(), (kind == 2).mean(),
+                                                     dry_rain / ws, n_casc / ws),
+               '- expected per wave-step, cascades ending behind the top layer .. walking all six layers:',
+               '  - vector instructions %.2f .. %.2f (fp64 arithmetic %.2f .. %.2f)' % (lo['VALU'], hi['VALU'], lo['fp64'],
+                                                                                     hi['fp64']),
+               '  - scalar ALU + branches %.2f .. %.2f (branches %.2f .. %.2f), scalar loads %.2f' % (
+                   lo['scalar'], hi['scalar'], lo['branch'], hi['branch'], lo['smem']), '']
+    result = {'kernel': 'smart_fast_steps', 'wave_steps': ws, 'per_wave_step_low': lo, 'per_wave_step_high': hi,
+              'fp64_share_of_valu': [lo['fp64'] / lo['VALU'], hi['fp64'] / hi['VALU']],
+              'arms': {'%s%d' % k: dict(v) for k, v in per.items()}, 'cascade': dict(cascade), 'glue_two_chunks': dict(glue)}
+    finish(out, report, result)
+
+
+# ---- the interval engine ---------------------------------------------------------------------------------------------
+def intervals_model(out):
+    import bench
+    from smartpy_amd.parameters import Parameters
+    from smartpy_amd.sampling import latin_hypercube
+    lines = assembly('smart_fast_intervals.hip', 'smart_fast_intervals')
+    blocks = asm_blocks(lines)
+    wet = [blk for blk in blocks if any(lab == '5' for lab, _ in blk[2]) and any(lab == '6' for lab, _ in blk[2])]
+    assert wet, 'no wet-interval asm found'
+    seg = segments(wet[0][2])
+    step = hist(seg['5'])
+    loop_tail = hist([op for op in seg['6'][len(seg['5']):]])
+    entry = hist(seg[''])
+    report = ['# smart_fast_intervals: the wet interval (smart_fast_arms.h: SMART_A_WET_INTERVAL)', '',
+              '- one wet step: %s' % fmt(step), '- loop tail, once per TWO steps: %s' % fmt(loop_tail),
+              '- entry, once per wet interval: %s' % fmt(entry), '']
+    # per-interval glue: everything of the run loop (the compiler loop around the asm statements of the report
+    # intervals) that is not inside an asm, per interval of the loop body (4 intervals per turn: kGroup)
+    # -> counted from the listing between the first and the last wet asm of the group that emits with prefetched
+    #    observations; reported as an upper bound (both sides of the wet / dry branch)
+    grp = wet[-4:] if len(wet) >= 4 else wet
+    span = lines[grp[0][0] - 60:grp[-1][1] + 60]
+    outside = []
+    inside = False
+    for ln in span:
+        if 'ASMSTART' in ln:
+            inside = True
+        elif 'ASMEND' in ln:
+            inside = False
+        elif not inside:
+            outside.append(ln)
+    glue = hist([op for lab, op in insts(outside) if op])
+    per_iv = {c: glue[c] / len(grp) for c in glue}
+    report.append('- hipcc\'s code around the wet asm, per interval, BOTH sides of the wet / dry branch, emit included '
+                  '(upper bound): VALU %.1f (fp64 %.1f), scalar %.1f' % (per_iv['VALU'], per_iv.get('fp64', 0),
+                                                                         per_iv['scalar']))
+    base = bench.synthetic_forcing(0, True)[0]
+    f = np.concatenate([base[:bench.WARM_DAYS * 24], base])[::24]
+    rain, pe = f[:, 0], f[:, 1]
+    T = latin_hypercube(100000, Parameters().ranges, seed=2718)[:, 0]
+    pad = (-len(T)) % 64
+    Tw = np.concatenate([T, np.full(pad, T[-1])]).reshape(-1, 64)
+    tmin, tmax = Tw.min(1), Tw.max(1)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        thr = np.where(rain > 0, pe / rain, np.where(pe > 0, np.inf, -np.inf))
+    any_wet = tmax[:, None] >= thr[None, :]
+    any_dry = tmin[:, None] < thr[None, :]
+    n_waves, n_iv = any_wet.shape
+    ws = n_waves * n_iv * 24
+    n_wet, n_dry = int(any_wet.sum()), int(any_dry.sum())
+    valu = n_wet * (24 * step['VALU'] + entry['VALU']) + n_waves * n_iv * per_iv['VALU']
+    fp64 = n_wet * 24 * step['fp64'] + n_waves * n_iv * per_iv.get('fp64', 0)
+    scal = n_wet * (12 * loop_tail['scalar'] + entry['scalar']) + n_waves * n_iv * per_iv['scalar']
+    report += ['', '## headline run (1e5 LHS rows as drawn, %d wavefronts x %d intervals of 24 steps)' % (n_waves, n_iv), '',
+               '- intervals with a wet lane in the wave: %.4f; with a dry lane: %.4f (both: %.4f)' % (
+                   n_wet / (n_waves * n_iv), n_dry / (n_waves * n_iv), (any_wet & any_dry).mean()),
+               '- expected per wave-step: vector instructions <= %.2f, of them fp64 arithmetic >= %.2f in the wet steps '
+               'alone (%.3f of the vector instructions); scalar ALU + branches <= %.2f' % (
+                   valu / ws, n_wet * 24 * step['fp64'] / ws, n_wet * 24 * step['fp64'] / valu, scal / ws), '']
+    result = {'kernel': 'smart_fast_intervals', 'wave_steps': ws, 'valu_per_wave_step_upper': valu / ws,
+              'fp64_in_wet_steps_per_wave_step': n_wet * 24 * step['fp64'] / ws, 'fp64_upper': fp64 / ws,
+              'fp64_share_of_valu': n_wet * 24 * step['fp64'] / valu, 'scalar_per_wave_step_upper': scal / ws,
+              'wet_step': dict(step), 'wet_interval_fraction': n_wet / (n_waves * n_iv)}
+    finish(out, report, result)
+
+
+def finish(out, report, result):
+    print('\n'.join(report))
+    if out:
+        with open(out + '.md', 'w') as fh:
+            fh.write('\n'.join(report) + '\n')
+        with open(out + '.json', 'w') as fh:
+            json.dump(result, fh, indent=1)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1]
+    out = sys.argv[2] if len(sys.argv) > 2 else None
+    {'steps': steps_model, 'intervals': intervals_model}[which](out)
