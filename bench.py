@@ -333,6 +333,7 @@ def main():
         pmc, pmc_note = pmc_summary(pmc_key)
         traffic, insts = pmc.get('hbm_bytes_per_launch'), pmc.get('valu_insts_per_launch')
         held_clock, held_frac = pmc.get('held_clock_hz'), pmc.get('issue_frac_at_held_clock')
+        fp64_share = pmc.get('fp64_share_of_valu')
         issue = None if insts is None else insts * VALU_ISSUE_CYCLES / (N_SIMD * kern_s * CLOCK_HZ)
         roofline = {
             'bound': 'valu-fp64-issue',
@@ -340,6 +341,11 @@ def main():
             'peak': N_SIMD * CLOCK_HZ / VALU_ISSUE_CYCLES / 1e12,
             'unit': 'T wave-instructions/s',
             'frac': issue,
+            # ... of which fp64 ARITHMETIC (fma / add / mul / min / max / ldexp; no moves, compares, selects): the same
+            # fraction times the arithmetic's share of the vector instructions, from the compiler's assembly of the
+            # hot loop weighed with this workload's path frequencies (tools/isa_model.py, profiles/r03_isa_model_*.md)
+            'useful_frac': None if issue is None or fp64_share is None else issue * fp64_share,
+            'fp64_share_of_valu': fp64_share,
             'clock_basis_hz': CLOCK_HZ,
             # the same fraction over the shader cycles the chip actually ran (it lowers its clock under this load):
             # taken whole from the profiled runs (SQ_INSTS_VALU x 4 / (1,024 SIMDs x GRBM_GUI_ACTIVE / 8)), not mixed
@@ -350,7 +356,9 @@ def main():
             'kernel': kernels, 'launch_ms': launch_ms, 'traffic': traffic, 'pmc_key': pmc_key, 'pmc_source': pmc_note,
             # the reference's literal operation count against the fp64 vector peak: NOT a bound (the kernel executes
             # fewer operations than the reference writes down), kept as the algorithmic ratio
-            'algorithmic_ratio': {'flops_per_sample_step': flops_per_step,
+            'algorithmic_ratio': {'note': 'not a bound: the reference\'s operation count over the time of a kernel '
+                                          'that executes fewer operations',
+                                  'flops_per_sample_step': flops_per_step,
                                   'tflops': units_per_launch * flops_per_step / kern_s / 1e12,
                                   'peak_tflops': FP64_VALU_PEAK_TFLOPS,
                                   'ratio': units_per_launch * flops_per_step / kern_s / 1e12 / FP64_VALU_PEAK_TFLOPS},

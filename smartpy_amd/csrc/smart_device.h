@@ -75,6 +75,10 @@ __device__ __forceinline__ void raise_status(const KArgs &a, int bit)
 #ifndef SMART_NT_STORE
 #define SMART_NT_STORE 0
 #endif
+#ifndef SMART_IV_DEFER
+#define SMART_IV_DEFER 0 // interval / run engine: 1 = a dry interval defers its evaporation demand to the next wet one (measured:
+                         // no gain at any load, and its extra live value costs the kernel with exits its third wave per SIMD)
+#endif
 #ifndef SMART_CHUNK_THREADED
 #define SMART_CHUNK_THREADED 1 // the four steps of a chunk as one threaded asm (0: four single-step asms; A/B builds)
 #endif
@@ -814,11 +818,41 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
 
     // A per-lane if / else: a wavefront whose lanes all fall on one side skips the other (s_cbranch_execz); in a mixed
     // wavefront each side runs under its lanes' mask.  Either way a lane's arithmetic depends on its own sample only.
+    // Without rain the whole wavefront is on one side whatever its T values are (ex = -peva): the scalar unit sees that
+    // from the forcing itself and spares the run its compare, its EXEC region and -- a calm run: neither rain nor
+    // evaporation, the night block of sub-daily data -- the filling.  For forcing without negative or non-finite values
+    // and waves with no layer above capacity (`quick`, as in the step loop); the kernels whose wet interval is the
+    // asm loop.
+    bool quick = false;
+    if constexpr (piecewise && Model::kWetAsm) {
+        m.note_capacity();
+        quick = m.over_mask == 0 && !(fflags & kForcingInsane);
+    }
     auto interval = [&](const double2 v, double &acc, double &num, double &den) {
+        if constexpr (piecewise && Model::kWetAsm) {
+            if (quick && __builtin_bit_cast(unsigned long long, v.x) == 0) {
+                if (__builtin_bit_cast(unsigned long long, v.y) == 0) {
+#if SMART_IV_DEFER
+                    if (__builtin_amdgcn_ballot_w64(m.pend > 0.0) != 0)
+                        m.flush_pending();
+#endif
+                    m.calm_interval(run_len, acc);
+                } else {
+                    m.dry_interval(-v.y, run_len, acc);
+                }
+                return;
+            }
+        }
         const double ex = m.excess(v.x, v.y);
         if (ex < 0.0) {
             m.dry_interval(ex, run_len, acc);
         } else {
+#if SMART_IV_DEFER
+            // what the lane's dry intervals since its last wet one have added to `pend` is taken from the layers now
+            // (FastModel::dry_interval): one cascade per dry spell instead of one per dry interval
+            if (m.pend > 0.0)
+                m.flush_pending();
+#endif
             m.wet_interval(ex, run_len, acc, num, den);
         }
     };
@@ -879,7 +913,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
     auto park_state = [&]() {
         if constexpr (Model::kSplit) {
             m.save_state(park, 1);
-            if constexpr (!piecewise)
+            if constexpr (!piecewise || SMART_IV_DEFER)
                 park[15] = m.pend;
         }
     };
@@ -889,6 +923,9 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     const double inv_gap = 1.0 / (double)gap;
     const bool starts_run = ra == 0 && (rb > 0 || last);
+    constexpr bool deferring = !piecewise || SMART_IV_DEFER; // is an evaporation demand carried in `pend`?
+    if constexpr (piecewise && deferring)
+        m.pend = seg > 0 ? hand[15 * kWave] : 0.0; // evaporation demand not yet taken from the layers (dry_interval)
     if constexpr (runs) {
         // `per` runs make a report interval; the walk is over runs, the report falls on every per-th of them
         const long per = gap / run_len;
@@ -1007,6 +1044,8 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
             }
         }
 #endif
+    }
+    if constexpr (deferring) {
         if (last)
             m.flush_pending(); // the final state vector wants the layers as the reference leaves them
     }
@@ -1018,7 +1057,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
             double flows[7];
             Model m0 = m;
             m0.load_state(park, 1);
-            if constexpr (!piecewise) {
+            if constexpr (deferring) {
                 m0.begin_lazy(park[15]);
                 m0.flush_pending();
             }
@@ -1043,7 +1082,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         hand[20 * kWave] = rep.C2;
         hand[21 * kWave] = rep.C3;
         hand[22 * kWave] = rep.shift;
-        if constexpr (!piecewise)
+        if constexpr (deferring)
             hand[15 * kWave] = m.pend;
         if (!(a.debug_drop && slot == 0 && seg == 0)) // test knob: a hand-over that never arrives
             publish_slice(a, slot, seg, true);

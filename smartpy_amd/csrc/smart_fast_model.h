@@ -470,6 +470,26 @@ struct FastModel {
 #endif
     static constexpr bool kWetAsm = SMART_WET_ASM && kLeakBalance && !kExits && !SPLIT && SMART_FAST_BALANCE_SUMS && !STIFF;
 
+    // `n` wet steps with ZERO excess for every lane (rain == 0 and peva == 0 over the run: wave-uniform, decided by the
+    // caller on the scalar unit; never when a layer may be above its capacity): no overland flow, nothing to fill
+    __device__ __forceinline__ void calm_interval(long n, double &acc)
+    {
+        static_assert(kWetAsm, "calm_interval() is the asm loop of the straight-line merged kernels");
+        double tot = layer_sum();
+        double t0, t1, xf, xg, w_s1, w_p2, w_p3, w_p4, w_p5, w_p6, w_ai;
+        int cnt;
+        asm volatile(SMART_A_CALM_INTERVAL
+                     : [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), [l4] "+v"(l4), [l5] "+v"(l5),
+                       [ys] "+v"(u_ove), [yf] "+v"(u_int), [yg] "+v"(u_sgw), [riv] "+v"(u_riv), [acc] "+v"(acc),
+                       [tot] "+v"(tot), [xgs] "+v"(xg_sum), [t0] "=&v"(t0), [t1] "=&v"(t1), [xf] "=&v"(xf),
+                       [xg] "=&v"(xg), [s1] "=&v"(w_s1), [p2] "=&v"(w_p2), [p3] "=&v"(w_p3), [p4] "=&v"(w_p4),
+                       [p5] "=&v"(w_p5), [p6] "=&v"(w_p6), [ai] "=&v"(w_ai), [cnt] "=&s"(cnt)
+                     : [cs] "v"(car_s), [cf] "v"(car_f), [cg] "v"(car_g), [oma] "v"(om_ar), [ds] "v"(dec_s),
+                       [df] "v"(dec_f), [dg] "v"(dec_g), [sz] "v"(sz), [k3] "s"(-(1.0 / 3.0)), [k5] "s"(-0.2),
+                       [k6] "s"(-(1.0 / 6.0)), [n] "s"((int)n)
+                     : "scc");
+    }
+
     // `n` wet steps with the same rain excess: the layer sum is handed from step to step
     __device__ __forceinline__ void wet_interval(double ex, long n, double &acc, double &num, double &den)
     {
@@ -919,6 +939,13 @@ struct FastModel {
         // the two differ by the rounding of n subtractions).  Every lane does the same thing, so a sample's
         // arithmetic does not depend on its wave neighbours; the early exits only skip identity operations.
         double d = -ex * (double)n;
+#if SMART_IV_DEFER
+        // ... and, by the same argument, the demands of CONSECUTIVE dry intervals add up as well: nothing looks at the
+        // layers before the lane's next wet interval, so the demand only joins `pend` here and the cascade runs once
+        // per dry spell, in front of that wet interval (run_ensemble_merged) -- 13 instead of 36 vector instructions
+        // for a dry interval.  `pend` travels in the slice hand-over like the states.
+        pend += d;
+#else
         dry(l0, d, pC);
         if (!kExits || __builtin_amdgcn_ballot_w64(d > 0.0) != 0) {
             dry(l1, d, pC);
@@ -929,6 +956,7 @@ struct FastModel {
                 dry(l5, d, pC);
             }
         }
+#endif
         acc += fma(B_r, u_riv, fma(B_q, u_ove, fma(B_i, u_int, B_g * u_sgw)));
         u_riv = fma(P_r, u_riv, fma(A_q, u_ove, fma(A_i, u_int, A_g * u_sgw)));
         u_ove *= P_q;

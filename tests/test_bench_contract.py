@@ -82,6 +82,12 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     f = d['flat_forcing']
     assert 'smart_fast_steps' in f['kernel'] and 0 < f['value'] < d['value'] * 1.05
     assert abs(d['value'] - 20000 * 96432 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    r6 = d['runs_of_6']           # 6-hourly data in the hourly run: the interval engine over runs of six steps
+    assert 'smart_fast_runs' in r6['kernel'] and 0 < r6['value'] < d['value'] * 1.05
+    st = d['strong_1e6']          # config 4 beside config 3, one command for both series
+    assert st['runs_total'] == st['runs_per_gpu'] == 1000000 and 'smart_fast_intervals_exits' in st['kernel']
+    assert d['ranks']['world_size'] == 1 and len(d['ranks']['devices']) == 1
+    assert 'useful_frac' in r and 'not a bound' in r['algorithmic_ratio']['note']
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 1e6 and 'sample' in c
     assert d['value'] > 50 * c['value']          # sanity: the GPU path is orders of magnitude ahead of the host cores
@@ -101,8 +107,9 @@ def test_bench_with_two_ranks_launched_the_way_the_driver_does(config, samples):
     out = subprocess.check_output(
         [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
          '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
-         '--warmup', '1', '--config', str(config), '--samples', str(samples), '--no-cpu-baseline', '--no-flat'],
-        cwd=ROOT, env=env, stderr=subprocess.DEVNULL, timeout=600).decode()
+         '--warmup', '1', '--config', str(config), '--samples', str(samples), '--no-flat'] +
+        ([] if config == 3 else ['--no-cpu-baseline']),       # config 3: the whole line, cpu_baseline and parity included
+        cwd=ROOT, env=env, stderr=subprocess.DEVNULL, timeout=900).decode()
     lines = [ln for ln in out.splitlines() if ln.startswith('{')]
     assert len(lines) == 1                                   # rank 0 prints, rank 1 does not
     d = json.loads(lines[0])
@@ -114,5 +121,17 @@ def test_bench_with_two_ranks_launched_the_way_the_driver_does(config, samples):
         assert d['scaling'] == 'strong' and c['runs_total'] == samples and c['runs_per_gpu'] == samples // 2
     else:                   # strong: 64 catchments cut by catchment
         assert d['scaling'] == 'strong' and c['runs_total'] == 64 * samples and c['runs_per_gpu'] == 32 * samples
+    # the line says who took part: backend, one device and one launch time per rank
+    r = d['ranks']
+    assert r['backend'] == 'gloo' and r['world_size'] == 2 and len(r['devices']) == 2
+    assert len(r['launch_ms_per_rank']) == 2 and all(ms > 0 for ms in r['launch_ms_per_rank'])
+    assert sorted(x['rank'] for x in r['ranks']) == [0, 1] and len({x['pid'] for x in r['ranks']}) == 2
+    if config == 3:
+        # N > 1 keeps rank 0's CPU baseline and the in-run parity check, and carries config 4's strong-scaled figure
+        assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 1e6
+        assert d['parity']['ok'] and d['parity']['max_rel_discharge'] <= 1e-6
+        st = d['strong_1e6']
+        assert st['scaling'] == 'strong' and st['runs_total'] == 1000000 and st['runs_per_gpu'] == 500000
+        assert len(st['launch_ms_per_rank']) == 2 and st['value'] > 0
     per_step = c['runs_total'] * 96432            # sample-timesteps of one step, warm-up included
     assert abs(d['value'] - per_step / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']

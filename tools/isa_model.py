@@ -101,39 +101,53 @@ def steps_model(out):
     blocks = asm_blocks(lines)
     chunk = [blk for blk in blocks if any(lab == '130' for lab, _ in blk[2]) and any(lab == '100' for lab, _ in blk[2])]
     assert chunk, 'no threaded chunk asm found'
-    seg = segments(chunk[0][2])
-    arms = {}
-    report = ['# smart_fast_steps: the threaded chunk (smart_fast_arms.h: SMART_A_CHUNK), per arm', '']
-    for j in range(4):
-        for kind, base in (('calm', 100), ('dry', 110), ('rain', 120)):
-            arms[kind, j] = hist(seg[str(base + j)])
-        # the rain arm runs on into '8' (behind the EXEC region) and the cascade hooks' return labels
-    # labels inside an arm (8:, 3j1:, 4j1:) split it further: add the pieces that follow an arm up to the next arm label
-    order = [lab for lab, op in chunk[0][2] if lab is not None]
-    arm_of = {}
-    cur = None
-    for lab in order:
-        if lab in [str(x) for x in range(100, 104)] + [str(x) for x in range(110, 114)] + [str(x) for x in range(120, 124)]:
-            cur = lab
-        elif re.fullmatch(r'[34]\d0', lab) or lab == '130':
-            cur = 'ool' + lab if lab != '130' else None
-        if cur:
-            arm_of[lab] = cur
-    full = {}
-    for lab, ops in seg.items():
-        if lab in arm_of:
-            full.setdefault(arm_of[lab], []).extend(ops)
-    cascade = hist(full.get('ool300', []))
-    names = {'10': 'calm', '11': 'dry', '12': 'rain'}
-    per = {}
-    for lab, ops in sorted(full.items()):
-        if lab.startswith('ool'):
+    # the asm in order: pieces between labels, each piece owned by the arm (or out-of-line cascade) it lies in
+    pieces, cur_lab = [['', []]], ''
+    for lab, op in chunk[0][2]:
+        if lab is not None:
+            pieces.append([lab, []])
+        else:
+            pieces[-1][1].append(op)
+    arm_labels = {str(b + j): (k, j) for k, b in (('calm', 100), ('dry', 110), ('rain', 120)) for j in range(4)}
+    owner, per_ops, ool_ops, top_ops = None, {}, {}, []
+    for lab, ops in pieces:
+        if lab == '':
+            top_ops += ops
             continue
-        per[names[lab[:2]], int(lab[2])] = hist(ops)
-        report.append('- arm %s of step %s: %s' % (names[lab[:2]], lab[2], fmt(per[names[lab[:2]], int(lab[2])])))
+        if lab in arm_labels:
+            owner = arm_labels[lab]
+        elif re.fullmatch(r'[34]\d0', lab):
+            owner = 'ool' + lab
+        elif lab == '130':
+            owner = None
+        if owner is None:
+            continue
+        (ool_ops if isinstance(owner, str) else per_ops).setdefault(owner, []).extend(ops)
+    report = ['# smart_fast_steps: the threaded chunk (smart_fast_arms.h: SMART_A_CHUNK), per arm', '']
+    per = {k: hist(v) for k, v in per_ops.items()}
+    for k in sorted(per):
+        report.append('- arm %s of step %d: %s' % (k[0], k[1], fmt(per[k])))
+    cascade = hist(ool_ops['ool300'])
     report.append('- the deferred cascade, out of line, all six layers: %s' % fmt(cascade))
-    top = hist(seg[''])
+    top = hist(top_ops)
     report.append('- dispatch at the top of the chunk: %s' % fmt(top))
+    # the soil half of a rain arm (skipped by s_cbranch_execz when no lane of the wave is wet): from behind that
+    # branch up to the label 8
+    r0 = per_ops['rain', 0]
+    soil_ops = []
+    seen = False
+    for lab, ops in pieces:
+        if lab == '120':
+            seen = True
+        if seen:
+            if lab == '8':
+                break
+            if 's_cbranch_execz' in ops:
+                soil_ops += ops[ops.index('s_cbranch_execz') + 1:]
+            elif soil_ops or lab == '401':
+                soil_ops += ops
+    rain_soil = hist(soil_ops)
+    report.append('- of a rain arm, the soil half under EXEC (skipped when no lane is wet): %s' % fmt(rain_soil))
     # glue: the ping-pong loop = the innermost compiler loop that holds two chunk asms
     a, bnd = chunk[0][0], chunk[1][1] if len(chunk) > 1 else chunk[0][1]
     head = max(i for i in range(a) if re.match(r'^\.LBB\d+_\d+:', lines[i]))
@@ -181,7 +195,6 @@ def steps_model(out):
         for c in ('VALU', 'fp64', 'scalar', 'branch', 'smem'):
             tot[c] += arm[c] * n_waves
     # rain steps in which no lane of the wave is wet skip the soil half (s_cbranch_execz): subtract it
-    rain_soil = hist(seg['120'][seg['120'].index('s_cbranch_execz') + 1:] + seg.get('401', []))
     dry_rain = int((kind == 2).sum()) * n_waves - n_rain_soil
     for c in ('VALU', 'fp64', 'scalar', 'branch'):
         tot[c] -= rain_soil[c] * dry_rain
@@ -191,7 +204,7 @@ def steps_model(out):
     ws = n_waves * n_steps
     lo = {c: tot[c] / ws for c in tot}
     hi = {c: (tot[c] + cascade[c] * n_casc) / ws for c in tot}
-    first = hist(full.get('ool300', [])[:5])                 # a cascade that ends behind the top layer
+    first = hist(ool_ops['ool300'][:5] + ool_ops['ool300'][-8:])   # a cascade that ends behind the top layer
     lo = {c: (tot[c] + first[c] * n_casc) / ws for c in tot}
     report += ['## flat_forcing leg (1e5 LHS rows as drawn, %d wavefronts x %d steps)' % (n_waves, n_steps), '',
                '- steps: calm %.3f, dry %.3f, rain %.3f; rain steps whose wave has no wet lane: %.4f of all wave-steps; '

@@ -35,6 +35,15 @@ def dominant_first(kernels):
     return sorted(kernels, key=lambda k: -total.get(k, 0.0))
 
 
+def fp64_share(kernel):
+    name = kernel.split('::')[-1]
+    path = os.path.join(os.path.dirname(dst) or '.', 'r03_isa_model_%s.json' % name.replace('smart_fast_', ''))
+    if not os.path.exists(path):
+        return None
+    share = json.load(open(path)).get('fp64_share_of_valu')
+    return min(share) if isinstance(share, list) else share
+
+
 def timed(values):
     """the per-dispatch values of the timed steps (the warm-up dispatches dropped, when there are enough left)"""
     return values[n_warm:] if len(values) > n_warm else values
@@ -177,6 +186,9 @@ if workload and main and 'hbm_bytes_per_launch' in out:
         'issue_frac_at_held_clock': (c['SQ_INSTS_VALU'] * 4.0 / (1024 * c['GRBM_GUI_ACTIVE'] / 8.0)
                                      if 'SQ_INSTS_VALU' in c and 'GRBM_GUI_ACTIVE' in c else None),
         'avg_ms_kernel_trace': out.get('full_size_dispatch_ms', {}).get('avg'),
+        # share of the vector instructions that are fp64 arithmetic (tools/isa_model.py: the compiler's assembly of the
+        # hot loop weighed with this workload's path frequencies); null for kernels without a model
+        'fp64_share_of_valu': fp64_share(main[0]),
         'source': dst + '.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU / GRBM_GUI_ACTIVE (separate '
                   'passes, tools/profile.sh) on the bench command of this workload; FETCH_SIZE doubled per '
                   'MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B), an upper bound here since the reads '
