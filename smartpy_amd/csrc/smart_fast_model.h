@@ -25,6 +25,13 @@
 //     a dry interval is ONE evaporation step with gap times the demand plus a precomputed linear routing map
 //     (dry_interval), a wet interval is `gap` straight-line wet steps whose leak amounts come from mass balance
 //     (wet_balance: 74 vector instructions per step against 117 in the step loop);
+//   * the same engine advances forcing that is constant over shorter runs (k steps, k a divisor of the report gap:
+//     6-hourly data in an hourly run) a run at a time, the report mean accumulating across runs (smart_fast_runs);
+//     runs without rain are classified on the scalar unit (every lane dry, or -- no evaporation either -- calm: wet
+//     steps with nothing to fill);
+//   * forcing that varies from step to step takes the step loop, written at the instruction level: three asm arms
+//     (dry / calm / rain) picked per step on the scalar unit, threaded through chunks of four steps
+//     (smart_fast_arms.h); the wet interval of the straight-line interval kernel is an asm loop as well;
 //   * launches with more blocks of 64 samples than SIMDs are time-sliced (smart_device.h) so that the hardware
 //     dispatcher evens out what a whole-run-per-wavefront mapping leaves idle.
 //
@@ -684,6 +691,8 @@ struct FastModel {
     }
 
     // ---- step loop with deferred evaporation (forcing that varies inside the report interval) -----------------------
+    // (step_lazy() below is the compiled form of round 2, kept behind -DSMART_STEP_ARMS=0 as the bit-for-bit yardstick
+    // of the asm arms further down, which perform the same operations in the same order)
     // A dry step does two unrelated things: the reservoirs drain (routing, needed every step: the river's outflow is
     // reported) and the evaporation demand is taken from the soil layers (6 x 3 dependent instructions) -- but nothing
     // looks at the layers again until the lane's next WET step.  The cascade composes additively (dry_interval below:

@@ -1,5 +1,6 @@
 // smart_fast_steps.hip -- the step loops of the regular (class 0) rows: forcing that varies inside the report interval
-// (genuinely sub-daily data), raw reports, and report gaps of one step.  See smart_fast_entry.h for the family.
+// (genuinely sub-daily data: the asm arms of smart_fast_arms.h), raw reports, and report gaps of one step.  See
+// smart_fast_entry.h for the family.
 #include "smart_fast_entry.h"
 
 namespace smart {

@@ -7,7 +7,9 @@ whatever order and on whatever CUs the competing work leaves free -- the situati
 With `flat` the forcing varies inside the day: the step loop with deferred evaporation, whose pending demand travels
 in the hand-over.
 
-    python tools/debug/time_slices_stress.py <n_samples> <launches> [busy] [flat]
+With `runs` the forcing is constant over runs of six steps: the run engine.
+
+    python tools/debug/time_slices_stress.py <n_samples> <launches> [busy] [flat | runs]
 """
 import sys, time
 sys.path.insert(0, '.')
@@ -18,8 +20,11 @@ from smartpy_amd.parameters import Parameters
 dev = torch.device('cuda:0')
 forcing = bench.synthetic_forcing(0, True)[0]
 flat = 'flat' in sys.argv[3:]
+runs = 'runs' in sys.argv[3:]
 if flat:
     forcing = bench.hourly_varying_forcing(forcing)
+if runs:
+    forcing = bench.six_hourly_forcing(forcing)
 T, W = forcing.shape[0], 8760
 ft = torch.as_tensor(forcing, device=dev)
 obs = torch.rand(T // 24, dtype=torch.float64, device=dev) + 0.5
@@ -53,5 +58,5 @@ for i in range(reps):
         bad += 1
 torch.cuda.synchronize()
 print('N=%d%s: %s; %d launches, %.2f ms each incl. poison + compare, %d differ, %d with a non-zero status word'
-      % (n, (' sub-daily forcing' if flat else '') + (' + competing stream' if busy else ''), p.describe(), reps, (time.perf_counter() - t0) / reps * 1e3, bad,
+      % (n, (' sub-daily forcing' if flat else '') + (' 6-hourly forcing' if runs else '') + (' + competing stream' if busy else ''), p.describe(), reps, (time.perf_counter() - t0) / reps * 1e3, bad,
          timeouts))

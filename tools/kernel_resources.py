@@ -7,6 +7,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'smartpy_amd', 'csrc')
 UNITS = {'smart_fast_intervals': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
+         'smart_fast_runs': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
          'smart_fast_steps': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
          'smart_fast_guarded': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
          'smart_literal': ['-ffp-contract=off'], 'smart_capi': []}
