@@ -182,6 +182,12 @@ __device__ __forceinline__ bool same_bits(double x, double y)
 #endif
 constexpr int kChunk = SMART_CHUNK;
 
+// does the model want to look at a chunk before its steps (LiteralModelT<true>::begin_chunk)?
+template <class Model, class = void>
+struct chunk_hook : std::false_type {};
+template <class Model>
+struct chunk_hook<Model, std::enable_if_t<Model::kChunkHook>> : std::true_type {};
+
 // The rain excess of the kChunk steps of a chunk is evaluated together, ahead of the steps (independent FMAs that
 // fill issue slots while the first step's dependent chain starts).
 template <class Model, class Body, class ChunkEnd>
@@ -200,6 +206,8 @@ __device__ __forceinline__ void time_loop_chunked(const Model &m, const double2 
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
             nxt[j] = f[pre + j];
+        if constexpr (chunk_hook<Model>::value)
+            const_cast<Model &>(m).begin_chunk(cur, kChunk);
         double ex[kChunk];
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
@@ -214,6 +222,8 @@ __device__ __forceinline__ void time_loop_chunked(const Model &m, const double2 
     }
     for (long t = n_chunks * kChunk; t < n; ++t) {
         const double2 v = f[t];
+        if constexpr (chunk_hook<Model>::value)
+            const_cast<Model &>(m).begin_chunk(&v, 1);
         body(v, m.excess(v.x, v.y));
     }
 }

@@ -21,7 +21,13 @@ SMART_FAST_KERNEL(smart_fast_stiff) { guarded_kernel<1, FastModel<true, false>>(
 
 SMART_FAST_KERNEL(smart_fast_guard) { guarded_kernel<2, FastModel<true, true>>(a, forcing, obs, ws); }
 
-SMART_FAST_KERNEL(smart_fast_illcond) { guarded_kernel<3, LiteralModel>(a, forcing, obs, ws); }
+#ifndef SMART_ILLCOND_RECIP
+#define SMART_ILLCOND_RECIP 1 // divisions by per-sample constants through cached reciprocals (0: true divisions)
+#endif
+SMART_FAST_KERNEL(smart_fast_illcond)
+{
+    guarded_kernel<3, LiteralModelT<SMART_ILLCOND_RECIP != 0>>(a, forcing, obs, ws);
+}
 
 const void *fast_kernel_guarded(FastKernel k)
 {

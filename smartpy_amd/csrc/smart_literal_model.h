@@ -10,16 +10,33 @@
 // with dt / RK > 2: there the river's explicit Euler update amplifies any rounding difference by |1 - dt/RK| on
 // every step its 95 % rule does not fire, so only the reference's own operation order reproduces its discharge
 // ("Ill-conditioned samples").
+//
+// RECIP (the ill-conditioned rows of the fast mode, smart_fast_illcond): 31 of a step's 39 divisions are by one of ten
+// per-sample constants (area, Z, dt, the four routing constants) or by 1e3 / 2 .. 6, and an IEEE division is ten
+// instructions on gfx950 (v_div_scale x2, v_rcp, four refinement FMAs, v_div_fmas, v_div_fixup) -- half of the literal
+// step.  With y = RN(1 / b) kept per sample (one true division at set-up), Markstein's correction step
+//     q0 = RN(a y);   r = RN(a - b q0)  [exact: one FMA];   q = RN(q0 + r y)
+// returns the correctly rounded quotient RN(a / b) -- THE SAME BITS as the division -- for every a, unless b's
+// significand is all ones (P. Markstein, IBM J. Res. Dev. 34 (1990), Theorem 4.2; the tail of hipcc's own division
+// sequence is this step) or the computation leaves the normal range (r is exact only while a - b q0 is representable:
+// |a| >= 2^-969 is enough).  Both conditions are checked, wave-uniformly: the divisors once per run, the twelve
+// states and the step's forcing once per chunk of four steps against [2^-800, 2^800] (a state shrinks by 2^-53 per
+// step at most: (1 - dt/k) of a double dt/k < 1); a wave that fails takes the true divisions for that chunk.  What is
+// NOT checked are numerators formed inside the step from products with tiny factors (a leak l s'^6 with s' ~ 1e-50):
+// a quotient of a numerator below 2^-969 may differ in its last bit -- of a number that is zero to any hydrologist.
+// tests/test_gpu_parity.py keeps comparing the kernel with the literal kernel (true divisions throughout) bit for bit.
 #pragma once
 
 #include "smart_device.h"
 
 namespace smart {
 
-struct LiteralModel {
+template <bool RECIP>
+struct LiteralModelT {
     static constexpr bool kExactDivide = true;
     static constexpr bool kBalanceSums = false;
     static constexpr bool kTracksOutputs = true; // out[] holds the seven outputs of the last step taken
+    static constexpr bool kChunkHook = RECIP;    // time_loop_chunked() calls begin_chunk() ahead of every chunk
 
     double area, dt;
     double pT, pC, pH, pD, pS, pZ, sk, fk, gk, rk;
@@ -45,6 +62,60 @@ struct LiteralModel {
 #pragma unroll
         for (int i = 0; i < 7; ++i)
             out[i] = 0.0;
+        if constexpr (RECIP) {
+            y_area = 1.0 / area, y_z = 1.0 / pZ, y_dt = 1.0 / dt;
+            y_sk = 1.0 / sk, y_fk = 1.0 / fk, y_gk = 1.0 / gk, y_rk = 1.0 / rk;
+            // a divisor is fit for the correction step if it is a positive normal number within [2^-500, 2^500] whose
+            // significand is not all ones
+            auto fit = [](double b) {
+                const unsigned long long u = __builtin_bit_cast(unsigned long long, b);
+                const unsigned long long frac = u & 0x000fffffffffffffull;
+                return u - 0x20b0000000000000ull < 0x3e80000000000000ull && frac != 0x000fffffffffffffull;
+            };
+            const bool ok = fit(area) && fit(pZ) && fit(dt) && fit(sk) && fit(fk) && fit(gk) && fit(rk);
+            divisors_fit = __builtin_amdgcn_ballot_w64(!ok) == 0;
+            quick = false;
+        }
+    }
+
+    // ---- RECIP: division by a per-sample constant b with y = RN(1 / b) at hand -------------------------------------
+    double y_area, y_z, y_dt, y_sk, y_fk, y_gk, y_rk;
+    bool divisors_fit, quick; // wave-uniform: every divisor of the wave is fit; this chunk may use the correction step
+
+    template <bool Q>
+    __device__ __forceinline__ static double dv(double a, double b, double y)
+    {
+#pragma clang fp contract(off)
+        if constexpr (Q) {
+            const double q0 = a * y;
+            const double r = __builtin_fma(-b, q0, a);
+            return __builtin_fma(r, y, q0);
+        } else {
+            return a / b;
+        }
+    }
+
+    // 0 or within [2^-800, 2^800): nothing of what this step divides leaves the normal range
+    __device__ __forceinline__ static bool in_range(double x)
+    {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+        return u == 0 || u - 0x0df0000000000000ull < 0x6400000000000000ull;
+    }
+
+    // ahead of a chunk of (at most) four steps, with their forcing
+    __device__ __forceinline__ void begin_chunk(const double2 *f4, int n)
+    {
+        if constexpr (RECIP) {
+            bool ok = in_range(v_ove) && in_range(v_dra) && in_range(v_int) && in_range(v_sgw) && in_range(v_dgw) &&
+                      in_range(v_riv);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                ok = ok && in_range(v_ly[i]);
+            bool forcing_ok = true; // (scalar unit: the forcing is wave-uniform)
+            for (int j = 0; j < n; ++j)
+                forcing_ok = forcing_ok && in_range(f4[j].x) && in_range(f4[j].y);
+            quick = divisors_fit && forcing_ok && __builtin_amdgcn_ballot_w64(!ok) == 0;
+        }
     }
 
     __device__ void set_states(const double *st)
@@ -82,12 +153,18 @@ struct LiteralModel {
     // run_one_step_river, structure.py:461-503, with rk already in seconds: outflow of the step, v updated
     __device__ static double river(double dt, double q_in, double rk, double &v)
     {
+        return river_q<false>(dt, q_in, rk, v, 0.0, 0.0);
+    }
+
+    template <bool Q>
+    __device__ static double river_q(double dt, double q_in, double rk, double &v, double y_rk, double y_dt)
+    {
 #pragma clang fp contract(off)
-        double q = v / rk; // :487
+        double q = dv<Q>(v, rk, y_rk); // :487
         const double v_old = v;
         const double tmp = v_old + (q_in - q) * dt; // :490
         if (tmp < 0.0) {                            // :492-496
-            q = 0.95 * (q_in + v_old / dt);
+            q = 0.95 * (q_in + dv<Q>(v_old, dt, y_dt));
             v += (q_in - q) * dt;
         } else {
             v = tmp; // :498
@@ -95,11 +172,12 @@ struct LiteralModel {
         return q;
     }
 
-    __device__ static double route(double &v, double k, double x_mm, double area, double dt)
+    template <bool Q>
+    __device__ static double route(double &v, double k, double y_k, double x_mm, double area, double dt)
     {
 #pragma clang fp contract(off)
-        const double q = v / k;
-        v += (x_mm / 1e3 * area) - (q * dt);
+        const double q = dv<Q>(v, k, y_k);
+        v += (dv<Q>(x_mm, 1e3, 1e-3) * area) - (q * dt);
         if (v < 0.0)
             v = 0.0;
         return q;
@@ -114,12 +192,24 @@ struct LiteralModel {
 
     __device__ void step(double rain_in, double peva_in, double /*ex*/, double &acc, double &num, double &den)
     {
+        if constexpr (RECIP) {
+            if (quick) { // wave-uniform
+                step_q<true>(rain_in, peva_in, acc, num, den);
+                return;
+            }
+        }
+        step_q<false>(rain_in, peva_in, acc, num, den);
+    }
+
+    template <bool Q>
+    __device__ __forceinline__ void step_q(double rain_in, double peva_in, double &acc, double &num, double &den)
+    {
 #pragma clang fp contract(off)
         const double z = pZ / 6.0; // structure.py:329-337
         double l[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
-            l[i] = v_ly[i] / area * 1e3; // :339-347
+            l[i] = dv<Q>(v_ly[i], area, y_area) * 1e3; // :339-347
         double tot = 0.0 + 0.0;          // Python's sum() over [0.0, l1..l6] (:350)
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -132,7 +222,7 @@ struct LiteralModel {
 
         if (ex >= 0.0) { // :359
             aeva += peva_in;
-            const double hp = pH * (tot / pZ); // :363
+            const double hp = pH * dv<Q>(tot, pZ, y_z); // :363
             of = hp * ex;
             ex -= of;
 #pragma unroll
@@ -148,7 +238,7 @@ struct LiteralModel {
             }
             df = pD * ex;                      // :376
             inf = (1.0 - pD) * ex;             // :377
-            const double s1 = pS * (tot / pZ); // :379
+            const double s1 = pS * dv<Q>(tot, pZ, y_z); // :379
             double pw[6];                      // s1 ** (i + 1) as a product chain
             pw[0] = s1;
 #pragma unroll
@@ -165,7 +255,8 @@ struct LiteralModel {
             sh = 0.0;
 #pragma unroll
             for (int i = 0; i < 6; ++i) { // :387-392
-                const double lk = l[i] * (s1 / (double)(i + 1));
+                constexpr double by[6] = {1.0, 1.0 / 2.0, 1.0 / 3.0, 1.0 / 4.0, 1.0 / 5.0, 1.0 / 6.0}; // RN(1 / (i + 1))
+                const double lk = l[i] * (i == 0 ? s1 : dv<Q>(s1, (double)(i + 1), by[i])); // s1 / 1 is s1
                 if (lk < l[i]) {
                     sh += lk;
                     l[i] -= lk;
@@ -202,20 +293,20 @@ struct LiteralModel {
             }
         }
 
-        out[0] = aeva / 1e3 * area / dt; // :424
-        out[1] = route(v_ove, sk, of, area, dt);
-        out[2] = route(v_dra, sk, df, area, dt);
-        out[3] = route(v_int, fk, inf, area, dt);
-        out[4] = route(v_sgw, gk, sh, area, dt);
-        out[5] = route(v_dgw, gk, dp, area, dt);
+        out[0] = dv<Q>(dv<Q>(aeva, 1e3, 1e-3) * area, dt, y_dt); // :424
+        out[1] = route<Q>(v_ove, sk, y_sk, of, area, dt);
+        out[2] = route<Q>(v_dra, sk, y_sk, df, area, dt);
+        out[3] = route<Q>(v_int, fk, y_fk, inf, area, dt);
+        out[4] = route<Q>(v_sgw, gk, y_gk, sh, area, dt);
+        out[5] = route<Q>(v_dgw, gk, y_gk, dp, area, dt);
 #pragma unroll
         for (int i = 0; i < 6; ++i)
-            v_ly[i] = l[i] / 1e3 * area; // :456-457
+            v_ly[i] = dv<Q>(l[i], 1e3, 1e-3) * area; // :456-457
 
         // river, structure.py:487-498; inflow summed left to right (:254)
         q_in = out[1] + out[2] + out[3] + out[4] + out[5];
         q_gw = out[4] + out[5];
-        const double q = river(dt, q_in, rk, v_riv);
+        const double q = river_q<Q>(dt, q_in, rk, v_riv, y_rk, y_dt);
         out[6] = q;
         q_out = q;
         acc += q;
@@ -223,5 +314,8 @@ struct LiteralModel {
         den += q_in;
     }
 };
+
+using LiteralModel = LiteralModelT<false>;      // the literal kernel: true divisions, nothing to check
+using LiteralModelRecip = LiteralModelT<true>;  // the ill-conditioned rows of the fast mode
 
 } // namespace smart

@@ -143,7 +143,8 @@ def fmt_hist(h):
 
 def main():
     kernel, out = sys.argv[1], sys.argv[2]
-    lib = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'smartpy_amd', 'csrc', 'libsmart_amd.so')
+    rest = [x for x in sys.argv[3:] if not x.startswith('--')]
+    lib = rest[0] if rest else os.path.join(ROOT, 'smartpy_amd', 'csrc', 'libsmart_amd.so')
     start, symbol, body = disassemble(lib, kernel)
     insts = parse(start, body)
     blocks, loops, block_of = blocks_and_loops(insts)
@@ -159,7 +160,15 @@ def main():
     tails = {}
     for lp in loops:
         tails.setdefault(lp['tail'], []).append(lp)
+    # --hot: list only the loops that are mostly fp64 arithmetic (the time-loop bodies) in full; the rest of the kernel
+    # (set-up, hand-over, reports, the other variants' code) one line per block
+    hot = {lp['id'] for lp in loops if 60 <= lp['n_insts'] <= 2800 and lp['depth'] >= (2 if len(loops) > 20 else 1) and
+           lp['hist'].get('fp64', 0) + lp['hist'].get('valu', 0) >= 0.6 * lp['n_insts']} if '--hot' in sys.argv else None
     for b in blocks:
+        if hot is not None and not (set(b['loops']) & hot):
+            lines.append(';; (block B%d at %#x, %d instructions, not in a hot loop: %s)' % (
+                b['id'], insts[b['lo']]['addr'], b['hi'] - b['lo'], fmt_hist(b['hist'])))
+            continue
         if b['loops']:
             lines.append(';; ---- block B%d [loops %s] %s' % (b['id'], ','.join('L%d' % k for k in b['loops']),
                                                               fmt_hist(b['hist'])))
@@ -178,14 +187,16 @@ def main():
         fh.write('\n'.join(lines) + '\n')
     with open(out + '.json', 'w') as fh:
         json.dump({'kernel': symbol, 'n_insts': len(insts),
-                   'blocks': [{k: b[k] for k in ('id', 'loops', 'hist', 'ops')} | {
+                   'blocks': [{k: b[k] for k in ('id', 'loops', 'hist')} | {
                        'addr': insts[b['lo']]['addr'], 'n': b['hi'] - b['lo'],
                        'ends_with': insts[b['hi'] - 1]['op'],
                        'target': insts[b['hi'] - 1]['target']} for b in blocks],
                    'loops': [{k: lp[k] for k in ('id', 'depth', 'n_insts', 'hist')} | {
                        'head_addr': insts[lp['head']]['addr'], 'tail_addr': insts[lp['tail']]['addr']} for lp in loops]},
                   fh, indent=1)
-    print('\n'.join(lines[:3 + len(loops) + 1]))
+    print('\n'.join(lines[:2]))
+    for lp in sorted(loops, key=lambda l: -l['hist'].get('fp64', 0))[:6]:
+        print('  L%d depth %d, %d instructions: %s' % (lp['id'], lp['depth'], lp['n_insts'], fmt_hist(lp['hist'])))
 
 
 if __name__ == '__main__':

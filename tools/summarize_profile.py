@@ -71,6 +71,11 @@ if trace:
     with open(trace[0]) as f:
         rows = [r for r in csv.DictReader(f) if is_main(r['Kernel_Name'])]
     if rows:
+        # the dominant kernel of the call: of the time-loop kernels, the one with the largest total time (a daily
+        # ensemble runs three side by side: their dispatches must not be averaged together)
+        top = dominant_first(sorted({r['Kernel_Name'].split('(')[0] for r in rows}))[0]
+        rows = [r for r in rows if r['Kernel_Name'].split('(')[0] == top]
+        out['dominant_kernel'] = top
         gmax = max(int(r['Grid_Size_X']) for r in rows)
         rows.sort(key=lambda r: int(r['Start_Timestamp']))
         every = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows if int(r['Grid_Size_X']) == gmax]
@@ -78,7 +83,7 @@ if trace:
         out['full_size_dispatch_ms'] = {'n': len(full), 'avg': sum(full) / len(full), 'min': min(full), 'max': max(full),
                                         'grid_x': gmax, 'warmup_dispatches_dropped': len(every) - len(full),
                                         'warmup_ms': every[:len(every) - len(full)]}
-        lines += ['## full-size dispatches of the dominant kernel (grid %d threads; `bench.py %s`)' % (gmax, out.get('bench_args', '')),
+        lines += ['## full-size dispatches of the dominant kernel `%s` (grid %d threads; `%s`)' % (top, gmax, out.get('bench_args', '')),
                   '', '- the %d timed steps: avg = %.4f ms, min = %.4f ms, max = %.4f ms' % (len(full), sum(full) / len(full), min(full), max(full)),
                   '- the %d warm-up launches before them (clock still ramping): %s ms' % (
                       len(every) - len(full), ', '.join('%.3f' % v for v in every[:len(every) - len(full)])), '']
