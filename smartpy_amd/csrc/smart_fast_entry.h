@@ -18,7 +18,8 @@
 //   smart_fast_plain             class 0, raw reports or gap 1                                   step loop
 //   smart_fast_stiff             class 1: some k * 3600 < dt (clamps, 95 % rule reachable)        step loop, STIFF
 //   smart_fast_guard             class 2: S outside [0, 0.5], C < 0 or Z <= 0                     step loop, GUARD
-//   smart_fast_illcond           class 3: dt / (RK * 3600) > 2 (the river only)                   literal model
+//   smart_fast_illcond           class 3: dt / (RK * 3600) > 2 (the river only)                   literal model, divisions
+//                                                                                                 through cached reciprocals
 #pragma once
 
 #include "smart_fast_model.h"

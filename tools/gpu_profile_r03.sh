@@ -21,6 +21,7 @@ bash tools/profile_cmd.sh r03_runs_of_6 tools/debug/runs_only.py 100000 12
   echo "== -DSMART_WET_ASM=0 (hipcc's wet-interval loop) against the shipped library"
   python tools/debug/steps_bits.py compare /tmp/b_wet0.npz /tmp/b_new.npz ) > gpurun_out/r03_steps_bits.txt 2>&1
 tail -6 gpurun_out/r03_steps_bits.txt
+python tools/debug/recip_bits.py > gpurun_out/r03_recip_bits.txt 2>&1; tail -2 gpurun_out/r03_recip_bits.txt
 bash tools/gpu_configs.sh r03 > gpurun_out/configs_r03.log 2>&1; tail -30 gpurun_out/configs_r03.log
 timeout 1500 bash tools/gpu_soak.sh > gpurun_out/r03_time_slice_soak.txt 2>&1; tail -5 gpurun_out/r03_time_slice_soak.txt
 du -sh gpurun_out
