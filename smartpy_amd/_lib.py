@@ -81,6 +81,13 @@ def lib():
             raise ImportError(
                 "smartpy_amd: the HIP extension %s has not been built.  Run `python -m smartpy_amd.build` "
                 "(needs hipcc; cross-compiles for gfx950 without a GPU).  There is no CPU fallback." % LIB_PATH)
+        # torch first: its wheel brings a HIP runtime of its own, and the one that is loaded first is the one that
+        # owns the device.  Loaded the other way round (this library, then torch: __graft_entry__.build() followed by
+        # smoke() in ONE process did that) the library's own runtime reports "no ROCm-capable device".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)       # AttributeError here = the header and the library disagree
