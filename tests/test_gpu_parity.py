@@ -995,7 +995,7 @@ def run_interval_cases(eng, setenv, seed, n_cases):
     worst = 0.0
     for case in range(n_cases):
         dt = float(rng.choice([900.0, 3600.0, 10800.0]))
-        gap = int(rng.choice([2, 3, 8, 24, 48]))
+        gap = int(rng.choice([2, 3, 4, 8, 12, 24, 48]))    # (4, 12: whole chunks of four steps, but an odd number of them)
         n_rep = int(rng.integers(64, 200))
         T = n_rep * gap
         W = int(rng.integers(0, n_rep // 2 + 1)) * gap if rng.random() < 0.7 else 0
