@@ -467,14 +467,17 @@ static KArgs kernel_args(const SmartEnsemble *e, const Workspace &w)
     a.seg_blocks = a.n_blocks * a.n_catch;
     a.hdr = w.hdr;
     a.fflags = nullptr;
-    // the run lengths the forcing is tested for: divisors of the report gap, largest first, down to 2
-    if (a.report_type == SMART_REPORT_SUMMARY && a.gap >= 2 && a.gap <= 0x7fffffff)
-        for (long d = a.gap; d >= 2 && a.n_div < kMaxDiv; --d)
-            if (a.gap % d == 0) {
-                a.div[a.n_div++] = (int)d;
-                if (d > 4096 && a.n_div >= 2)
-                    d = d / 2 + 1; // (a gap in the thousands: no need to walk every candidate down from gap / 2)
-            }
+    // the run lengths the forcing is tested for: the kMaxDiv largest divisors of the report gap, largest first, down
+    // to 2 -- gap / q for q = 1, 2, 3, ... (at most sqrt(gap) trial divisions, whatever the gap)
+    if (a.report_type == SMART_REPORT_SUMMARY && a.gap >= 2 && a.gap <= 0x7fffffff) {
+        for (long q = 1; q * q <= a.gap && a.n_div < kMaxDiv; ++q)
+            if (a.gap % q == 0 && a.gap / q >= 2)
+                a.div[a.n_div++] = (int)(a.gap / q);
+        // ... and, if there is room left, the small ones q itself (below sqrt(gap)), largest first
+        for (long q = (long)std::sqrt((double)a.gap) + 1; q >= 2 && a.n_div < kMaxDiv; --q)
+            if (q * q < a.gap && a.gap % q == 0 && q < a.div[a.n_div - 1])
+                a.div[a.n_div++] = (int)q;
+    }
     return a;
 }
 
