@@ -6,6 +6,8 @@ Gates
                  fp64 bit patterns; and within 1e-11 of the reference-exact oracle / the reference's own values.
   fast mode    : relative difference <= 1e-9 on discharge (contract of BASELINE.json: 1e-6), 1e-10 on gw.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1105,6 +1107,44 @@ def test_run_length_interval_engine(eng, example, monkeypatch, run_len, shift):
     # time slices change nothing, and asking for the final row does not change the discharge
     assert bits_equal(results[0][1], results[1][1]) and bits_equal(results[2][1], results[3][1])
     assert bits_equal(results[0][1], results[2][1]) and bits_equal(results[0][2], results[1][2])
+
+
+def test_asm_loops_are_bit_identical_to_the_compiled_ones(tmp_path):
+    """The step loop (three asm arms threaded through chunks of four steps) and the wet interval of the interval / run
+    engine (an asm loop) perform the operations of the C++ they replace in the same order: every output bit is the
+    same.  Built here, on the box, next to the shipped library: the same sources with -DSMART_STEP_ARMS=0
+    -DSMART_WET_ASM=0 (FastModel::step_lazy and hipcc's own wet-interval loop, round 2's kernels) -- then discharge,
+    groundwater ratio, objective functions and final rows of some thirty seeded set-ups (the bench's sub-daily
+    forcing, random gaps 2 ... 48 with storms, droughts, exact zeros, -0.0 rain, negative evaporation, layers above
+    capacity; piecewise-constant and 6- / 3-hourly forcing; whole and time-sliced; with and without the final row)
+    from both libraries, in processes of their own.  profiles/r03_steps_bits.txt is the full list's result."""
+    import subprocess
+    import sys
+    from smartpy_amd import build as hip_build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = str(tmp_path / 'libsmart_amd_compiled_loops.so')
+    hip_build.build(force=True, extra_flags=['-DSMART_STEP_ARMS=0', '-DSMART_WET_ASM=0'], lib_path=variant)
+    try:
+        tool = os.path.join(root, 'tools', 'debug', 'steps_bits.py')
+        env = dict(os.environ, STEPS_BITS_QUICK='1')
+        env.pop('SMART_AMD_LIB', None)
+        subprocess.check_call([sys.executable, tool, 'dump', str(tmp_path / 'shipped.npz')], cwd=root, env=env,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+        subprocess.check_call([sys.executable, tool, 'dump', str(tmp_path / 'compiled.npz')], cwd=root,
+                              env=dict(env, SMART_AMD_LIB=variant), stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL, timeout=900)
+    finally:
+        for name in os.listdir(hip_build.CSRC):        # the variant's object files sit next to the sources
+            if name.endswith('.libsmart_amd_compiled_loops.so.o'):
+                os.remove(os.path.join(hip_build.CSRC, name))
+    a, b = np.load(tmp_path / 'shipped.npz'), np.load(tmp_path / 'compiled.npz')
+    arrays = [k for k in a.files if not k.endswith('/kernel')]
+    assert len(arrays) >= 60 and sorted(a.files) == sorted(b.files)
+    kernels = ' '.join(str(a[k]) for k in a.files if k.endswith('/kernel'))
+    assert all(name in kernels for name in ('smart_fast_steps', 'smart_fast_steps_states', 'smart_fast_intervals',
+                                            'smart_fast_runs'))
+    for k in arrays:
+        assert bits_equal(a[k], b[k]), k
 
 
 def test_launch_captures_into_a_hip_graph(eng, example):

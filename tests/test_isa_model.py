@@ -1,0 +1,57 @@
+"""The instruction accounting behind roofline.frac / useful_frac, checked against the tree: the compiler's own assembly of
+the hot loops (tools/isa_model.py: hipcc -S of the kernel sources, cross-compiled, no GPU) must say what DESIGN.md and
+smart_fast_arms.h say -- and must agree with the vector-instruction counts the PMC passes measured on the GPU for the
+same workload and the same kernel sources (profiles/traffic_latest.json)."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason='needs hipcc (cross-compiles without a GPU)')
+
+
+def run_model(which, tmp_path):
+    out = str(tmp_path / which)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'isa_model.py'), which, out], cwd=ROOT,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500)
+    return json.load(open(out + '.json'))
+
+
+def measured(workload):
+    sys.path.insert(0, ROOT)
+    import bench
+    entry, note = bench.pmc_summary(workload)
+    return entry, note
+
+
+def test_the_headline_wet_step_is_73_fp64_instructions_and_the_count_matches_the_pmc(tmp_path):
+    m = run_model('intervals', tmp_path)
+    step = m['wet_step']
+    assert step['fp64'] == 73 and step['VALU'] == 73 and step.get('scalar', 0) == 0      # nothing but arithmetic
+    assert 0.90 <= m['fp64_share_of_valu'] <= 1.0
+    entry, note = measured('config3:runs_per_gpu=100000:discharge=1:math=fast')
+    if not entry:
+        pytest.skip('no PMC summary for the current kernel sources: ' + note)
+    per_wave_step = entry['valu_insts_per_launch'] / m['wave_steps']
+    # the model's figure is an upper bound (both sides of hipcc's wet / dry branch around the asm are counted for
+    # every interval), the wet steps alone a lower one: the measured count lies between them
+    assert m['fp64_in_wet_steps_per_wave_step'] <= per_wave_step <= m['valu_per_wave_step_upper'] * 1.01, \
+        (m['fp64_in_wet_steps_per_wave_step'], per_wave_step, m['valu_per_wave_step_upper'])
+
+
+def test_the_arms_of_the_step_loop_have_the_documented_sizes(tmp_path):
+    m = run_model('steps', tmp_path)
+    arms = m['arms']
+    for j in range(4):
+        assert arms['dry%d' % j]['VALU'] == 9 and arms['dry%d' % j]['fp64'] == 9
+        assert arms['calm%d' % j]['VALU'] == 51 and arms['calm%d' % j]['fp64'] == 50
+        assert arms['rain%d' % j]['VALU'] == 83 and arms['rain%d' % j]['fp64'] == 77
+    lo, hi = m['per_wave_step_low']['VALU'], m['per_wave_step_high']['VALU']
+    assert 36.0 < lo < hi < 39.0                                     # 37.5 measured
+    assert m['glue_two_chunks']['scalar'] <= 12                      # hipcc's loop around two chunks of four steps

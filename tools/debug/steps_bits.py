@@ -71,6 +71,8 @@ def cases():
         out.append(dict(name='rnd%02d_gap%d' % (case, gap), forcing=np.stack([rain, peva], axis=1), params=params,
                         dt=dt, W=W, gap=gap, slices=str(rng.choice(['', '0', '3', '9'])),
                         final=bool(rng.random() < 0.5), initial=initial))
+    if os.environ.get('STEPS_BITS_QUICK'):     # the test suite's share: every kind of set-up, the lighter ones
+        out = [c for c in out if c['params'].shape[0] <= 400 and c['forcing'].shape[0] <= 12000]
     return out
 
 
