@@ -529,14 +529,14 @@ static int decide(const SmartEnsemble *e, const DeviceCtx *d, const Workspace &w
     // a workspace without room for it means a plain launch
     if (x.n_seg > 1 && (!w.slices || w.slice_room < slice_bytes(e->n_samples, e->n_catchments)))
         x.n_seg = 1;
-    // early exits in the interval engine pay off once a SIMD holds three waves to issue from (FastModel::kExits;
-    // measured with the per-variant kernels, tools/ab_exits.sh: off wins by 5 % at 1.53 blocks per SIMD and by 4 % at
-    // 1.9, on wins by 6 % at 2.4 and by 7 % at 3.1 and above)
-    // With rows ordered so that a wavefront's 64 samples behave alike (SMART_PLAN_ROWS_ORDERED) the exits trigger far
-    // more often: on from 1.7 blocks per SIMD (tools/debug/sort_rows.py: at 1.9, 12.8 ms with exits against 13.1
-    // without; at 1.53, 11.15 against 10.95).
+    // Early exits inside every step of the interval engine (FastModel::kExits) cost a wavefront a taken branch where
+    // they trigger; the straight-line kernels run their wet intervals in two modes instead (SMART_WET_MODES: one
+    // taken branch per interval) and keep the asm loop.  The exits win once a SIMD holds three waves whose scalar
+    // work and branches hide behind each other's vector work -- by 1.5 to 2.5 % from 3 blocks per SIMD on (3.05,
+    // 4.6, 15: config 4 on one GPU, config 5), level at 2.44, and lose 6 % at 1.9 and 1.53; rows ordered or not
+    // (tools/gpu_r03_l.sh, gpu_r03_n.sh: profiles/r03_ab_exits_modes.txt).
     const char *env = getenv("SMART_EXITS");
-    x.exits = env ? atoi(env) != 0 : x.load > ((e->plan & SMART_PLAN_ROWS_ORDERED) ? 1.7 : 2.0);
+    x.exits = env ? atoi(env) != 0 : x.load > 2.5;
     x.class_mask = plan & 0xf;
     if (plan & SMART_PLAN_CLASS_REGULAR) {
         if (x.intervals) {

@@ -833,10 +833,11 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
     // evaporation, the night block of sub-daily data -- the filling.  For forcing without negative or non-finite values
     // and waves with no layer above capacity (`quick`, as in the step loop); the kernels whose wet interval is the
     // asm loop.
-    bool quick = false;
+    bool quick = false, fits = false;
     if constexpr (piecewise && Model::kWetAsm) {
         m.note_capacity();
-        quick = m.over_mask == 0 && !(fflags & kForcingInsane);
+        fits = m.over_mask == 0; // for good: only a caller's initial state puts a layer above its capacity (no GUARD here)
+        quick = fits && !(fflags & kForcingInsane);
     }
     auto interval = [&](const double2 v, double &acc, double &num, double &den) {
         if constexpr (piecewise && Model::kWetAsm) {
@@ -863,7 +864,10 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
             if (m.pend > 0.0)
                 m.flush_pending();
 #endif
-            m.wet_interval(ex, run_len, acc, num, den);
+            if constexpr (piecewise && Model::kWetAsm)
+                m.wet_interval(ex, run_len, acc, num, den, fits);
+            else
+                m.wet_interval(ex, run_len, acc, num, den);
         }
     };
 

@@ -8,7 +8,9 @@
 //                               `pend`, drain the reservoirs -- 9 vector instructions, no compare, no EXEC change;
 //   rain == 0, peva == 0  CALM  every lane is wet with zero excess: route, the three leak passes, reservoirs -- 51
 //                               instructions, no EXEC change, no filling;
-//   rain > 0              RAIN  the general step: excess per lane, wet lanes under EXEC, filling, leaks -- 84.
+//   rain > 0              RAIN  the general step: excess per lane, wet lanes under EXEC, filling, leaks -- 84, of
+//                               which 17 (the filling below the top layer) are skipped when the top layer takes the
+//                               excess of every wet lane (SMART_RAIN_FILL_EXIT: 59 % of the rainy steps).
 // The deferred evaporation cascade (FastModel::flush_pending) is due in the calm and the rain arm when a wet lane has
 // a demand pending -- read from `pend` itself (lanes with something pending are exactly the lanes with pend > 0; the
 // lane mask step_lazy() carries says the same, but an SGPR pair that lives across `asm` statements is taken for
@@ -90,7 +92,26 @@
             "v_mul_f64 %[xs], %[eh], %[tot]\n\t"                                                                       \
             "v_fma_f64 %[xf], -%[pd], %[t1], %[xf]\n\t"                                                                \
             "v_fma_f64 %[xs], %[pd], %[t1], %[xs]\n\t"
-#define SMART_A_FILL "v_mul_f64 %[eh], %[hz], %[ex]\n\t" SMART_A_FILL_REST
+#define SMART_A_FILL(drain) "v_mul_f64 %[eh], %[hz], %[ex]\n\t" SMART_A_FILL_REST drain
+// ... with a way out behind the top layer: when no lane has excess left there (59 % of the rainy steps of the
+// flat-forcing workload) the other five layers see  t = l + 0; l = min(t, z); t - l = 0  -- the identity as long as
+// no layer is above its capacity (QUICK waves only) -- and the saturation excess is zero (v_cmp_nle: a NaN goes on)
+#ifndef SMART_RAIN_FILL_EXIT
+#define SMART_RAIN_FILL_EXIT 1
+#endif
+#if SMART_RAIN_FILL_EXIT
+#define SMART_A_FILL_QUICK(drain)                                                                                      \
+    "v_mul_f64 %[eh], %[hz], %[ex]\n\t"                                                                                \
+    "v_fma_f64 %[xf], -%[eh], %[tot], %[ex]\n\t" SMART_A_FILL1("l0", "xf") "v_mul_f64 %[xs], %[eh], %[tot]\n\t"        \
+                                                                           "v_cmp_nle_f64 vcc, %[t1], 0\n\t"           \
+                                                                           "s_cbranch_vccz 6f\n\t" SMART_A_FILL1(      \
+                                                                               "l1", "t1") SMART_A_FILL1("l2", "t1")   \
+        SMART_A_FILL1("l3", "t1") SMART_A_FILL1("l4", "t1") SMART_A_FILL1("l5", "t1")                                  \
+            "v_fma_f64 %[xf], -%[pd], %[t1], %[xf]\n\t"                                                                \
+            "v_fma_f64 %[xs], %[pd], %[t1], %[xs]\n\t" drain "6:\n\t"
+#else
+#define SMART_A_FILL_QUICK(drain) SMART_A_FILL(drain)
+#endif
 // s', s'^2 and s'^3 live in the registers of three temporaries that are dead by the time the leaks start (the excess,
 // e_h and the routing / cascade temporary): 6 VGPRs less
 #define SMART_S1 "ex"
@@ -104,23 +125,23 @@
     "v_add_f64 %[t1], %[l5], %[l4]\n\t"                                                                                \
     "v_add_f64 %[" dst "], %[t1], %[" dst "]\n\t"
 // the three leak passes (structure.py:381-399); `deep`: the SPLIT models' sum of what the third pass takes
-#define SMART_A_LEAKS_(S1, P2, P3, deep)                                                                                            \
-    "v_mul_f64 %[" S1 "], %[sz], %[tot]\n\t"                                                                     \
-    "v_mul_f64 %[" P2 "], %[" S1 "], %[" S1 "]\n\t"                                                  \
-    "v_mul_f64 %[" P3 "], %[" S1 "], %[" P2 "]\n\t"                                                  \
-    "v_mul_f64 %[p4], %[" P2 "], %[" P2 "]\n\t"                                                            \
-    "v_mul_f64 %[p5], %[" S1 "], %[p4]\n\t"                                                                      \
-    "v_mul_f64 %[p6], %[" P3 "], %[" P3 "]\n\t" SMART_A_LEAK("l0", S1) SMART_A_LEAK("l1", P2)  \
-        SMART_A_LEAK("l2", P3) SMART_A_LEAK("l3", "p4") SMART_A_LEAK("l4", "p5") SMART_A_LEAK("l5", "p6")        \
-            SMART_A_LSUM("ai") SMART_A_LEAK("l0", S1) "v_mul_f64 %[t1], %[" S1 "], -0.5\n\t"               \
+#define SMART_A_LEAKS_(S1, P2, P3, deep)                                                                               \
+    "v_mul_f64 %[" S1 "], %[sz], %[tot]\n\t"                                                                           \
+    "v_mul_f64 %[" P2 "], %[" S1 "], %[" S1 "]\n\t"                                                                    \
+    "v_mul_f64 %[" P3 "], %[" S1 "], %[" P2 "]\n\t"                                                                    \
+    "v_mul_f64 %[p4], %[" P2 "], %[" P2 "]\n\t"                                                                        \
+    "v_mul_f64 %[p5], %[" S1 "], %[p4]\n\t"                                                                            \
+    "v_mul_f64 %[p6], %[" P3 "], %[" P3 "]\n\t" SMART_A_LEAK("l0", S1) SMART_A_LEAK("l1", P2)                          \
+        SMART_A_LEAK("l2", P3) SMART_A_LEAK("l3", "p4") SMART_A_LEAK("l4", "p5") SMART_A_LEAK("l5", "p6")              \
+            SMART_A_LSUM("ai") SMART_A_LEAK("l0", S1) "v_mul_f64 %[t1], %[" S1 "], -0.5\n\t"                           \
                                                             "v_fma_f64 %[l1], %[l1], %[t1], %[l1]\n\t"                 \
-                                                            "v_mul_f64 %[t1], %[" S1 "], %[k3]\n\t"              \
+                                                            "v_mul_f64 %[t1], %[" S1 "], %[k3]\n\t"                    \
                                                             "v_fma_f64 %[l2], %[l2], %[t1], %[l2]\n\t"                 \
-                                                            "v_ldexp_f64 %[t1], -%[" S1 "], -2\n\t"              \
+                                                            "v_ldexp_f64 %[t1], -%[" S1 "], -2\n\t"                    \
                                                             "v_fma_f64 %[l3], %[l3], %[t1], %[l3]\n\t"                 \
-                                                            "v_mul_f64 %[t1], %[" S1 "], %[k5]\n\t"              \
+                                                            "v_mul_f64 %[t1], %[" S1 "], %[k5]\n\t"                    \
                                                             "v_fma_f64 %[l4], %[l4], %[t1], %[l4]\n\t"                 \
-                                                            "v_mul_f64 %[t1], %[" S1 "], %[k6]\n\t"              \
+                                                            "v_mul_f64 %[t1], %[" S1 "], %[k6]\n\t"                    \
                                                             "v_fma_f64 %[l5], %[l5], %[t1], %[l5]\n\t" deep            \
                 SMART_A_LEAK("l0", "p6") SMART_A_LEAK("l1", "p5") SMART_A_LEAK("l2", "p4")                             \
                     SMART_A_LEAK("l3", P3) SMART_A_LEAK("l4", P2) SMART_A_LEAK("l5", S1)
@@ -153,7 +174,7 @@
 #define SMART_A_CALM_SPLIT                                                                                             \
     "v_fma_f64 %[yd], %[yd], %[ds], 0\n\t"                                                                             \
     "v_fma_f64 %[ydg], %[ydg], %[dg], %[dp]\n\t"
-#define SMART_A_RAIN(rn, pe, casc, zeros, drain, deep, split)                                                          \
+#define SMART_A_RAIN(rn, pe, casc, zeros, fill, deep, split)                                                           \
     "v_mov_b64 %[t1], %[" pe "]\n\t"                                                                                   \
     "v_fma_f64 %[ex], %[" rn "], %[pt], -%[t1]\n\t"                                                                    \
     "v_cmp_le_f64 %[wm], 0, %[ex]\n\t"                                                                                 \
@@ -164,7 +185,7 @@
                                                         "v_mov_b64 %[xg], 0\n\t" zeros                                 \
                                                         "s_and_saveexec_b64 %[sv], %[wm]\n\t"                          \
                                                         "s_cbranch_execz 8f\n\t"                                       \
-                                                        "s_and_b64 %[tmp], %[tmp], %[wm]\n\t" casc SMART_A_FILL drain  \
+                                                        "s_and_b64 %[tmp], %[tmp], %[wm]\n\t" casc fill                \
         SMART_A_LEAKS(deep) "v_add_f64 %[t1], %[tot], -%[ai]\n\t"                                                      \
                             "v_add_f64 %[xf], %[xf], %[t1]\n\t" SMART_A_TOT_XG "8:\n\t"                                \
                             "s_or_b64 exec, exec, %[sv]\n\t"                                                           \
@@ -202,12 +223,13 @@
     "s_cbranch_scc0 5f\n\t"                                                                                            \
     "s_cmp_eq_u64 %[pe0], 0\n\t"                                                                                       \
     "s_cbranch_scc0 7f\n\t" SMART_A_CALM(SMART_A_CASC_CALM("9"), deep, calm_split) "s_branch 9f\n\t"                   \
-        SMART_A_CASC_CALM_OOL("9") "5:\n\t" SMART_A_RAIN("rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros, drain, deep,     \
-                                                         rain_split) "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL("9")      \
-                                   "7:\n\t" SMART_A_DRY("pe0", dry_split) "9:\n\t"
+        SMART_A_CASC_CALM_OOL("9") "5:\n\t" SMART_A_RAIN("rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros,                  \
+                                                         SMART_A_FILL_QUICK(drain), deep, rain_split)                  \
+            "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL("9")                                                               \
+            "7:\n\t" SMART_A_DRY("pe0", dry_split) "9:\n\t"
 // the rain arm alone (waves that may not take the shortcuts)
 #define SMART_A_STEP_RAIN(deep, zeros, drain, rain_split)                                                              \
-    SMART_A_RAIN("rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros, drain, deep, rain_split)                                 \
+    SMART_A_RAIN("rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros, SMART_A_FILL(drain), deep, rain_split)                   \
     "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL("9") "9:\n\t"
 
 // ---- a chunk of four steps, threaded ---------------------------------------------------------------------------
@@ -233,53 +255,107 @@
     "s_cbranch_scc1 10" j "b\n\t"
 #define SMART_A_CALM_J(j, deep, split) "10" j ":\n\t" SMART_A_CALM(SMART_A_CASC_CALM(j), deep, split)
 #define SMART_A_DRY_J(j, split) "11" j ":\n\t" SMART_A_DRY("pe" j, split)
-#define SMART_A_RAIN_J(j, zeros, drain, deep, split)                                                                   \
-    "12" j ":\n\t" SMART_A_RAIN("rn" j, "pe" j, SMART_A_CASC_RAIN(j), zeros, drain, deep, split)
+#define SMART_A_RAIN_J(j, zeros, fill, deep, split)                                                                    \
+    "12" j ":\n\t" SMART_A_RAIN("rn" j, "pe" j, SMART_A_CASC_RAIN(j), zeros, fill, deep, split)
 #define SMART_A_CHUNK(deep, calm_split, zeros, drain, rain_split, dry_split)                                           \
     SMART_A_NEXT_FROM_CALM("0") SMART_A_CALM_J("0", deep, calm_split) SMART_A_NEXT_FROM_CALM("1")                      \
     SMART_A_CALM_J("1", deep, calm_split) SMART_A_NEXT_FROM_CALM("2") SMART_A_CALM_J("2", deep, calm_split)            \
     SMART_A_NEXT_FROM_CALM("3") SMART_A_CALM_J("3", deep, calm_split) "s_branch 130f\n\t"                              \
     SMART_A_CASC_CALM_OOL("0") SMART_A_CASC_CALM_OOL("1") SMART_A_CASC_CALM_OOL("2") SMART_A_CASC_CALM_OOL("3")        \
-    SMART_A_RAIN_J("0", zeros, drain, deep, rain_split) SMART_A_NEXT_FROM_RAIN("1")                                    \
-    SMART_A_RAIN_J("1", zeros, drain, deep, rain_split) SMART_A_NEXT_FROM_RAIN("2")                                    \
-    SMART_A_RAIN_J("2", zeros, drain, deep, rain_split) SMART_A_NEXT_FROM_RAIN("3")                                    \
-    SMART_A_RAIN_J("3", zeros, drain, deep, rain_split) "s_branch 130f\n\t"                                            \
+    SMART_A_RAIN_J("0", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) SMART_A_NEXT_FROM_RAIN("1")                \
+    SMART_A_RAIN_J("1", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) SMART_A_NEXT_FROM_RAIN("2")                \
+    SMART_A_RAIN_J("2", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) SMART_A_NEXT_FROM_RAIN("3")                \
+    SMART_A_RAIN_J("3", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) "s_branch 130f\n\t"                        \
     SMART_A_CASC_RAIN_OOL("0") SMART_A_CASC_RAIN_OOL("1") SMART_A_CASC_RAIN_OOL("2") SMART_A_CASC_RAIN_OOL("3")        \
     SMART_A_DRY_J("0", dry_split) SMART_A_NEXT_FROM_DRY("1") SMART_A_DRY_J("1", dry_split) SMART_A_NEXT_FROM_DRY("2")  \
     SMART_A_DRY_J("2", dry_split) SMART_A_NEXT_FROM_DRY("3") SMART_A_DRY_J("3", dry_split) "130:\n\t"
 // not QUICK: the rain arm four times
 #define SMART_A_CHUNK_RAIN(deep, zeros, drain, rain_split)                                                             \
-    SMART_A_RAIN_J("0", zeros, drain, deep, rain_split) SMART_A_RAIN_J("1", zeros, drain, deep, rain_split)            \
-    SMART_A_RAIN_J("2", zeros, drain, deep, rain_split) SMART_A_RAIN_J("3", zeros, drain, deep, rain_split)            \
+    SMART_A_RAIN_J("0", zeros, SMART_A_FILL(drain), deep, rain_split)                                                  \
+    SMART_A_RAIN_J("1", zeros, SMART_A_FILL(drain), deep, rain_split)                                                  \
+    SMART_A_RAIN_J("2", zeros, SMART_A_FILL(drain), deep, rain_split)                                                  \
+    SMART_A_RAIN_J("3", zeros, SMART_A_FILL(drain), deep, rain_split)                                                  \
     "s_branch 130f\n\t" SMART_A_CASC_RAIN_OOL("0") SMART_A_CASC_RAIN_OOL("1") SMART_A_CASC_RAIN_OOL("2")               \
     SMART_A_CASC_RAIN_OOL("3") "130:\n\t"
 
 // ---- the wet interval of the interval engine (FastModel::wet_interval, merged regular variant, no exits) ----------
-// `n` wet steps with one excess, two per turn of the loop: 73 vector instructions a step (5 routing, 22 filling, 34
-// for the three leak passes with their powers, 8 for the layer sum / the balances, 4 reservoirs) and 1.5 scalar ones.
+// `n` wet steps with one excess: 73 vector instructions a step (5 routing, 22 filling, 34 for the three leak passes
+// with their powers, 8 for the layer sum / the balances, 4 reservoirs) and 2 scalar ones (counter, back-edge).
 // hipcc's own loop over the same arithmetic carries 5 to 8 more per step (a 64-bit counter, a constant rebuilt in
 // every turn, s_waitcnt's for loads that were long in) -- and a lone wavefront issues ONE instruction of any kind
 // per turn of its SIMD.  s', s'^2, s'^3 in registers of their own here: `ex` and `eh` live across the steps.
-#define SMART_A_WET_STEP                                                                                               \
-    SMART_A_ROUTE SMART_A_FILL_REST SMART_A_LEAKS_("s1", "p2", "p3", "") "v_add_f64 %[t1], %[tot], -%[ai]\n\t"         \
-                                                                         "v_add_f64 %[xf], %[xf], %[t1]\n\t"           \
-        SMART_A_TOT_XG "v_fma_f64 %[ys], %[ys], %[ds], %[xs]\n\t"                                                      \
-                       "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                                      \
-                       "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                                      \
-                       "v_add_f64 %[xgs], %[xgs], %[xg]\n\t"
+#define SMART_A_WET_HEAD SMART_A_ROUTE "v_fma_f64 %[xf], -%[eh], %[tot], %[ex]\n\t" SMART_A_FILL1("l0", "xf")
+#define SMART_A_WET_FILL_TAIL                                                                                          \
+    SMART_A_FILL1("l1", "t1") SMART_A_FILL1("l2", "t1") SMART_A_FILL1("l3", "t1") SMART_A_FILL1("l4", "t1")            \
+        SMART_A_FILL1("l5", "t1") "v_mul_f64 %[xs], %[eh], %[tot]\n\t"                                                 \
+                                  "v_fma_f64 %[xf], -%[pd], %[t1], %[xf]\n\t"                                          \
+                                  "v_fma_f64 %[xs], %[pd], %[t1], %[xs]\n\t"
+#define SMART_A_WET_REST                                                                                               \
+    SMART_A_LEAKS_("s1", "p2", "p3", "") "v_add_f64 %[t1], %[tot], -%[ai]\n\t"                                         \
+                                         "v_add_f64 %[xf], %[xf], %[t1]\n\t" SMART_A_TOT_XG                            \
+                                         "v_fma_f64 %[ys], %[ys], %[ds], %[xs]\n\t"                                    \
+                                         "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                    \
+                                         "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                    \
+                                         "v_add_f64 %[xgs], %[xgs], %[xg]\n\t"
+#define SMART_A_WET_STEP SMART_A_WET_HEAD SMART_A_WET_FILL_TAIL SMART_A_WET_REST
+// SMART_WET_MODES 0: every step fills all six layers (round 3's first form, kept for the A/B).
+// 1 / 2: two loops.  While the rain excess of every lane fits into the TOP layer -- 39 % of the wet wave-steps of the
+// headline workload, 58 % of those of 6-hourly forcing, and within an interval a prefix of its steps: the top layer
+// fills up, it does not empty under rain -- the other five layers see  t = l + 0; l = min(t, z); t - l = 0,  the
+// identity as long as no layer is above its capacity (`ok`, wave-uniform, known at the start of the launch: nothing
+// but a caller's initial state puts a layer there), and the saturation excess is zero: 15 instructions for a compare
+// and a branch that is NOT taken.  The first step that leaves something over in any lane (or meets a NaN: v_cmp_nle)
+// jumps into the middle of the loop of full steps and the interval ends there: one taken branch per interval, where
+// an exit inside every step (the kernels with exits, FastModel::kExits) costs a lone wavefront one per step.
+// Bit-identical to mode 0 (tools/debug/steps_bits.py).  2: both loops unrolled twice.
+#ifndef SMART_WET_MODES
+#define SMART_WET_MODES 1
+#endif
+#define SMART_A_WET_ABSORBED(fix)                                                                                      \
+    SMART_A_WET_HEAD "v_cmp_nle_f64 vcc, %[t1], 0\n\t"                                                                 \
+                     "s_cbranch_vccnz " fix "f\n\t"                                                                    \
+                     "v_mul_f64 %[xs], %[eh], %[tot]\n\t" SMART_A_WET_REST
+#define SMART_A_WET_FULL(fix) SMART_A_WET_HEAD fix ":\n\t" SMART_A_WET_FILL_TAIL SMART_A_WET_REST
+#if SMART_WET_MODES == 0
 #define SMART_A_WET_INTERVAL                                                                                           \
     "s_add_i32 %[cnt], %[n], 1\n\t"                                                                                    \
     "s_lshr_b32 %[cnt], %[cnt], 1\n\t"                                                                                 \
     "s_bitcmp1_b32 %[n], 0\n\t"                                                                                        \
     "s_cbranch_scc1 6f\n\t"                                                                                            \
-    "5:\n\t" SMART_A_WET_STEP "6:\n\t" SMART_A_WET_STEP "s_add_i32 %[cnt], %[cnt], -1\n\t"                            \
+    "5:\n\t" SMART_A_WET_STEP "6:\n\t" SMART_A_WET_STEP "s_add_i32 %[cnt], %[cnt], -1\n\t"                             \
     "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                       \
     "s_cbranch_scc1 5b\n\t"
-// ... and the calm interval: `n` wet steps with ZERO excess (no rain, no evaporation: the night block of sub-daily data)
-// need no filling -- with no layer above capacity it is the identity, as in the calm arm of the step loop: 51
+#elif SMART_WET_MODES == 1
+// cnt counts up from -n: s_add_u32 carries out (SCC) when it reaches zero
+#define SMART_A_WET_INTERVAL                                                                                           \
+    "s_sub_u32 %[cnt], 0, %[n]\n\t"                                                                                    \
+    "s_cmp_eq_u32 %[ok], 0\n\t"                                                                                        \
+    "s_cbranch_scc1 6f\n\t"                                                                                            \
+    "5:\n\t" SMART_A_WET_ABSORBED("7") "s_add_u32 %[cnt], %[cnt], 1\n\t"                                               \
+    "s_cbranch_scc0 5b\n\t"                                                                                            \
+    "s_branch 9f\n\t"                                                                                                  \
+    "6:\n\t" SMART_A_WET_FULL("7") "s_add_u32 %[cnt], %[cnt], 1\n\t"                                                   \
+    "s_cbranch_scc0 6b\n\t"                                                                                            \
+    "9:\n\t"
+#else
+#define SMART_A_WET_INTERVAL                                                                                           \
+    "s_sub_u32 %[cnt], 0, %[n]\n\t"                                                                                    \
+    "s_cmp_eq_u32 %[ok], 0\n\t"                                                                                        \
+    "s_cbranch_scc1 6f\n\t"                                                                                            \
+    "5:\n\t" SMART_A_WET_ABSORBED("7") "s_add_u32 %[cnt], %[cnt], 1\n\t"                                               \
+    "s_cbranch_scc1 9f\n\t" SMART_A_WET_ABSORBED("8") "s_add_u32 %[cnt], %[cnt], 1\n\t"                                \
+    "s_cbranch_scc0 5b\n\t"                                                                                            \
+    "s_branch 9f\n\t"                                                                                                  \
+    "6:\n\t" SMART_A_WET_FULL("7") "s_add_u32 %[cnt], %[cnt], 1\n\t"                                                   \
+    "s_cbranch_scc1 9f\n\t" SMART_A_WET_FULL("8") "s_add_u32 %[cnt], %[cnt], 1\n\t"                                    \
+    "s_cbranch_scc0 6b\n\t"                                                                                            \
+    "9:\n\t"
+#endif
+// ... and the calm interval: `n` wet steps with ZERO excess (no rain, no evaporation: the night block of sub-daily
+// data) need no filling -- with no layer above capacity it is the identity, as in the calm arm of the step loop: 51
 // instructions a step instead of 73.
 #define SMART_A_CALM_STEP                                                                                              \
-    SMART_A_ROUTE SMART_A_LEAKS_("s1", "p2", "p3", "") "v_add_f64 %[xf], %[tot], -%[ai]\n\t" SMART_A_TOT_XG             \
+    SMART_A_ROUTE SMART_A_LEAKS_("s1", "p2", "p3", "") "v_add_f64 %[xf], %[tot], -%[ai]\n\t" SMART_A_TOT_XG            \
     "v_fma_f64 %[ys], %[ys], %[ds], 0\n\t"                                                                             \
     "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                                                         \
     "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                                                         \
@@ -289,6 +365,6 @@
     "s_lshr_b32 %[cnt], %[cnt], 1\n\t"                                                                                 \
     "s_bitcmp1_b32 %[n], 0\n\t"                                                                                        \
     "s_cbranch_scc1 6f\n\t"                                                                                            \
-    "5:\n\t" SMART_A_CALM_STEP "6:\n\t" SMART_A_CALM_STEP "s_add_i32 %[cnt], %[cnt], -1\n\t"                          \
+    "5:\n\t" SMART_A_CALM_STEP "6:\n\t" SMART_A_CALM_STEP "s_add_i32 %[cnt], %[cnt], -1\n\t"                           \
     "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                       \
     "s_cbranch_scc1 5b\n\t"

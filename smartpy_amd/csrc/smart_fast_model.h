@@ -498,7 +498,9 @@ struct FastModel {
     }
 
     // `n` wet steps with the same rain excess: the layer sum is handed from step to step
-    __device__ __forceinline__ void wet_interval(double ex, long n, double &acc, double &num, double &den)
+    // `fits`: no layer of this wavefront is above its capacity (wave-uniform; SMART_WET_MODES in smart_fast_arms.h)
+    __device__ __forceinline__ void wet_interval(double ex, long n, double &acc, double &num, double &den,
+                                                 const bool fits = false)
     {
         if constexpr (kWetAsm) {
             // the whole interval as one asm loop (smart_fast_arms.h: SMART_A_WET_INTERVAL), the arithmetic of
@@ -516,8 +518,8 @@ struct FastModel {
                          : [cs] "v"(car_s), [cf] "v"(car_f), [cg] "v"(car_g), [oma] "v"(om_ar), [ds] "v"(dec_s),
                            [df] "v"(dec_f), [dg] "v"(dec_g), [sz] "v"(sz), [z] "v"(z), [pd] "v"(pD), [ex] "v"(ex),
                            [eh] "v"(e_h), [k3] "s"(-(1.0 / 3.0)), [k5] "s"(-0.2), [k6] "s"(-(1.0 / 6.0)),
-                           [n] "s"((int)n)
-                         : "scc");
+                           [n] "s"((int)n), [ok] "s"(__builtin_amdgcn_readfirstlane((int)fits))
+                         : "scc", "vcc");
         } else if (kLeakBalance) {
             const double e_h = ex * hz;
             double tot = layer_sum();

@@ -8,7 +8,7 @@ SQ_INSTS_SALU of profiles/r03_*.md).  Needs hipcc (cross-compiles without a GPU)
 
 The hot loops are `asm` statements (smartpy_amd/csrc/smart_fast_arms.h): in hipcc -S output they stand between
 ;;#ASMSTART / ;;#ASMEND with their local labels intact, so every arm is delimited by its label (100: calm, 110: dry,
-120: rain arm of step 0, ... 130: end of chunk; 5: / 6: the two copies of the wet step).  The classes are those of
+120: rain arm of step 0, ... 130: end of chunk; 5: / 6: the two loops of the wet interval).  The classes are those of
 tools/isa_report.py.  What is NOT in an asm (the glue hipcc writes around the chunks and the intervals) is counted
 from the enclosing loop of the same listing.
 """
@@ -87,6 +87,15 @@ def segments(body):
     return seg
 
 
+def fill_paths(workload):
+    """path frequencies of the filling cascade (tools/fill_paths.py: a numpy walk of the soil layers over the bench
+    workloads; depends on the workload only)"""
+    path = os.path.join(ROOT, 'profiles', 'r03_fill_paths.json')
+    if not os.path.exists(path):
+        raise SystemExit('run  python tools/fill_paths.py profiles/r03_fill_paths.json  first')
+    return json.load(open(path))[workload]
+
+
 def fmt(c):
     return 'VALU %3d (fp64 %3d, vcmp %d, vmov %d) scalar %2d (branch %d) smem %d' % (
         c['VALU'], c.get('fp64', 0), c.get('vcmp', 0), c.get('vmov', 0), c['scalar'], c.get('branch', 0), c.get('smem', 0))
@@ -148,6 +157,12 @@ def steps_model(out):
                 soil_ops += ops
     rain_soil = hist(soil_ops)
     report.append('- of a rain arm, the soil half under EXEC (skipped when no lane is wet): %s' % fmt(rain_soil))
+    # ... and of that half, the five lower layers of the filling cascade with the saturation excess (skipped by
+    # s_cbranch_vccz when the top layer takes the excess of every lane: SMART_RAIN_FILL_EXIT)
+    fill_tail = hist(soil_ops[soil_ops.index('s_cbranch_vccz') + 1:soil_ops.index('s_cbranch_vccz') + 18])
+    assert fill_tail['VALU'] == 17 and fill_tail['scalar'] == 0, fill_tail
+    report.append('- of that half, the filling below the top layer (skipped when the top layer takes every lane\'s '
+                  'excess): %s' % fmt(fill_tail))
     # glue: the ping-pong loop = the innermost compiler loop that holds two chunk asms
     a, bnd = chunk[0][0], chunk[1][1] if len(chunk) > 1 else chunk[0][1]
     head = max(i for i in range(a) if re.match(r'^\.LBB\d+_\d+:', lines[i]))
@@ -198,6 +213,10 @@ def steps_model(out):
     dry_rain = int((kind == 2).sum()) * n_waves - n_rain_soil
     for c in ('VALU', 'fp64', 'scalar', 'branch'):
         tot[c] -= rain_soil[c] * dry_rain
+    paths = fill_paths('flat_forcing')
+    n_absorbed = paths['absorbed_by_the_top_layer'] * n_rain_soil
+    for c in ('VALU', 'fp64'):
+        tot[c] -= fill_tail[c] * n_absorbed
     n_chunks = n_steps // 4
     for c in ('VALU', 'fp64', 'scalar', 'branch', 'smem'):
         tot[c] += top[c] * n_chunks * n_waves + glue[c] * (n_chunks // 2) * n_waves
@@ -208,8 +227,10 @@ def steps_model(out):
     lo = {c: (tot[c] + first[c] * n_casc) / ws for c in tot}
     report += ['## flat_forcing leg (1e5 LHS rows as drawn, %d wavefronts x %d steps)' % (n_waves, n_steps), '',
                '- steps: calm %.3f, dry %.3f, rain %.3f; rain steps whose wave has no wet lane: %.4f of all wave-steps; '
-               'cascades due: %.4f per wave-step' % ((kind == 0).mean(), (kind == 1).mean(), (kind == 2).mean(),
-                                                     dry_rain / ws, n_casc / ws),
+               'cascades due: %.4f per wave-step; rainy steps whose excess the top layer takes in every wet lane: %.3f of '
+               'the rainy steps with a wet lane (tools/fill_paths.py, %d rows)' % (
+                   (kind == 0).mean(), (kind == 1).mean(), (kind == 2).mean(), dry_rain / ws, n_casc / ws,
+                   paths['absorbed_by_the_top_layer'], paths['rows']),
                '- expected per wave-step, cascades ending behind the top layer .. walking all six layers:',
                '  - vector instructions %.2f .. %.2f (fp64 arithmetic %.2f .. %.2f)' % (lo['VALU'], hi['VALU'], lo['fp64'],
                                                                                      hi['fp64']),
@@ -217,7 +238,8 @@ def steps_model(out):
                    lo['scalar'], hi['scalar'], lo['branch'], hi['branch'], lo['smem']), '']
     result = {'kernel': 'smart_fast_steps', 'wave_steps': ws, 'per_wave_step_low': lo, 'per_wave_step_high': hi,
               'fp64_share_of_valu': [lo['fp64'] / lo['VALU'], hi['fp64'] / hi['VALU']],
-              'arms': {'%s%d' % k: dict(v) for k, v in per.items()}, 'cascade': dict(cascade), 'glue_two_chunks': dict(glue)}
+              'arms': {'%s%d' % k: dict(v) for k, v in per.items()}, 'cascade': dict(cascade), 'glue_two_chunks': dict(glue),
+              'fill_below_the_top_layer': dict(fill_tail), 'fill_absorbed_share': paths['absorbed_by_the_top_layer']}
     finish(out, report, result)
 
 
@@ -228,15 +250,27 @@ def intervals_model(out):
     from smartpy_amd.sampling import latin_hypercube
     lines = assembly('smart_fast_intervals.hip', 'smart_fast_intervals')
     blocks = asm_blocks(lines)
-    wet = [blk for blk in blocks if any(lab == '5' for lab, _ in blk[2]) and any(lab == '6' for lab, _ in blk[2])]
+    wet = [blk for blk in blocks if {'5', '6', '7', '9'} <= {lab for lab, _ in blk[2]}]
     assert wet, 'no wet-interval asm found'
     seg = segments(wet[0][2])
-    step = hist(seg['5'])
-    loop_tail = hist([op for op in seg['6'][len(seg['5']):]])
+    # 5: the loop of steps whose excess the top layer takes in every lane (ends with its counter, its back-edge and the
+    # jump over the other loop); 6: head of a full step, 7: where the first step that leaves something over joins
+    # it; 9: end
+    assert seg['5'][-3:] == ['s_add_u32', 's_cbranch_scc0', 's_branch'] and seg['7'][-2:] == ['s_add_u32', 's_cbranch_scc0']
+    absorbed = hist(seg['5'][:-3])
+    step = hist(seg['6'] + seg['7'][:-2])
+    loop_tail = hist(seg['7'][-2:])
     entry = hist(seg[''])
+    paths = fill_paths('headline')
+    share = paths['absorbed_prefix_of_the_run']
     report = ['# smart_fast_intervals: the wet interval (smart_fast_arms.h: SMART_A_WET_INTERVAL)', '',
-              '- one wet step: %s' % fmt(step), '- loop tail, once per TWO steps: %s' % fmt(loop_tail),
-              '- entry, once per wet interval: %s' % fmt(entry), '']
+              '- a full wet step: %s' % fmt(step),
+              '- a step whose excess the top layer takes in every lane: %s' % fmt(absorbed),
+              '- loop tail, once per step: %s' % fmt(loop_tail),
+              '- entry, once per wet interval: %s' % fmt(entry),
+              '- steps in the absorbed prefix of their interval: %.3f of the wet wave-steps; intervals that change '
+              'mode: %.2f of the wet ones (tools/fill_paths.py, %d rows)' % (share, paths['mode_switches_per_wet_run'],
+                                                                          paths['rows']), '']
     # per-interval glue: everything of the run loop (the compiler loop around the asm statements of the report
     # intervals) that is not inside an asm, per interval of the loop body (4 intervals per turn: kGroup)
     # -> counted from the listing between the first and the last wet asm of the group that emits with prefetched
@@ -271,19 +305,23 @@ def intervals_model(out):
     n_waves, n_iv = any_wet.shape
     ws = n_waves * n_iv * 24
     n_wet, n_dry = int(any_wet.sum()), int(any_dry.sum())
-    valu = n_wet * (24 * step['VALU'] + entry['VALU']) + n_waves * n_iv * per_iv['VALU']
-    fp64 = n_wet * 24 * step['fp64'] + n_waves * n_iv * per_iv.get('fp64', 0)
-    scal = n_wet * (12 * loop_tail['scalar'] + entry['scalar']) + n_waves * n_iv * per_iv['scalar']
+    mean = {c: share * absorbed[c] + (1 - share) * step[c] for c in ('VALU', 'fp64', 'scalar')}
+    # (the step that changes mode runs the absorbed head, its compare and the full rest: one instruction more)
+    valu = n_wet * (24 * mean['VALU'] + paths['mode_switches_per_wet_run'] + entry['VALU']) + n_waves * n_iv * per_iv['VALU']
+    fp64_wet = n_wet * 24 * mean['fp64']
+    fp64 = fp64_wet + n_waves * n_iv * per_iv.get('fp64', 0)
+    scal = n_wet * (24 * (loop_tail['scalar'] + mean['scalar']) + entry['scalar']) + n_waves * n_iv * per_iv['scalar']
     report += ['', '## headline run (1e5 LHS rows as drawn, %d wavefronts x %d intervals of 24 steps)' % (n_waves, n_iv), '',
                '- intervals with a wet lane in the wave: %.4f; with a dry lane: %.4f (both: %.4f)' % (
                    n_wet / (n_waves * n_iv), n_dry / (n_waves * n_iv), (any_wet & any_dry).mean()),
                '- expected per wave-step: vector instructions <= %.2f, of them fp64 arithmetic >= %.2f in the wet steps '
                'alone (%.3f of the vector instructions); scalar ALU + branches <= %.2f' % (
-                   valu / ws, n_wet * 24 * step['fp64'] / ws, n_wet * 24 * step['fp64'] / valu, scal / ws), '']
+                   valu / ws, fp64_wet / ws, fp64_wet / valu, scal / ws), '']
     result = {'kernel': 'smart_fast_intervals', 'wave_steps': ws, 'valu_per_wave_step_upper': valu / ws,
-              'fp64_in_wet_steps_per_wave_step': n_wet * 24 * step['fp64'] / ws, 'fp64_upper': fp64 / ws,
-              'fp64_share_of_valu': n_wet * 24 * step['fp64'] / valu, 'scalar_per_wave_step_upper': scal / ws,
-              'wet_step': dict(step), 'wet_interval_fraction': n_wet / (n_waves * n_iv)}
+              'fp64_in_wet_steps_per_wave_step': fp64_wet / ws, 'fp64_upper': fp64 / ws,
+              'fp64_share_of_valu': fp64_wet / valu, 'scalar_per_wave_step_upper': scal / ws,
+              'wet_step': dict(step), 'absorbed_step': dict(absorbed), 'absorbed_share': share,
+              'wet_interval_fraction': n_wet / (n_waves * n_iv)}
     finish(out, report, result)
 
 
