@@ -35,12 +35,18 @@ def dominant_first(kernels):
     return sorted(kernels, key=lambda k: -total.get(k, 0.0))
 
 
-def fp64_share(kernel):
+def fp64_share(kernel, measured_valu=None, workload=''):
+    """share of the vector instructions that are fp64 arithmetic: the model's figure (a lower bound: hipcc's code
+    around the asm loops is counted on both sides of its branches); for the workload the model describes (the headline
+    run) the fp64 instructions of the wet steps over the MEASURED vector instructions"""
     name = kernel.split('::')[-1]
     path = os.path.join(os.path.dirname(dst) or '.', 'r03_isa_model_%s.json' % name.replace('smart_fast_', ''))
     if not os.path.exists(path):
         return None
-    share = json.load(open(path)).get('fp64_share_of_valu')
+    model = json.load(open(path))
+    if measured_valu and workload.startswith('config3:runs_per_gpu=100000') and 'fp64_in_wet_steps_per_wave_step' in model:
+        return model['fp64_in_wet_steps_per_wave_step'] * model['wave_steps'] / measured_valu
+    share = model.get('fp64_share_of_valu')
     return min(share) if isinstance(share, list) else share
 
 
@@ -193,7 +199,7 @@ if workload and main and 'hbm_bytes_per_launch' in out:
         'avg_ms_kernel_trace': out.get('full_size_dispatch_ms', {}).get('avg'),
         # share of the vector instructions that are fp64 arithmetic (tools/isa_model.py: the compiler's assembly of the
         # hot loop weighed with this workload's path frequencies); null for kernels without a model
-        'fp64_share_of_valu': fp64_share(main[0]),
+        'fp64_share_of_valu': fp64_share(main[0], c.get('SQ_INSTS_VALU'), workload),
         'source': dst + '.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU / GRBM_GUI_ACTIVE (separate '
                   'passes, tools/profile.sh) on the bench command of this workload; FETCH_SIZE doubled per '
                   'MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B), an upper bound here since the reads '
