@@ -334,6 +334,7 @@ def main():
         traffic, insts = pmc.get('hbm_bytes_per_launch'), pmc.get('valu_insts_per_launch')
         held_clock, held_frac = pmc.get('held_clock_hz'), pmc.get('issue_frac_at_held_clock')
         fp64_share = pmc.get('fp64_share_of_valu')
+        flops = pmc.get('fp64_flops_per_launch')
         issue = None if insts is None else insts * VALU_ISSUE_CYCLES / (N_SIMD * kern_s * CLOCK_HZ)
         roofline = {
             'bound': 'valu-fp64-issue',
@@ -346,6 +347,12 @@ def main():
             # hot loop weighed with this workload's path frequencies (tools/isa_model.py, profiles/r03_isa_model_*.md)
             'useful_frac': None if issue is None or fp64_share is None else issue * fp64_share,
             'fp64_share_of_valu': fp64_share,
+            # the flops the kernel EXECUTES, counted (SQ_INSTS_VALU_{FMA x 2, ADD, MUL}_F64 x 64 lanes; min / max / ldexp
+            # and compares are in none of these counters), over this run's launch time, against the fp64 vector peak --
+            # which is all-FMA: a kernel that issued an add or a mul on every cycle would read 0.5
+            'executed_flops': None if flops is None else {
+                'per_launch': flops, 'per_sample_step': flops / units_per_launch, 'tflops': flops / kern_s / 1e12,
+                'peak_tflops': FP64_VALU_PEAK_TFLOPS, 'frac': flops / kern_s / 1e12 / FP64_VALU_PEAK_TFLOPS},
             'clock_basis_hz': CLOCK_HZ,
             # the same fraction over the shader cycles the chip actually ran (it lowers its clock under this load):
             # taken whole from the profiled runs (SQ_INSTS_VALU x 4 / (1,024 SIMDs x GRBM_GUI_ACTIVE / 8)), not mixed

@@ -8,10 +8,11 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 python3 -c "import bench; print(bench.kernel_source_hash())" > $OUT/source_hash.txt
 echo "$ARGS" > $OUT/args.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py $ARGS > $OUT/trace_bench.log 2>&1
-echo "trace rc=$?"
-for PASS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE"; do
+if [ -z "$ONLY" ]; then rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py $ARGS > $OUT/trace_bench.log 2>&1
+echo "trace rc=$?"; fi
+for PASS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64"; do
   NAME=$(echo $PASS | cut -d' ' -f1)
+  [ -n "$ONLY" ] && [ "$ONLY" != "$NAME" ] && continue
   rocprofv3 --pmc $PASS --kernel-trace --output-format csv -d $OUT/pmc_$NAME -o pmc -- python3 bench.py $ARGS > $OUT/pmc_${NAME}_bench.log 2>&1
   echo "pmc $NAME rc=$?"
 done

@@ -178,6 +178,32 @@ if main and clock:
             '%.3f' % rec['issue_frac_at_held_clock'] if 'issue_frac_at_held_clock' in rec else '-',
             '%.3f' % rec['salu_per_valu'] if 'salu_per_valu' in rec else '-'))
     out['held_clock_hz'] = out['per_kernel'][main[0]]['held_clock_hz']
+    # fp64 arithmetic by instruction class, COUNTED (SQ_INSTS_VALU_{FMA,ADD,MUL}_F64: wave-level instructions; v_min /
+    # v_max / v_ldexp / v_cmp on doubles are in none of them) -> the flops the kernel executes, 64 lanes per instruction
+    if any('SQ_INSTS_VALU_FMA_F64' in out['pmc'][k] for k in main):
+        lines += ['', '## fp64 arithmetic as the counters see it, per time-loop kernel and launch', '',
+                  '| kernel | FMA_F64 | ADD_F64 | MUL_F64 | TRANS_F64 | their share of SQ_INSTS_VALU | flops executed (2 FMA + ADD + MUL) x 64 | TFLOP/s at the clock held (of 78.6 x clock / 2.4 GHz) |',
+                  '|---|---|---|---|---|---|---|---|']
+        for k in main:
+            c0 = out['pmc'][k]
+            if 'SQ_INSTS_VALU_FMA_F64' not in c0:
+                continue
+            fma, add, mul = c0['SQ_INSTS_VALU_FMA_F64'], c0['SQ_INSTS_VALU_ADD_F64'], c0['SQ_INSTS_VALU_MUL_F64']
+            rec = out['per_kernel'][k]
+            rec['fp64_fma_add_mul_insts'] = fma + add + mul
+            rec['fp64_flops_per_launch'] = (2 * fma + add + mul) * 64.0
+            if c0.get('SQ_INSTS_VALU'):
+                rec['fp64_fma_add_mul_share_of_valu'] = (fma + add + mul) / c0['SQ_INSTS_VALU']
+            tfl = frac = None
+            if 'GRBM_GUI_ACTIVE' in c0 and rec.get('held_clock_hz'):
+                secs = c0['GRBM_GUI_ACTIVE'] / 8.0 / rec['held_clock_hz']       # the dispatch's duration in the cycle pass
+                tfl = rec['fp64_flops_per_launch'] / secs / 1e12
+                frac = tfl / (78.6 * rec['held_clock_hz'] / 2.4e9)
+                rec['fp64_tflops_at_held_clock'], rec['fp64_flop_frac_at_held_clock'] = tfl, frac
+            lines.append('| `%s` | %.4g | %.4g | %.4g | %.3g | %s | %.4g | %s |' % (
+                k[:60], fma, add, mul, c0.get('SQ_INSTS_VALU_TRANS_F64', 0.0),
+                '%.3f' % rec['fp64_fma_add_mul_share_of_valu'] if 'fp64_fma_add_mul_share_of_valu' in rec else '-',
+                rec['fp64_flops_per_launch'], '%.1f (%.3f)' % (tfl, frac) if tfl else '-'))
     lines += ['', '(dominant kernel of the call: `%s`)' % main[0], '']
 if workload and main and 'hbm_bytes_per_launch' in out:
     tpath = os.path.join(os.path.dirname(dst) or '.', 'traffic_latest.json')
@@ -200,6 +226,10 @@ if workload and main and 'hbm_bytes_per_launch' in out:
         # share of the vector instructions that are fp64 arithmetic (tools/isa_model.py: the compiler's assembly of the
         # hot loop weighed with this workload's path frequencies); null for kernels without a model
         'fp64_share_of_valu': fp64_share(main[0], c.get('SQ_INSTS_VALU'), workload),
+        # counted, not modelled: FMA + ADD + MUL on doubles (min / max / ldexp are in none of the three counters), and
+        # the flops they are (2 per FMA, 64 lanes per instruction)
+        'fp64_fma_add_mul_insts_per_launch': out['per_kernel'][main[0]].get('fp64_fma_add_mul_insts'),
+        'fp64_flops_per_launch': out['per_kernel'][main[0]].get('fp64_flops_per_launch'),
         'source': dst + '.md: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU / GRBM_GUI_ACTIVE (separate '
                   'passes, tools/profile.sh) on the bench command of this workload; FETCH_SIZE doubled per '
                   'MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B), an upper bound here since the reads '
