@@ -1111,9 +1111,11 @@ def test_run_length_interval_engine(eng, example, monkeypatch, run_len, shift):
 
 def test_asm_loops_are_bit_identical_to_the_compiled_ones(tmp_path):
     """The step loop (three asm arms threaded through chunks of four steps) and the wet interval of the interval / run
-    engine (an asm loop) perform the operations of the C++ they replace in the same order: every output bit is the
-    same.  Built here, on the box, next to the shipped library: the same sources with -DSMART_STEP_ARMS=0
-    -DSMART_WET_ASM=0 (FastModel::step_lazy and hipcc's own wet-interval loop, round 2's kernels) -- then discharge,
+    engine (an asm loop in two modes: the filling below the top layer is skipped while the top layer takes the excess
+    of every lane) perform the operations of the C++ they replace in the same order, and leave out only identities:
+    every output bit is the same.  Built here, on the box, next to the shipped library: the same sources with
+    -DSMART_STEP_ARMS=0 -DSMART_WET_ASM=0 (FastModel::step_lazy and hipcc's own wet-interval loop, round 2's kernels,
+    which fill all six layers in every wet step) -- then discharge,
     groundwater ratio, objective functions and final rows of some thirty seeded set-ups (the bench's sub-daily
     forcing, random gaps 2 ... 48 with storms, droughts, exact zeros, -0.0 rain, negative evaporation, layers above
     capacity; piecewise-constant and 6- / 3-hourly forcing; whole and time-sliced; with and without the final row)
