@@ -488,6 +488,46 @@ struct Reporter {
         }
     }
 
+    // The same with the observation of report interval r and its deviation from the mean requested when interval
+    // r - 1 was reported (prime() ahead of the first).  The run engine: -3.8 % (11.78 -> 11.33 ms on 6-hourly values).
+    // NOT the step loops: there the request is caught by the next chunk's s_waitcnt lgkmcnt(0) (scalar loads return
+    // out of order: there is no other wait) and the two live SGPR pairs cost more than they hide -- +2 % in the step
+    // loop of the merged kernels, +5 % on the daily ensemble's literal chain (tools/gpu_r03_p.sh); the same request as
+    // a vector load (counted by vmcnt, values in VGPRs) cost the step loop 3.5 % (tools/gpu_r03_q.sh).
+    double e_nx = 0.0, w_nx = 0.0;
+
+    __device__ __forceinline__ void prime(const KArgs &a, long r)
+    {
+        if (want_obj && a.R > 0) {
+            const long nx = r < a.R ? r : a.R - 1;
+            e_nx = obs[nx];
+            w_nx = ws[kWsHead + nx];
+        }
+    }
+
+    __device__ __forceinline__ void emit_ahead(const KArgs &a, const LaneCtx &x, long r, double val)
+    {
+        const double e = e_nx, w = w_nx;
+        prime(a, r + 1);
+        if (a.discharge && x.live)
+#if SMART_NT_STORE
+            __builtin_nontemporal_store(val, &a.discharge[(x.c * a.R + r) * a.ld + x.n]);
+#else
+            a.discharge[(x.c * a.R + r) * a.ld + x.n] = val;
+#endif
+        if (want_obj && r == 0)
+            shift = val;
+        if (want_obj && !is_nan_bits(e)) { // montecarlo.py:195-196
+            const double d = val - e;
+            const double u = val - shift;
+            A += d;
+            B += d * d;
+            C1 += u;
+            C2 += u * u;
+            C3 += w * u;
+        }
+    }
+
     // The same with the observation e = obs[r] and w = e - mean(e) requested ahead of time by the caller
     // (interval_loop_obs): no scalar-load latency between the last step of the interval and the moments.
     __device__ __forceinline__ void emit_prefetched(const KArgs &a, const LaneCtx &x, long r, double val, double e,
@@ -948,12 +988,13 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
             m.begin_run();
         long j = 0, r = ra;
         double acc = 0.0;
+        rep.prime(a, ra);
         interval_loop(f, ra * per, rb * per, run_len, [&](long, const double2 v) {
             if (Model::kSplit && j == 0 && r == a.R - 1)
                 park_state();
             interval(v, acc, num, den);
             if (++j == per) {
-                rep.emit(a, x, r, acc * inv_gap);
+                rep.emit_ahead(a, x, r, acc * inv_gap);
                 q_out_total += acc;
                 acc = 0.0;
                 j = 0;
