@@ -412,6 +412,43 @@ def test_headline_size_properties(eng):
     assert rel(gw[rows], gwo) < 1e-10
 
 
+@pytest.mark.parametrize('leg, kernel', [('runs_of_6', 'smart_fast_runs[16 slices'),
+                                         ('flat_forcing', 'smart_fast_steps[16 slices')])
+def test_bench_legs_at_full_size(eng, leg, kernel):
+    """The two other legs of the bench line at their full size: the headline's 1e5 LHS rows x hourly 10 years on
+    6-hourly values (the run engine, two-mode wet intervals over runs of six steps) and on forcing that varies inside
+    the day (the step loop's asm arms).  Same properties as test_headline_size_properties: bit-identical under a
+    permutation of the rows; 32 rows against the oracle -- discharge series, objective functions, groundwater ratio;
+    physical ranges."""
+    import torch
+    import bench
+    N = 100000
+    params = lhs_oracle.lhs_params(N, seed=2718)
+    base, rng = bench.synthetic_forcing(0, hourly=True)
+    f = bench.six_hourly_forcing(base) if leg == 'runs_of_6' else bench.hourly_varying_forcing(base)
+    T, W = f.shape[0], 8760
+    obs = np.abs(rng.normal(2.0, 1.0, T // 24))
+    obs[rng.random(T // 24) < 0.12] = np.nan
+    dev_p = torch.from_numpy(params).cuda()
+    kw = dict(extra=bench.EXTRA, obs=obs, gw_obs=0.12667)
+    out = eng.run_ensemble(dev_p, f, bench.AREA, 3600.0, W, 24, **kw)
+    assert kernel in out._prepared.describe()                               # the kernel the bench leg names
+    perm = torch.randperm(N, device='cuda', generator=torch.Generator(device='cuda').manual_seed(2))
+    out_p = eng.run_ensemble(dev_p[perm], f, bench.AREA, 3600.0, W, 24, want_discharge=False, **kw)
+    assert torch.equal(out.objfn[perm], out_p.objfn) and torch.equal(out.gw[perm], out_p.gw)
+    gw, obj = out.gw.cpu().numpy(), out.objfn.cpu().numpy()
+    assert np.all(np.isfinite(obj)) and np.all((gw >= 0) & (gw <= 1)) and np.all(obj[:, 0] <= 1)
+    rows = np.sort(np.random.default_rng(13).choice(N, 32, replace=False))
+    dis, gwo, _ = so.run_batch(bench.AREA, 3600.0, T, W, f[:, 0].copy(), f[:, 1].copy(), params[rows], bench.EXTRA,
+                               so.REPORT_SUMMARY, 24)
+    got = out.discharge[torch.from_numpy(rows).cuda()].cpu().numpy()
+    assert got.shape == dis.shape == (32, T // 24)
+    assert rel(got, dis) < REL_FAST
+    want = objfn_oracle.objective_matrix(dis, obs, gwo, 0.12667)
+    assert rel(obj[rows, :7], want[:, :7]) < 1e-9 and np.array_equal(obj[rows, 7], want[:, 7])
+    assert rel(gw[rows], gwo) < 1e-10
+
+
 def test_config4_size_one_million_samples(eng):
     """BASELINE config 4's size on one GPU: 1e6 LHS samples x hourly 10 years, objective functions only (the [N, 9]
     block the ranks all-gather).  (i) a 125,000-row block of it -- one rank's shard on 8 GPUs -- run on its own gives
