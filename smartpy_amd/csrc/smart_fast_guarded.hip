@@ -24,6 +24,10 @@ SMART_FAST_KERNEL(smart_fast_guard) { guarded_kernel<2, FastModel<true, true>>(a
 #ifndef SMART_ILLCOND_RECIP
 #define SMART_ILLCOND_RECIP 1 // divisions by per-sample constants through cached reciprocals (0: true divisions)
 #endif
+// the ill-conditioned rows (dt / RK > 2) and any row with a NaN or an infinite parameter (wave_class(): class 3) on
+// the literal model -- which is why this translation unit is compiled WITHOUT -fno-honor-nans (build.py): what a NaN
+// does in the reference's compares and branches is part of what this kernel reproduces, bit for bit with the literal
+// kernel (tests/test_gpu_parity.py: ..._wild_parameters_...)
 SMART_FAST_KERNEL(smart_fast_illcond)
 {
     guarded_kernel<3, LiteralModelT<SMART_ILLCOND_RECIP != 0>>(a, forcing, obs, ws);

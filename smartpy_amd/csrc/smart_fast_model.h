@@ -1000,9 +1000,15 @@ __device__ inline int wave_class(const KArgs &a, long block, long catchment)
 #else
     const bool unstable = !(p[9] * 3600.0 >= 0.5 * dt);
 #endif
+    // a parameter that is NaN or infinite: the reference's own operation order, compiled with NaNs honoured (the fast
+    // kernels are not: -fno-honor-nans), decides what comes out -- tested on the bit patterns for that reason
+    bool wild = false;
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+        wild = wild || (__builtin_bit_cast(unsigned long long, p[i]) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
     const bool any_stiff = __builtin_amdgcn_ballot_w64(stiff) != 0;
     const bool any_guard = __builtin_amdgcn_ballot_w64(guard) != 0;
-    const bool any_unstable = __builtin_amdgcn_ballot_w64(unstable) != 0;
+    const bool any_unstable = __builtin_amdgcn_ballot_w64(unstable || wild) != 0;
     return any_unstable ? 3 : (any_guard ? 2 : (any_stiff ? 1 : 0));
 }
 

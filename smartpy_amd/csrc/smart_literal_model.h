@@ -72,7 +72,13 @@ struct LiteralModelT {
                 const unsigned long long frac = u & 0x000fffffffffffffull;
                 return u - 0x20b0000000000000ull < 0x3e80000000000000ull && frac != 0x000fffffffffffffull;
             };
-            const bool ok = fit(area) && fit(pZ) && fit(dt) && fit(sk) && fit(fk) && fit(gk) && fit(rk);
+            // ... and the other five parameters finite: the identities of the reciprocal path (clamps and hand-downs as
+            // maxima / minima, "d = 0.0" as C (d - d)) hold for numbers, not for a NaN that has to come out as one
+            auto finite = [](double x) {
+                return (__builtin_bit_cast(unsigned long long, x) & 0x7ff0000000000000ull) != 0x7ff0000000000000ull;
+            };
+            const bool ok = fit(area) && fit(pZ) && fit(dt) && fit(sk) && fit(fk) && fit(gk) && fit(rk) && finite(pT) &&
+                            finite(pC) && finite(pH) && finite(pD) && finite(pS);
             divisors_fit = __builtin_amdgcn_ballot_w64(!ok) == 0;
             quick = false;
         }
@@ -199,7 +205,7 @@ struct LiteralModelT {
     __device__ void step(double rain_in, double peva_in, double /*ex*/, double &acc, double &num, double &den)
     {
         if constexpr (RECIP) {
-            if (quick) { // wave-uniform
+            if (__builtin_expect(quick, 1)) { // wave-uniform; the other form out of the way of the loop's instruction stream
                 step_q<true>(rain_in, peva_in, acc, num, den);
                 return;
             }
@@ -234,7 +240,13 @@ struct LiteralModelT {
 #pragma unroll
             for (int i = 0; i < 6; ++i) { // :367-374
                 const double sp = z - l[i];
-                if (ex <= sp) {
+                if constexpr (Q) {
+                    // what the layer takes is min(ex, sp) either way, and "ex = 0.0" is ex - ex: the excess handed down
+                    // without its two selects (the level keeps its own: l + (z - l) need not round to z)
+                    const double put = __builtin_fmin(ex, sp);
+                    l[i] = ex <= sp ? l[i] + ex : z;
+                    ex = ex - put;
+                } else if (ex <= sp) {
                     l[i] += ex;
                     ex = 0.0;
                 } else {
@@ -268,7 +280,7 @@ struct LiteralModelT {
                     level -= lk;
                 }
             };
-            if (unguarded) { // (two copies of the passes, one branch: the flag is wave-uniform)
+            if (__builtin_expect(unguarded, 1)) { // (two copies of the passes, one branch: the flag is wave-uniform)
 #pragma unroll
                 for (int i = 0; i < 6; ++i) { // :381-385
                     const double lk = l[i] * pw[i];
@@ -315,7 +327,15 @@ struct LiteralModelT {
             aeva += rain;
 #pragma unroll
             for (int i = 0; i < 6; ++i) { // :409-419
-                if (l[i] >= d) {
+                if constexpr (Q) {
+                    // both sides of the reference's branch take min(l, d) from the layer and add it to the evaporation;
+                    // "l = 0.0" is l - l, "d = 0.0" is C (d - d) for a finite C (checked once per run, with the
+                    // divisors): the same bits without a compare and three selects per layer
+                    const double take = __builtin_fmin(l[i], d);
+                    l[i] -= take;
+                    aeva += take;
+                    d = pC * (d - take);
+                } else if (l[i] >= d) {
                     l[i] -= d;
                     aeva += d;
                     d = 0.0;

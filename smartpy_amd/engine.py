@@ -92,12 +92,14 @@ def n_reports(n_steps, gap, report_type):
 def variant_classes(params, delta_sec):
     """Which arithmetic variant of the fast kernels a parameter row needs -- the rules of wave_class() in
     csrc/smart_fast_model.h: 0 regular, 1 stiff (some k*3600 < dt: clamps / river rule reachable), 2 guarded
-    (S outside [0, 0.5], C < 0 or Z <= 0), 3 ill-conditioned (dt / (RK*3600) > 2, the river: literal arithmetic)."""
+    (S outside [0, 0.5], C < 0 or Z <= 0), 3 ill-conditioned (dt / (RK*3600) > 2, the river: literal arithmetic) --
+    and any row with a NaN or an infinite parameter, for the literal arithmetic to decide what comes of it."""
     k = params[:, 6:10] * 3600.0
     cls = torch.zeros(params.shape[0], dtype=torch.int64, device=params.device)
     cls[~(k >= delta_sec).all(dim=1)] = 1
     cls[~((params[:, 4] >= 0.0) & (params[:, 4] <= 0.5) & (params[:, 1] >= 0.0) & (params[:, 5] > 0.0))] = 2
     cls[~(k[:, 3] >= 0.5 * delta_sec)] = 3
+    cls[~torch.isfinite(params).all(dim=1)] = 3
     return cls
 
 

@@ -1186,6 +1186,68 @@ def test_asm_loops_are_bit_identical_to_the_compiled_ones(tmp_path):
         assert bits_equal(a[k], b[k]), k
 
 
+def test_ill_conditioned_rows_with_wild_parameters_match_the_literal_kernel(eng, example):
+    """The ill-conditioned rows of the fast mode run the reference's operation order with a few identities applied where
+    wave-uniform checks allow them (divisions through reciprocals, clamps and the two cascades' hand-downs as
+    minima / maxima: smart_literal_model.h).  Rows whose parameters are NaN, infinite, negative or zero must take the
+    same decisions as the literal kernel: every output the same bits, or NaN where it has NaN."""
+    rng = np.random.default_rng(77)
+    n = 192                                                  # three wavefronts of ill-conditioned rows (RK = 1 h, daily)
+    params = lhs_oracle.lhs_params(n, seed=5)
+    params[:, 9] = rng.uniform(1.0, 8.0, n)                  # dt / RK = 3 ... 24
+    wild = [(0, np.nan), (1, np.nan), (1, np.inf), (1, -0.5), (1, 0.0), (1, -0.0), (2, np.nan), (2, 5.0), (3, np.nan),
+            (3, -1.0), (4, np.nan), (4, 0.9), (4, 0.0), (5, 1e-3), (6, 0.5), (7, np.inf), (8, 1e300), (0, 0.0), (0, -1.0)]
+    for k, (col, val) in enumerate(wild):                    # one wild value per row, spread over the three wavefronts
+        params[(k * 10 + 3) % n, col] = val
+    T, W = 900, 120
+    rain = rng.gamma(0.6, 5.0, T) * (rng.random(T) < 0.6)
+    peva = np.maximum(0.0, rng.normal(1.5, 1.0, T))
+    f = forcing_of(rain, peva)
+    kw = dict(extra=example['extra'], want_final=True)
+    with np.errstate(all='ignore'):
+        fast = eng.run_ensemble(params, f, example['area'], 86400.0, W, 1, **kw)
+        lit = eng.run_ensemble(params, f, example['area'], 86400.0, W, 1, math_mode='literal', **kw)
+    assert 'smart_fast_illcond' in fast._prepared.describe()
+
+    def same_bits_or_both_nan(x, y):
+        return (x.view(np.uint64) == y.view(np.uint64)) | (np.isnan(x) & np.isnan(y))
+    for name in ('discharge', 'gw', 'final_vars'):
+        a, b = getattr(fast, name).cpu().numpy(), getattr(lit, name).cpu().numpy()
+        same = same_bits_or_both_nan(a, b)
+        assert same.all(), (name, int((~same).sum()))
+    # the literal kernel itself against the oracle on the wild rows (the reference's branches seeing NaNs)
+    wild_rows = sorted((k * 10 + 3) % n for k in range(len(wild)))
+    with np.errstate(all='ignore'):
+        dis, gwo, _ = so.run_batch(example['area'], 86400.0, T, W, rain, peva, params[wild_rows], example['extra'],
+                                   so.REPORT_SUMMARY, 1)
+    assert same_bits_or_both_nan(lit.discharge.cpu().numpy()[wild_rows], dis).all()
+    # ... and in an hourly run, where no row is ill-conditioned: a row with a NaN or an infinite parameter is taken out
+    # of the fast arithmetic (compiled with -fno-honor-nans) and handed to the same literal model
+    params = lhs_oracle.lhs_params(256, seed=6)
+    odd = {}
+    for k, (col, val) in enumerate([(0, np.nan), (2, np.nan), (3, np.nan), (4, np.nan), (1, np.inf), (7, np.inf),
+                                    (5, np.nan), (9, np.nan), (6, -np.inf)]):
+        params[k * 27 + 5, col] = val
+        odd[k * 27 + 5] = col
+    T, W = 24 * 60, 24 * 10
+    f = forcing_of(example['rain_hourly'][:T], example['peva_hourly'][:T])
+    with np.errstate(all='ignore'):
+        fast = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, extra=example['extra'])
+        lit = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, extra=example['extra'], math_mode='literal')
+    assert 'smart_fast_illcond' in fast._prepared.describe() and 'smart_fast_intervals' in fast._prepared.describe()
+    a, b = fast.discharge.cpu().numpy(), lit.discharge.cpu().numpy()
+    rows = sorted(odd)
+    ga, gb = fast.gw.cpu().numpy()[rows], lit.gw.cpu().numpy()[rows]
+    # (report means: the literal kernel sums a day's 24 outflows pairwise like numpy, this one in sequence -- the NaNs in
+    # the same places, the numbers to the last bits)
+    assert np.array_equal(np.isnan(a[rows]), np.isnan(b[rows])) and np.array_equal(np.isnan(ga), np.isnan(gb))
+    ok = ~np.isnan(b[rows])
+    assert rel(a[rows][ok], b[rows][ok]) < 1e-12 and rel(ga[~np.isnan(gb)], gb[~np.isnan(gb)]) < 1e-12
+    assert np.isnan(b[rows]).any() and ok.any()              # both kinds of outcome are in the set
+    rest = np.setdiff1d(np.arange(256), rows)
+    assert np.isfinite(a[rest]).all() and rel(a[rest], b[rest]) < REL_FAST
+
+
 def test_launch_captures_into_a_hip_graph(eng, example):
     """With every input resident on the device the call is pure stream work -- kernels plus, for a time-sliced launch,
     a stream-ordered allocation, a memset and a free -- so it captures into a HIP graph and replays to the same bits."""
