@@ -402,7 +402,8 @@ def test_public_surface_has_every_name_of_the_reference():
 def test_rows_are_classified_and_grouped_by_arithmetic_variant():
     """engine.variant_classes mirrors wave_class() of csrc/smart_fast_model.h: 1 stiff (some k*3600 < dt), 2 guarded
     (S outside [0, 0.5], C < 0, Z <= 0), 3 ill-conditioned (dt / RK > 2 -- the river constant only: the catchment
-    reservoirs' clamp at zero forgets a perturbation); the most demanding wins.  _variant_grouping
+    reservoirs' clamp at zero forgets a perturbation) or any NaN / infinite parameter; the most
+    demanding wins.  _variant_grouping
     puts each class into whole wavefronts of 64 (padded with copies of its last row), keeps every row, and with
     sort_rows orders a class by T (64 bins), then S * Z."""
     import torch
@@ -427,6 +428,12 @@ def test_rows_are_classified_and_grouped_by_arithmetic_variant():
     assert (cls[:40] == 1).all() and (cls[40:60] == 3).all() and (cls[60:70] == 1).all()
     assert (cls[70:80][k[70:80, 3] >= 0.5 * dt] == 2).all() and (cls[80:90] == 3).all()
     assert engine.variant_classes(torch.from_numpy(p), 3600.0).max() == 2      # hourly steps: nothing stiff by default
+    # a NaN or an infinite parameter anywhere in the row: the literal model decides what comes of it, at any step length
+    q = lhs_oracle.lhs_params(64, seed=10)
+    for row, (col, val) in enumerate([(0, np.nan), (2, np.inf), (3, -np.inf), (5, np.nan), (8, np.inf), (9, np.nan)]):
+        q[row * 7, col] = val
+    got = engine.variant_classes(torch.from_numpy(q), 3600.0).numpy()
+    assert (got[[0, 7, 14, 21, 28, 35]] == 3).all() and (np.delete(got, [0, 7, 14, 21, 28, 35]) == 0).all()
 
     for sort_rows in (False, True):
         gather, inverse = engine._variant_grouping(torch.from_numpy(p), dt, sort_rows)
