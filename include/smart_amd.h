@@ -50,7 +50,10 @@ extern "C" {
                              /* reservoirs kept as outflows, FMA: <= 1e-9 relative on discharge;        */
                              /* wavefronts holding a sample with delta_sec / (k * 3600) > 2 (where the  */
                              /* reference's explicit update amplifies rounding differences) run the     */
-                             /* literal arithmetic instead                                              */
+                             /* literal arithmetic instead, and so do rows with a NaN or an infinite    */
+                             /* parameter.  The FORCING must be finite in this mode: what the           */
+                             /* reference's branches make of a NaN in it (structure.py:359, :409-419)   */
+                             /* only SMART_MATH_LITERAL reproduces                                      */
 
 /* error codes; the reference raises Exception at the cited places */
 #define SMART_OK 0

@@ -308,6 +308,13 @@ def prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, re
         mmode = _MATH[math_mode]
     except KeyError:
         raise Exception("math mode '{}' unknown.".format(math_mode))
+    # A NaN or an infinity in the forcing (a gap someone filled with 'nan'): the reference's branches see it -- a NaN
+    # excess is "not wet", the evaporation cascade then empties all six layers (structure.py:359, :409-419) -- and only
+    # the literal kernel takes those decisions; the fast kernels are compiled for numbers.  Forcing that arrives from
+    # the host is looked at here; a caller who keeps it on the device says math_mode='literal' for such data.
+    if mmode == MATH_FAST and not (isinstance(forcing_in, torch.Tensor) and forcing_in.is_cuda):
+        if not bool(np.isfinite(np.asarray(forcing_in, dtype=np.float64)).all()):
+            mmode = MATH_LITERAL
     R = n_reports(T, report_gap, rtype)
 
     area = as_device(np.full(C, area_m2, dtype=np.float64) if np.ndim(area_m2) == 0 else area_m2, device, (C,))

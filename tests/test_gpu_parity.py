@@ -1248,6 +1248,34 @@ def test_ill_conditioned_rows_with_wild_parameters_match_the_literal_kernel(eng,
     assert np.isfinite(a[rest]).all() and rel(a[rest], b[rest]) < REL_FAST
 
 
+def test_a_nan_in_the_forcing_is_for_the_literal_kernel(eng, example):
+    """A NaN in the forcing is not "wet" to the reference (structure.py:359: NaN >= 0 is False), and its evaporation
+    cascade then empties all six layers (:409-419: NaN compares False, d stays NaN): the run goes on from an empty
+    soil, with finite discharge.  Only the literal kernel takes those decisions; forcing handed over from the host
+    is checked, and a fast call on such data runs it -- bit-identical to the oracle, daily means included."""
+    import torch
+    params = lhs_oracle.lhs_params(130, seed=8)
+    T, W = 24 * 90, 24 * 15
+    rain, peva = example['rain_hourly'][:T].copy(), example['peva_hourly'][:T].copy()
+    rain[24 * 40 + 5] = np.nan
+    peva[24 * 60 + 11] = np.nan
+    f = forcing_of(rain, peva)
+    with np.errstate(all='ignore'):
+        out = eng.run_ensemble(params, f, example['area'], 3600.0, W, 24, extra=example['extra'])
+        dis, gwo, _ = so.run_batch(example['area'], 3600.0, T, W, rain, peva, params, example['extra'],
+                                     so.REPORT_SUMMARY, 24)
+    assert out._prepared.describe() == 'smart_ensemble_literal'
+    got = out.discharge.cpu().numpy()
+    assert np.isfinite(dis).all()
+    assert got.shape == dis.shape and int((got.view(np.int64) != dis.view(np.int64)).sum()) == 0
+    assert rel(out.gw.cpu().numpy(), gwo) < 1e-12        # (the ratio's two sums: sequential here, numpy's order there)
+    # the same data kept on the device is the caller's to flag (math_mode='literal'); the fast kernels answer with
+    # numbers of their own
+    lit = eng.run_ensemble(params, torch.from_numpy(f).cuda(), example['area'], 3600.0, W, 24, extra=example['extra'],
+                           math_mode='literal')
+    assert bits_equal(lit.discharge.cpu().numpy(), dis)
+
+
 def test_launch_captures_into_a_hip_graph(eng, example):
     """With every input resident on the device the call is pure stream work -- kernels plus, for a time-sliced launch,
     a stream-ordered allocation, a memset and a free -- so it captures into a HIP graph and replays to the same bits."""
