@@ -1006,6 +1006,22 @@ __device__ inline int wave_class(const KArgs &a, long block, long catchment)
 #pragma unroll
     for (int i = 0; i < 10; ++i)
         wild = wild || (__builtin_bit_cast(unsigned long long, p[i]) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+    // ... and a caller's INITIAL states the fast arithmetic is not made for: a NaN, an infinity, a negative volume (the
+    // reference's clamps and compares decide what follows), or soil so far above its capacity that s' = S tot / Z
+    // starts beyond the 0.5 the guard class stops at (tot / Z <= 1 from the first wet step on: the filling clamps)
+    if (a.initial) {
+        const double *ip = a.initial + (catchment * a.N + n) * 12;
+        double lay = 0.0;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const unsigned long long u = __builtin_bit_cast(unsigned long long, ip[i]);
+            wild = wild || (u & 0x7ff0000000000000ull) == 0x7ff0000000000000ull || u > 0x8000000000000000ull;
+            if (i >= 5 && i < 11)
+                lay += ip[i];
+        }
+        if (!wild) // (numbers from here on: the compare is safe under -fno-honor-nans)
+            wild = !(p[4] * (lay / a.area[catchment] * 1e3) / p[5] <= 0.5);
+    }
     const bool any_stiff = __builtin_amdgcn_ballot_w64(stiff) != 0;
     const bool any_guard = __builtin_amdgcn_ballot_w64(guard) != 0;
     const bool any_unstable = __builtin_amdgcn_ballot_w64(unstable || wild) != 0;

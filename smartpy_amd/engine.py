@@ -89,21 +89,30 @@ def n_reports(n_steps, gap, report_type):
     return int(_lib.lib().smart_n_reports(n_steps, gap, report_type))
 
 
-def variant_classes(params, delta_sec):
+def variant_classes(params, delta_sec, initial=None, area=None):
     """Which arithmetic variant of the fast kernels a parameter row needs -- the rules of wave_class() in
     csrc/smart_fast_model.h: 0 regular, 1 stiff (some k*3600 < dt: clamps / river rule reachable), 2 guarded
     (S outside [0, 0.5], C < 0 or Z <= 0), 3 ill-conditioned (dt / (RK*3600) > 2, the river: literal arithmetic) --
-    and any row with a NaN or an infinite parameter, for the literal arithmetic to decide what comes of it."""
+    and any row with a NaN or an infinite parameter, for the literal arithmetic to decide what comes of it; likewise a
+    row whose INITIAL states (initial [C, N, 12] or [N, 12], with the catchments' areas) hold a NaN, an infinity, a
+    negative volume, or soil so far above its capacity that S * sum(levels) / Z starts beyond 0.5 (in any catchment)."""
     k = params[:, 6:10] * 3600.0
     cls = torch.zeros(params.shape[0], dtype=torch.int64, device=params.device)
     cls[~(k >= delta_sec).all(dim=1)] = 1
     cls[~((params[:, 4] >= 0.0) & (params[:, 4] <= 0.5) & (params[:, 1] >= 0.0) & (params[:, 5] > 0.0))] = 2
     cls[~(k[:, 3] >= 0.5 * delta_sec)] = 3
     cls[~torch.isfinite(params).all(dim=1)] = 3
+    if initial is not None:
+        st = initial.reshape(-1, params.shape[0], 12)
+        ar = torch.as_tensor(area, dtype=torch.float64, device=params.device).reshape(-1, 1)
+        bad = (~torch.isfinite(st) | (st < 0.0)).any(dim=2)                  # (-0.0 is a zero like any other)
+        s_init = params[:, 4].unsqueeze(0) * (st[:, :, 5:11].sum(dim=2) / ar * 1e3) / params[:, 5].unsqueeze(0)
+        bad = bad | ~(s_init <= 0.5)
+        cls[bad.any(dim=0)] = 3
     return cls
 
 
-def _variant_grouping(params, delta_sec, sort_rows=False):
+def _variant_grouping(params, delta_sec, sort_rows=False, initial=None, area=None):
     """A wavefront runs ONE variant for its 64 lanes, the most general one any of its rows needs.  To keep a row's
     arithmetic (and cost) independent of its neighbours, rows are grouped by variant before the launch, each group
     padded to whole wavefronts with copies of its last row.  Returns (gather [N_run], inverse [N]) or None when the
@@ -117,7 +126,7 @@ def _variant_grouping(params, delta_sec, sort_rows=False):
     of the filling cascade fire.  -2.5 % launch time at 1e5 samples, -5 % at 125,000, -8 % at 1e6
     (tools/debug/sort_rows.py).  Only asked for when no discharge matrix is stored -- its columns would have to be
     permuted back, which costs more than the launch gains; the per-sample results are permuted back on the way out."""
-    cls = variant_classes(params, delta_sec)
+    cls = variant_classes(params, delta_sec, initial, area)
     mixed = int(cls.min()) != int(cls.max())
     if not mixed and not sort_rows:
         return None
@@ -342,6 +351,8 @@ def prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, re
     memo_on = [t for t in (params_in, forcing_in) if isinstance(t, torch.Tensor) and t.is_cuda]
     sort_rows = not want_discharge and discharge_out is None
     memo_key = (float(delta_sec), int(report_gap), rtype, C, N, T, bool(group_variants), sort_rows)
+    if initial is not None:
+        memo_on = []          # the rows' classes depend on the initial states as well: nothing is remembered across calls
     memo = _Memo.lookup('fast', memo_on, memo_key) if len(memo_on) == 2 and mmode == MATH_FAST else None
 
     # rows grouped by arithmetic variant (fast mode, one shared [N, 10] matrix spanning more than one wavefront)
@@ -350,7 +361,7 @@ def prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, re
     p._grouping, p._caller_out = None, None
     p._memo_of = (memo_on, memo_key) if len(memo_on) == 2 and mmode == MATH_FAST else None
     if group_variants and mmode == MATH_FAST and pstride == 0 and N > 64:
-        p._grouping = memo[0][0] if memo else _variant_grouping(params, float(delta_sec), sort_rows)
+        p._grouping = memo[0][0] if memo else _variant_grouping(params, float(delta_sec), sort_rows, initial, area)
         if p._grouping is not None:
             gather = p._grouping[0]
             params = params[gather].contiguous()

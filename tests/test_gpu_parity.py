@@ -1221,6 +1221,27 @@ def test_ill_conditioned_rows_with_wild_parameters_match_the_literal_kernel(eng,
         dis, gwo, _ = so.run_batch(example['area'], 86400.0, T, W, rain, peva, params[wild_rows], example['extra'],
                                    so.REPORT_SUMMARY, 1)
     assert same_bits_or_both_nan(lit.discharge.cpu().numpy()[wild_rows], dis).all()
+    # wild INITIAL states -- a NaN, an infinity, a negative volume, soil far above its capacity -- in rows the fast
+    # arithmetic would otherwise take (RK = 40 h): the same hand-over to the literal model
+    tame = lhs_oracle.lhs_params(n, seed=7)
+    tame[:, 6:10] = np.maximum(tame[:, 6:10], 40.0)
+    init = np.abs(rng.normal(1e5, 5e4, (n, 12)))
+    odd_states = [(0, np.nan), (3, np.nan), (5, np.nan), (8, np.nan), (11, np.nan), (0, np.inf), (6, np.inf), (11, np.inf),
+                  (2, -1e4), (5, -1e3), (11, -1e5), (7, 1e12), (10, 0.0), (11, 0.0), (4, -0.0)]
+    for k, (col, val) in enumerate(odd_states):
+        init[k * 12 + 1, col] = val
+    with np.errstate(all='ignore'):
+        fast = eng.run_ensemble(tame, f, example['area'], 86400.0, W, 1, initial=init, want_final=True)
+        lit = eng.run_ensemble(tame, f, example['area'], 86400.0, W, 1, initial=init, want_final=True,
+                               math_mode='literal')
+    assert 'smart_fast_illcond' in fast._prepared.describe() and 'smart_fast_plain' in fast._prepared.describe()
+    rows = [k * 12 + 1 for k in range(len(odd_states) - 3)]     # (the three zeros at the end are states like any other)
+    for name in ('discharge', 'gw', 'final_vars'):
+        a, b = getattr(fast, name).cpu().numpy(), getattr(lit, name).cpu().numpy()
+        assert same_bits_or_both_nan(a[rows], b[rows]).all(), name
+        rest = np.setdiff1d(np.arange(n), rows)
+        # (fast arithmetic: a reservoir drained to 1e-20 is a zero with another rounding history)
+        assert np.allclose(a[rest], b[rest], rtol=1e-8, atol=1e-9 * np.abs(b[rest]).max()), name
     # ... and in an hourly run, where no row is ill-conditioned: a row with a NaN or an infinite parameter is taken out
     # of the fast arithmetic (compiled with -fno-honor-nans) and handed to the same literal model
     params = lhs_oracle.lhs_params(256, seed=6)

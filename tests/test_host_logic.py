@@ -434,6 +434,14 @@ def test_rows_are_classified_and_grouped_by_arithmetic_variant():
         q[row * 7, col] = val
     got = engine.variant_classes(torch.from_numpy(q), 3600.0).numpy()
     assert (got[[0, 7, 14, 21, 28, 35]] == 3).all() and (np.delete(got, [0, 7, 14, 21, 28, 35]) == 0).all()
+    # ... and wild INITIAL states: a NaN, an infinity, a negative volume, soil so far above capacity that S tot / Z > 0.5
+    q = lhs_oracle.lhs_params(64, seed=11)
+    init = np.full((64, 12), 1e5)
+    init[3, 0], init[9, 7], init[17, 11], init[25, 6], init[33, 4] = np.nan, np.inf, -1.0, 1e13, -0.0
+    got = engine.variant_classes(torch.from_numpy(q), 3600.0, torch.from_numpy(init), [175.46e6]).numpy()
+    assert (got[[3, 9, 17, 25]] == 3).all() and (np.delete(got, [3, 9, 17, 25]) == 0).all()
+    two = np.stack([np.full((64, 12), 1e5), init])            # [C = 2, N, 12]: wild in any catchment counts
+    assert np.array_equal(engine.variant_classes(torch.from_numpy(q), 3600.0, torch.from_numpy(two), [1e8, 175.46e6]).numpy(), got)
 
     for sort_rows in (False, True):
         gather, inverse = engine._variant_grouping(torch.from_numpy(p), dt, sort_rows)
