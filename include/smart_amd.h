@@ -53,7 +53,8 @@ extern "C" {
                              /* literal arithmetic instead, and so do rows with a NaN or an infinite    */
                              /* parameter.  The FORCING must be finite in this mode: what the           */
                              /* reference's branches make of a NaN in it (structure.py:359, :409-419)   */
-                             /* only SMART_MATH_LITERAL reproduces                                      */
+                             /* only SMART_MATH_LITERAL reproduces -- a fast launch that meets one      */
+                             /* raises SMART_STATUS_NONFINITE_FORCING                                   */
 
 /* error codes; the reference raises Exception at the cited places */
 #define SMART_OK 0
@@ -90,6 +91,8 @@ extern "C" {
                                        /* NaN from that slice on; repeat the launch with time_slices = 1            */
 #define SMART_STATUS_STALE_PLAN 0x2    /* the plan did not cover a class / kind of forcing met on the device: those  */
                                        /* rows were NOT computed; repeat the launch with plan = 0                    */
+#define SMART_STATUS_NONFINITE_FORCING 0x4 /* SMART_MATH_FAST met a NaN or an infinity in the forcing: its outputs are */
+                                       /* not the reference's; repeat the launch with math_mode = SMART_MATH_LITERAL  */
 
 /*
  * One ensemble launch = the whole per-sample loop that spotpy's sampler drives

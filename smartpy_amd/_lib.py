@@ -18,7 +18,7 @@ PLAN_VALID = 0x100
 PLAN_CLASS_BITS = {0: 0x01, 1: 0x02, 2: 0x04, 3: 0x08}     # regular, stiff, guard, ill-conditioned
 PLAN_FORCING_PIECEWISE, PLAN_FORCING_VARYING, PLAN_FORCING_RUNS = 0x10, 0x20, 0x80
 PLAN_ROWS_ORDERED = 0x40
-STATUS_SLICE_TIMEOUT, STATUS_STALE_PLAN = 0x1, 0x2
+STATUS_SLICE_TIMEOUT, STATUS_STALE_PLAN, STATUS_NONFINITE_FORCING = 0x1, 0x2, 0x4
 
 _dp = ctypes.c_void_p   # device or host address, passed as an integer
 

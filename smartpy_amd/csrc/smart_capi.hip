@@ -192,6 +192,10 @@ __global__ void smart_forcing_scan(KArgs a, const double2 *__restrict__ forcing)
         bad |= forcing_flags_of_step(a, f, t);
     if (bad)
         __hip_atomic_fetch_or(a.fflags + blockIdx.y, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // a NaN or an infinity in the forcing: the fast kernels are not made for it (what the reference's branches do with
+    // it only the literal kernel reproduces) -- the launch goes on, and says so in its status word
+    if ((bad & kForcingNonFinite) && a.hdr)
+        __hip_atomic_fetch_or(a.hdr + kHdrStatus, kStatusNonFiniteForcing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Zeroes the header (status word, tickets), the forcing flags and the slice counters.  A kernel rather than
@@ -583,6 +587,8 @@ static int run(const SmartEnsemble *e)
 
     const dim3 grid((unsigned)a.n_blocks, (unsigned)e->n_catchments);
     if (e->math_mode == SMART_MATH_LITERAL) {
+        if (w.hdr) // a clean status word for smart_launch_status (a fast launch before this one may have left its own)
+            reset_workspace(w, e->n_catchments, nullptr, 0, s);
         a.hdr = nullptr;
         launch_literal(a, grid, a.np_mean ? (size_t)a.gap * kWave * sizeof(double) : 0, s);
         HIP_TRY(hipGetLastError());
@@ -612,10 +618,11 @@ static int run(const SmartEnsemble *e)
     }
     if (w.hdr) {
         reset_workspace(w, e->n_catchments, a_sliced.seg_flag, n_seg > 1 ? a.seg_blocks : 0, s);
-        if (x.intervals && (x.class_mask & SMART_PLAN_CLASS_REGULAR)) {
-            scan_forcing(e, a, w, s);
+        // every fast launch looks at its forcing (the merged kernels for what the flags say about runs of equal
+        // values; all of them for the NaN that belongs to the literal kernel: status word)
+        scan_forcing(e, a, w, s);
+        if (x.intervals && (x.class_mask & SMART_PLAN_CLASS_REGULAR))
             a.fflags = a_sliced.fflags = w.fflags;
-        }
     }
 
     // ---- launch: one kernel on the caller's stream; several fork onto the device's auxiliary streams and join

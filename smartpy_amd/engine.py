@@ -245,8 +245,15 @@ class PreparedEnsemble(object):
             return self._result()
         warnings.warn("smartpy_amd: launch status %#x (%s); repeating the launch %s" % (
             word, ' + '.join(n for b, n in ((_lib.STATUS_SLICE_TIMEOUT, 'a time slice timed out'),
-                                            (_lib.STATUS_STALE_PLAN, 'stale plan')) if word & b),
-            'without time slices' if word & _lib.STATUS_SLICE_TIMEOUT else 'with a fresh plan'))
+                                            (_lib.STATUS_STALE_PLAN, 'stale plan'),
+                                            (_lib.STATUS_NONFINITE_FORCING, 'a NaN or an infinity in the forcing'))
+                             if word & b),
+            'in literal arithmetic' if word & _lib.STATUS_NONFINITE_FORCING else (
+                'without time slices' if word & _lib.STATUS_SLICE_TIMEOUT else 'with a fresh plan')))
+        if word & _lib.STATUS_NONFINITE_FORCING:
+            # what the reference's branches make of a NaN only the literal kernel reproduces (forcing that came from the
+            # host never gets here: prepare_ensemble looked at it)
+            self._e.math_mode = MATH_LITERAL
         if word & _lib.STATUS_SLICE_TIMEOUT:
             self._e.time_slices = 1
         if word & _lib.STATUS_STALE_PLAN:

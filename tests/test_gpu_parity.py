@@ -1290,11 +1290,22 @@ def test_a_nan_in_the_forcing_is_for_the_literal_kernel(eng, example):
     assert np.isfinite(dis).all()
     assert got.shape == dis.shape and int((got.view(np.int64) != dis.view(np.int64)).sum()) == 0
     assert rel(out.gw.cpu().numpy(), gwo) < 1e-12        # (the ratio's two sums: sequential here, numpy's order there)
-    # the same data kept on the device is the caller's to flag (math_mode='literal'); the fast kernels answer with
-    # numbers of their own
-    lit = eng.run_ensemble(params, torch.from_numpy(f).cuda(), example['area'], 3600.0, W, 24, extra=example['extra'],
-                           math_mode='literal')
-    assert bits_equal(lit.discharge.cpu().numpy(), dis)
+    # the same data kept on the device: the launch's own look at its forcing (smart_forcing_scan) leaves
+    # SMART_STATUS_NONFINITE_FORCING in the status word, and verify() repeats the launch in literal arithmetic
+    with pytest.warns(UserWarning, match='NaN or an infinity in the forcing'):
+        dev = eng.run_ensemble(params, torch.from_numpy(f).cuda(), example['area'], 3600.0, W, 24, extra=example['extra'])
+    assert dev._prepared.describe() == 'smart_ensemble_literal' and bits_equal(dev.discharge.cpu().numpy(), dis)
+    # ... also where no merged kernel is involved (a report every step: smart_fast_plain)
+    with np.errstate(all='ignore'):
+        dis1, _, _ = so.run_batch(example['area'], 3600.0, T, W, rain, peva, params[:70], example['extra'],
+                                  so.REPORT_SUMMARY, 1)
+    with pytest.warns(UserWarning, match='NaN or an infinity in the forcing'):
+        dev = eng.run_ensemble(params[:70], torch.from_numpy(f).cuda(), example['area'], 3600.0, W, 1, extra=example['extra'])
+    assert bits_equal(dev.discharge.cpu().numpy(), dis1)
+    # and a prepared call that is launched without verify() can still be asked
+    prep = eng.prepare_ensemble(params, torch.from_numpy(f).cuda(), example['area'], 3600.0, W, 24, extra=example['extra'])
+    prep.enqueue()
+    assert prep.status() & 0x4
 
 
 def test_launch_captures_into_a_hip_graph(eng, example):
