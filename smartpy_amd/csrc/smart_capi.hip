@@ -188,13 +188,19 @@ __global__ void smart_forcing_scan(KArgs a, const double2 *__restrict__ forcing)
 {
     const double2 *__restrict__ f = forcing + (long)blockIdx.y * a.T;
     int bad = 0;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < a.T; t += (long)gridDim.x * blockDim.x)
+    bool wild = false; // a NaN or an infinity (exponent bits all ones)
+    const unsigned long long top = 0x7ff0000000000000ull;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < a.T; t += (long)gridDim.x * blockDim.x) {
         bad |= forcing_flags_of_step(a, f, t);
+        const double2 v = f[t];
+        wild = wild || (__builtin_bit_cast(unsigned long long, v.x) & top) == top ||
+               (__builtin_bit_cast(unsigned long long, v.y) & top) == top;
+    }
     if (bad)
         __hip_atomic_fetch_or(a.fflags + blockIdx.y, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // a NaN or an infinity in the forcing: the fast kernels are not made for it (what the reference's branches do with
     // it only the literal kernel reproduces) -- the launch goes on, and says so in its status word
-    if ((bad & kForcingNonFinite) && a.hdr)
+    if (wild && a.hdr)
         __hip_atomic_fetch_or(a.hdr + kHdrStatus, kStatusNonFiniteForcing, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

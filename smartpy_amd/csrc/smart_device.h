@@ -17,7 +17,6 @@ namespace smart {
 
 constexpr int kMaxDiv = 12;
 constexpr int kForcingInsane = 1 << 30; // some value of the catchment's forcing is negative, -0, infinite or NaN
-constexpr int kForcingNonFinite = 1 << 29; // ... infinite or NaN: not for the fast kernels at all (SMART_STATUS_NONFINITE_FORCING)
 
 struct KArgs {
     long N, T, W, gap, R, first_len; // first_len: steps in report interval 0 (raw mode with T % gap != 0)
@@ -660,7 +659,6 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
 // every value finite and >= +0 (the shortcuts of FastModel::step_arms)?  One int of flags per catchment:
 //   bit i (i < n_div)   the forcing is NOT constant over the aligned runs of div[i] steps (div[0] = gap, descending)
 //   kForcingInsane      some value is negative, -0, infinite or NaN
-//   kForcingNonFinite   some value is infinite or NaN
 // A run of d steps is constant iff no step t with t % d != 0 differs from its predecessor: one compare per step, the
 // remainders only where the forcing changes.  smart_forcing_scan answers for the whole launch (a.fflags); without a
 // workspace every wavefront scans for itself (~0.1 ms for ten years of hourly steps).
@@ -671,8 +669,6 @@ __device__ __forceinline__ int forcing_flags_of_step(const KArgs &a, const doubl
     const unsigned long long top = 0x7ff0000000000000ull; // sign clear and exponent below all ones <=> bits < top
     if (__builtin_bit_cast(unsigned long long, v.x) >= top || __builtin_bit_cast(unsigned long long, v.y) >= top)
         bad |= kForcingInsane;
-    if ((__builtin_bit_cast(unsigned long long, v.x) & top) == top || (__builtin_bit_cast(unsigned long long, v.y) & top) == top)
-        bad |= kForcingNonFinite;
     if (t > 0) {
         const double2 u = f[t - 1];
         if (!(same_bits(v.x, u.x) && same_bits(v.y, u.y))) {
