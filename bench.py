@@ -200,16 +200,48 @@ def rank_evidence(device, launch_ms):
     import torch.distributed as dist
     props = torch.cuda.get_device_properties(device)
     mine = {'rank': sdist.rank_world()[0], 'device': '%s #%d' % (props.name, device.index),
+            'current_device': int(torch.cuda.current_device()), 'local_rank': sdist.env_world()[2],
             'uuid': str(getattr(props, 'uuid', '')), 'pci_bus_id': int(getattr(props, 'pci_bus_id', -1)),
             'host': os.uname().nodename, 'pid': os.getpid(), 'launch_ms': launch_ms}
+    try:        # the collective library torch was built against: RCCL's version on ROCm
+        rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:       # noqa: BLE001
+        rccl = None
+    lib = {'rccl_version': rccl, 'hip': getattr(torch.version, 'hip', None), 'torch': torch.__version__}
     if not sdist.is_distributed():
-        return {'backend': None, 'world_size': 1, 'devices': [mine['device']], 'launch_ms_per_rank': [launch_ms],
-                'ranks': [mine]}
+        return dict(lib, backend=None, world_size=1, devices=[mine['device']], launch_ms_per_rank=[launch_ms],
+                    ranks=[mine])
     everyone = [None] * dist.get_world_size()
     dist.all_gather_object(everyone, mine)
-    return {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
-            'devices': [r['device'] for r in everyone], 'launch_ms_per_rank': [r['launch_ms'] for r in everyone],
-            'ranks': everyone}
+    return dict(lib, backend=dist.get_backend(), world_size=dist.get_world_size(),
+                devices=[r['device'] for r in everyone], launch_ms_per_rank=[r['launch_ms'] for r in everyone],
+                ranks=everyone)
+
+
+def spawn_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` started bare (no WORLD_SIZE in the environment): start the N ranks ourselves, the way
+    the driver's launcher would -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port <free> bench.py <same arguments>` -- as a CHILD process, before this process has made any
+    GPU call (a process that has initialised the GPU must not exec another program on this pool, and need not: it only
+    relays).  Rank 0's JSON line goes to stdout as it is, anything else the ranks print to stderr; returns the
+    launcher's return code.  The reference's counterpart: `mpirun -np N python script.py` around spotpy's
+    parallel='mpi' (montecarlo.py:153-154, docs/_doc_src/tutorial/montecarlo_experiment.rst:129-141)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=os.getcwd())
+    for raw in child.stdout:
+        text = raw.decode('utf8', 'replace')
+        out = sys.stdout if text.startswith('{') else sys.stderr
+        out.write(text)
+        out.flush()
+    return child.wait()
 
 
 def main():
@@ -226,10 +258,11 @@ def main():
     ap.add_argument('--no-strong', action='store_true', help='skip the strong_1e6 leg (config 4 beside config 3)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:    # started bare: this process becomes the launcher
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank, world, device = sdist.init()
     if world != args.gpus:
-        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE is %d (launch with torch.distributed.run)'
-                         % (args.gpus, world))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE is %d' % (args.gpus, world))
     if device.type != 'cuda':
         raise SystemExit('bench.py needs a GPU: the engine has no CPU path')
 
@@ -386,6 +419,11 @@ def main():
                        'runs_total': n_runs_total, 'runs_per_gpu': n_local, 'n_steps': T, 'n_warm': W,
                        'math_mode': args.math, 'wet_fraction': w, 'parallelism': shard},
             'per_gpu': value / world,
+            # which scaling series this line belongs to; north_star's ">= 7x at 8 GPUs" reads on `value` for the weak
+            # series (per-GPU work fixed) and on strong_1e6.value for the strong one (1e6 samples in total, configs[3])
+            'series': {'value': '%s: %s' % (scaling, 'configs[%d]' % (cfg - 1)),
+                       'strong_1e6': 'strong: configs[3], 1e6 samples in total over the %d GPU(s)' % world,
+                       'target': '>= 7x the n_gpus=1 figure of the same series at n_gpus=8 (BASELINE.json north_star)'},
             'ranks': ranks,
             # the same rate counting the simulated steps only (the warm-up replays W of them)
             'value_without_warmup': n_runs_total * T * args.steps / elapsed,

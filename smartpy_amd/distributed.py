@@ -51,6 +51,13 @@ def init(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None and use_gpu and world > torch.cuda.device_count():
+            # more ranks than devices (a one-GPU box running the N-rank code path): RCCL refuses two ranks on one
+            # device, gloo stages the small result blocks through the host.  The bench line's `ranks.backend` says so.
+            import warnings
+            warnings.warn("smartpy_amd.distributed: %d ranks on %d device(s): collectives go through gloo, not RCCL"
+                          % (world, torch.cuda.device_count()))
+            backend = 'gloo'
         # lazy communicator creation (no device_id): the first collective binds RCCL to the current device, set above
         dist.init_process_group(backend=backend or ('nccl' if use_gpu else 'gloo'), rank=rank, world_size=world)
     return rank, world, device

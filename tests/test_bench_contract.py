@@ -57,6 +57,41 @@ def test_pmc_figures_are_only_quoted_for_the_code_they_were_measured_on(tmp_path
         assert 0 < entry['issue_frac_at_held_clock'] <= 1.0 and entry['valu_insts_per_launch'] > 0
 
 
+def test_bench_started_bare_with_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the way the driver starts N = 1) must not
+    exit with "launch with torch.distributed.run": it becomes the launcher of its two ranks and relays their return
+    code.  Without a GPU the ranks themselves stop at "bench.py needs a GPU" -- which is the evidence that they ran."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('on a GPU box the GPU test below runs the same command to the end')
+    assert r.returncode != 0
+    assert b'bench.py needs a GPU' in r.stderr and b'launch with torch.distributed.run' not in r.stderr
+    assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')]
+
+
+@pytest.mark.gpu
+def test_bench_bare_command_with_two_gpus_spawns_two_ranks():
+    """The driver's SCALE command may mirror its N = 1 command (no launcher): one JSON line, two ranks, two pids.  On
+    a one-GPU box both ranks share GPU 0 and distributed.init() picks gloo by itself (more ranks than devices)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'SMART_DIST_BACKEND')}
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
+                                   '--warmup', '1', '--samples', '20000', '--no-flat', '--no-strong',
+                                   '--no-cpu-baseline'], cwd=ROOT, env=env, stderr=subprocess.DEVNULL,
+                                  timeout=900).decode()
+    lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    r = d['ranks']
+    assert d['n_gpus'] == 2 and r['world_size'] == 2 and len({x['pid'] for x in r['ranks']}) == 2
+    import torch
+    assert r['backend'] == ('nccl' if torch.cuda.device_count() >= 2 else 'gloo')
+    assert r['rccl_version'] and all('current_device' in x for x in r['ranks'])
+    assert d['series']['value'].startswith('weak') and 'strong' in d['series']['strong_1e6']
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_fields():
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1',
