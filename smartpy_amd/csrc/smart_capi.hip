@@ -240,7 +240,10 @@ __global__ void smart_classify_forcing(KArgs a, int *hdr)
 }
 
 // ---- per-device context: what the library caches about a device, and the streams a multi-kernel launch forks onto
-constexpr int kMaxDevices = 64, kMaxAux = 4;
+// A call launches at most kMaxTodo kernels side by side: up to three kernels of the regular rows (one per kind of
+// forcing among the catchments: piecewise, runs, varying) + the stiff, guard and ill-conditioned classes = 6; the first
+// runs on the caller's stream, each other one on an auxiliary stream of its own.
+constexpr int kMaxDevices = 64, kMaxTodo = 8, kMaxAux = kMaxTodo - 1;
 
 struct DeviceCtx {
     std::once_flag once;
@@ -521,8 +524,16 @@ static hipError_t launch_kernel(FastKernel k, KArgs a, dim3 grid, size_t lds, hi
 // What a SMART_MATH_FAST call launches: the kernels (smart_fast_entry.h), sliced or not, and the load figures behind
 // the choices.  Shared by the launch itself and by smart_describe_launch.
 struct Decision {
-    Launch todo[kMaxAux + 1];
+    Launch todo[kMaxTodo];
     int n_todo = 0;
+    bool overflow = false;
+    void push(FastKernel k, bool sliced)
+    {
+        if (n_todo < kMaxTodo)
+            todo[n_todo++] = {k, sliced};
+        else
+            overflow = true;
+    }
     int n_seg = 1, per_simd = 0, exits = 0;
     int class_mask = 0, pc_mask = 0;
     bool intervals = false;
@@ -551,27 +562,29 @@ static int decide(const SmartEnsemble *e, const DeviceCtx *d, const Workspace &w
     if (plan & SMART_PLAN_CLASS_REGULAR) {
         if (x.intervals) {
             if (plan & SMART_PLAN_FORCING_PIECEWISE) {
-                x.todo[x.n_todo++] = {e->final_vars ? kIntervalsStates : (x.exits ? kIntervalsExits : kIntervals), true};
+                x.push(e->final_vars ? kIntervalsStates : (x.exits ? kIntervalsExits : kIntervals), true);
                 x.pc_mask |= 1;
             }
             if (plan & SMART_PLAN_FORCING_RUNS) {
-                x.todo[x.n_todo++] = {e->final_vars ? kRunsStates : (x.exits ? kRunsExits : kRuns), true};
+                x.push(e->final_vars ? kRunsStates : (x.exits ? kRunsExits : kRuns), true);
                 x.pc_mask |= 4;
             }
             if (plan & SMART_PLAN_FORCING_VARYING) {
-                x.todo[x.n_todo++] = {e->final_vars ? kStepsStates : kSteps, true};
+                x.push(e->final_vars ? kStepsStates : kSteps, true);
                 x.pc_mask |= 2;
             }
         } else {
-            x.todo[x.n_todo++] = {kPlain, false};
+            x.push(kPlain, false);
         }
     }
     if (plan & SMART_PLAN_CLASS_STIFF)
-        x.todo[x.n_todo++] = {kStiff, false};
+        x.push(kStiff, false);
     if (plan & SMART_PLAN_CLASS_GUARD)
-        x.todo[x.n_todo++] = {kGuard, false};
+        x.push(kGuard, false);
     if (plan & SMART_PLAN_CLASS_ILLCOND)
-        x.todo[x.n_todo++] = {kIllCond, false};
+        x.push(kIllCond, false);
+    if (x.overflow)
+        return fail(SMART_E_SIZE, "internal: a call wants more than %d kernels", kMaxTodo);
     if (x.n_todo == 0)
         return fail(SMART_E_SIZE, "the plan names no class of rows");
     return SMART_OK;

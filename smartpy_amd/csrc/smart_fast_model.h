@@ -1019,8 +1019,12 @@ __device__ inline int wave_class(const KArgs &a, long block, long catchment)
             if (i >= 5 && i < 11)
                 lay += ip[i];
         }
-        if (!wild) // (numbers from here on: the compare is safe under -fno-honor-nans)
-            wild = !(p[4] * (lay / a.area[catchment] * 1e3) / p[5] <= 0.5);
+        if (!wild) { // (finite numbers in; the quotient can still be a NaN -- area 0, 0 * inf -- and this function is
+                     // compiled with and without -fno-honor-nans: the NaN is tested on its bit pattern, like the host does
+                     // by `~(s <= 0.5)` on honest IEEE arithmetic)
+            const double s_init = p[4] * (lay / a.area[catchment] * 1e3) / p[5];
+            wild = is_nan_bits(s_init) || !(s_init <= 0.5);
+        }
     }
     const bool any_stiff = __builtin_amdgcn_ballot_w64(stiff) != 0;
     const bool any_guard = __builtin_amdgcn_ballot_w64(guard) != 0;

@@ -19,9 +19,17 @@
 // returns the correctly rounded quotient RN(a / b) -- THE SAME BITS as the division -- for every a, unless b's
 // significand is all ones (P. Markstein, IBM J. Res. Dev. 34 (1990), Theorem 4.2; the tail of hipcc's own division
 // sequence is this step) or the computation leaves the normal range (r is exact only while a - b q0 is representable:
-// |a| >= 2^-969 is enough).  Both conditions are checked, wave-uniformly: the divisors once per run, the twelve
-// states and the step's forcing once per chunk of four steps against [2^-800, 2^800] (a state shrinks by 2^-53 per
-// step at most: (1 - dt/k) of a double dt/k < 1); a wave that fails takes the true divisions for that chunk.  What is
+// |a| >= 2^-969 is enough).  The theorem wants y correctly rounded (it is: one true division) and q0 within an ulp of
+// a / b; RN(a y) is NOT always that close (two roundings of relative size 2^-53 are up to two ulps of a quotient whose
+// significand is next to 2: the remainder then needs 54 bits and the FMA rounds it) -- the claim of bit identity
+// rests on the theorem where its hypothesis holds AND on comparisons: tests/test_host_logic.py replays the three
+// operations in exact rational arithmetic on 1.5e5 pairs drawn to stress them (significands next to 1 and 2, divisors
+// of the model's kind): the remainder is inexact on 0.9 % of them and the quotient is the division's on all; and
+// tools/debug/recip_bits.py compared 5.5e7 kernel outputs with the true divisions (profiles/r03_recip_bits.txt): 0
+// differ.  Both conditions are checked, wave-uniformly: the divisors once per run ([2^-500, 2^500]), the twelve
+// states and the step's forcing once per chunk of four steps against [2^-400, 2^400) (a state shrinks by 2^-53 per
+// step at most: (1 - dt/k) of a double dt/k < 1) -- every quotient and every remainder then stays a normal number;
+// a wave that fails takes the true divisions for that chunk.  What is
 // NOT checked are numerators formed inside the step from products with tiny factors (a leak l s'^6 with s' ~ 1e-50):
 // a quotient of a numerator below 2^-969 may differ in its last bit -- of a number that is zero to any hydrologist.
 // tests/test_gpu_parity.py keeps comparing the kernel with the literal kernel (true divisions throughout) bit for bit.
@@ -101,11 +109,14 @@ struct LiteralModelT {
         }
     }
 
-    // 0 or within [2^-800, 2^800): nothing of what this step divides leaves the normal range
+    // 0 or within [2^-400, 2^400): with the divisors in [2^-500, 2^500] every quotient a / b of the step, and the
+    // remainder a - b q0 of its correction step (~ 2^-53 a), stays a NORMAL number (>= 2^-953) -- the exact-remainder
+    // assumption of the correction step, and what keeps subnormal layers (whose unguarded leak would round differently)
+    // off this path.  (Round 3 admitted [2^-800, 2^800): quotients down to 2^-1300, i.e. subnormal or zero -- advisor.)
     __device__ __forceinline__ static bool in_range(double x)
     {
         const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-        return u == 0 || u - 0x0df0000000000000ull < 0x6400000000000000ull;
+        return u == 0 || u - 0x26f0000000000000ull < 0x3200000000000000ull;
     }
 
     // ahead of a chunk of (at most) four steps, with their forcing

@@ -208,12 +208,30 @@ class ShardedEnsemble(object):
         return gather_rows(self._packed[:per], self.n_total, out=self._gathered)
 
     def verify(self):
-        """Status word of this rank's last launch (engine.PreparedEnsemble.verify).  When ANY rank had to repeat its
-        launch (a time slice that timed out, a stale plan) the matrix step() gathered holds that rank's NaN rows:
-        every rank then packs and gathers again, and the fresh [N, 9] / [C, N, 9] matrix is returned; None when the
-        matrix already returned by step() stands."""
-        out = self._prep.verify()
-        if max_over_ranks(1.0 if self._prep.repeated else 0.0, self.device) > 0.0:
+        """Status word of this rank's last launch (engine.PreparedEnsemble.verify), agreed over the ranks.
+
+        Returns None when the matrix step() returned stands on every rank; the freshly gathered [N, 9] / [C, N, 9]
+        matrix when ANY rank had to repeat its launch (a time slice that timed out, a stale plan: the matrix step()
+        gathered holds that rank's NaN rows, so every rank packs and gathers again).  (Not the EnsembleResult that
+        PreparedEnsemble.verify() returns: this rank's own outputs are `prepared.result()`.)
+
+        A rank whose repeated launch is not clean either raises SmartEngineError -- and so does every other rank, in
+        the same call: the outcome travels in the one reduction this method makes, so that no rank is left waiting in
+        a collective its failed peer never joins."""
+        from .engine import SmartEngineError
+        failure, out = None, None
+        try:
+            out = self._prep.verify()
+        except SmartEngineError as e:
+            failure = e
+        code = 2.0 if failure is not None else (1.0 if self._prep.repeated else 0.0)
+        worst = max_over_ranks(code, self.device)
+        if failure is not None:
+            raise failure
+        if worst >= 2.0:
+            raise SmartEngineError(-6, "smartpy_amd: another rank's repeated launch still reports a status; the "
+                                       "gathered results are not complete")
+        if worst >= 1.0:
             return self._pack_and_gather(out)
         return None
 

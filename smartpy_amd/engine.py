@@ -106,7 +106,10 @@ def variant_classes(params, delta_sec, initial=None, area=None):
         st = initial.reshape(-1, params.shape[0], 12)
         ar = torch.as_tensor(area, dtype=torch.float64, device=params.device).reshape(-1, 1)
         bad = (~torch.isfinite(st) | (st < 0.0)).any(dim=2)                  # (-0.0 is a zero like any other)
-        s_init = params[:, 4].unsqueeze(0) * (st[:, :, 5:11].sum(dim=2) / ar * 1e3) / params[:, 5].unsqueeze(0)
+        lay = torch.zeros_like(st[:, :, 5])         # summed in wave_class()'s order: 0.0 + ly1 + ... + ly6, left to right
+        for i in range(5, 11):
+            lay = lay + st[:, :, i]
+        s_init = params[:, 4].unsqueeze(0) * (lay / ar * 1e3) / params[:, 5].unsqueeze(0)
         bad = bad | ~(s_init <= 0.5)
         cls[bad.any(dim=0)] = 3
     return cls

@@ -81,7 +81,7 @@ def best_rows(sort_fn, constrained, nb_best):
         idx = torch.nonzero(constrained, as_tuple=False)[:, 0]
         keys = sort_fn[idx]
         order = torch.argsort(keys, stable=True)
-        picked = order[-nb_best:] if nb_best > 0 else order[:0]
+        picked = order[-nb_best:]       # (nb_best = 0: every constrained row, like best.py:287's `[-0:]` on the host)
         edge = keys[order[-nb_best - 1:]] if 0 < nb_best < order.numel() else keys[picked]
         tied = ((edge[1:] == edge[:-1]) | (torch.isnan(edge[1:]) & torch.isnan(edge[:-1]))).any() \
             if edge.numel() > 1 else False

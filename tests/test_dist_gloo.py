@@ -230,6 +230,16 @@ class _FlakyPrepared(_OraclePrepared):
         return self._last
 
 
+class _BrokenPrepared(_OraclePrepared):
+    """... whose verify() gives up on rank 1 (the repeated launch reports a status as well)."""
+
+    def verify(self):
+        if dist.is_initialized() and dist.get_rank() == 1:
+            from smartpy_amd.engine import SmartEngineError
+            raise SmartEngineError(-6, 'the repeated launch reports status 0x1 as well')
+        return self._last
+
+
 def _sharded_setup():
     rng = np.random.default_rng(5)
     C, N, days = 5, 6, 40
@@ -283,6 +293,19 @@ def _worker_sharded(rank, world, port, out_dir):
         assert flaky.verify() is None                   # nothing to repeat the second time
     else:
         assert again is None and torch.equal(first, got_s)
+    # a rank whose repeated launch fails too: EVERY rank raises, in the same verify() call -- none is left waiting in
+    # a reduction or a gather its failed peer never joins (advisor, round 3)
+    if world > 1:
+        engine.prepare_ensemble = _BrokenPrepared
+        broken = sdist.ShardedEnsemble(params, forcing[1], areas[1], 3600.0, 240, 24, axis='samples', obs=obs[1],
+                                       gw_obs=float(gw_obs[1]), extra=extra, device='cpu')
+        broken.step()
+        try:
+            broken.verify()
+            raise AssertionError('rank %d: verify() returned although rank 1 failed' % rank)
+        except engine.SmartEngineError as e:
+            assert ('another rank' in str(e)) == (rank == 0)
+        dist.barrier()                                  # both ranks are still in step with each other
     np.savez(os.path.join(out_dir, 'sharded_w%d_r%d.npz' % (world, rank)), c=got_c.numpy(), s=got_s.numpy(),
              w=got_w.numpy())
     if world > 1:

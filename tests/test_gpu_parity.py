@@ -1481,6 +1481,47 @@ def test_several_kernels_of_one_call_capture_into_a_hip_graph(eng):
         assert torch.equal(out.discharge, ref_dis) and torch.equal(out.gw, ref_gw)
 
 
+def test_a_call_without_a_plan_launches_every_kernel_it_could_need(eng):
+    """plan = 0 (a zeroed struct from C; a prepare_ensemble() inside a graph capture; the answer to a stale plan) in
+    summary mode with gap >= 2 expands to all three kinds of forcing + the three other row classes: six kernels side
+    by side, one more than the auxiliary streams of round 3 could take (advisor, round 3: a write past the end of
+    Decision::todo).  Three catchments -- daily values spread over the hours, 6-hourly values, hourly values -- and
+    rows of all four classes; the same bits as the planned call, whole and captured into a HIP graph."""
+    import torch
+    import bench
+    dev = torch.device('cuda:0')
+    base = bench.synthetic_forcing(0, hourly=True)[0][:24 * 200]
+    f = torch.as_tensor(np.stack([base, bench.six_hourly_forcing(base), bench.hourly_varying_forcing(base)]), device=dev)
+    rows = lhs_oracle.lhs_params(640, seed=77)
+    rows[64:128, 6] = 0.4           # SK < 1 h: stiff
+    rows[128:192, 4] = 0.7          # S > 0.5: guard
+    rows[192:256, 9] = 0.3          # RK < dt / 2: ill-conditioned
+    params = torch.as_tensor(rows, device=dev)
+    obs = np.abs(np.random.default_rng(5).normal(2.0, 1.0, 200))
+    kw = dict(extra=bench.EXTRA, obs=np.tile(obs, (3, 1)), gw_obs=0.15, group_variants=False)
+    planned = eng.prepare_ensemble(params, f, bench.AREA, 3600.0, 24 * 20, 24, **kw)
+    assert planned.describe().count('smart_fast_') == 6
+    want = planned.launch()
+    assert planned.status() == 0
+    want = (want.discharge.clone(), want.gw.clone(), want.objfn.clone())
+    blind = eng.prepare_ensemble(params, f, bench.AREA, 3600.0, 24 * 20, 24, **kw)
+    blind._e.plan = 0
+    assert blind.describe().count('smart_fast_') == 6
+    got = blind.launch()
+    assert blind.status() == 0
+    assert torch.equal(got.discharge, want[0]) and torch.equal(got.gw, want[1]) and torch.equal(got.objfn, want[2])
+    torch.cuda.synchronize()
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            blind.launch()
+    blind._dis.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    out = blind._result()
+    assert torch.equal(out.discharge, want[0]) and torch.equal(out.gw, want[1])
+
+
 def test_concurrent_launches_from_two_threads_on_two_streams(eng):
     """include/smart_amd.h promises that calls on different streams may run concurrently.  Two host threads, each with
     its own stream, workspace and outputs, launch at the same time -- a daily ensemble (three kernels forked onto the

@@ -624,3 +624,47 @@ def test_host_side_native_code_under_sanitizers(tmp_path, sanitizers):
                        env=dict(os.environ, ASAN_OPTIONS='detect_leaks=1'))
     assert r.returncode == 0 and 'hostio sanitize ok' in r.stdout, r.stdout + r.stderr
     assert 'Sanitizer' not in r.stderr and 'runtime error' not in r.stderr
+
+
+def test_reciprocal_correction_step_gives_the_bits_of_the_division():
+    """csrc/smart_literal_model.h (RECIP): q0 = RN(a y); r = a - b q0 [exact: one FMA]; q = RN(q0 + r y) with
+    y = RN(1 / b) is claimed to be RN(a / b) for every normal a unless b's significand is all ones.  The three
+    operations replayed in exact rational arithmetic (fractions: RN = float(Fraction), round-half-even) on pairs drawn
+    to stress them: significands next to 1 and next to 2 on either side, random ones, and divisors of the model's own
+    kind (k * 3600, areas, 1e3, 2 ... 6, step lengths).  (The remainder is NOT always exact: q0 can be more than an
+    ulp off when the quotient's significand is next to 2, ~1 % of these pairs; the final rounding still lands on the
+    division's result in every case -- which is what the kernel relies on, and what this test pins.)"""
+    from fractions import Fraction
+    rng = np.random.default_rng(20261003)
+    n = 40000
+
+    def near(edge, count):            # significands within a few hundred ulps of 1.0 (edge 0) or 2.0 (edge 1)
+        k = rng.integers(0, 400, count).astype(np.float64) * 2.0 ** -52
+        return (1.0 + k) if edge == 0 else (2.0 - 2.0 ** -52 - k)
+
+    def scaled(sig, count):
+        return sig * 2.0 ** rng.integers(-300, 300, count)
+
+    kinds = [(scaled(rng.uniform(1.0, 2.0, n), n), scaled(rng.uniform(1.0, 2.0, n), n))]
+    for ea in (0, 1):
+        for eb in (0, 1):
+            kinds.append((scaled(near(ea, n // 4), n // 4), scaled(near(eb, n // 4), n // 4)))
+    model_b = np.concatenate([rng.uniform(1, 2000, n // 4) * 3600.0, rng.uniform(1e4, 1e10, n // 4),
+                              np.tile([1e3, 2.0, 3.0, 4.0, 5.0, 6.0, 3600.0, 86400.0, 900.0], n // 36)])
+    kinds.append((rng.uniform(0.0, 1e9, len(model_b)) * rng.uniform(0, 1, len(model_b)) ** 8, model_b))
+    kinds.append((scaled(rng.uniform(1.0, 2.0, n), n), rng.integers(1, 1 << 20, n).astype(np.float64)))
+    checked = inexact = 0
+    for a_all, b_all in kinds:
+        for a, b in zip(a_all.tolist(), b_all.tolist()):
+            if a == 0.0 or (np.float64(b).view(np.uint64) & np.uint64(0x000fffffffffffff)) == np.uint64(0x000fffffffffffff):
+                continue
+            fa, fb = Fraction(a), Fraction(b)
+            y = float(1 / fb)
+            q0 = float(fa * Fraction(y))
+            r = float(fa - fb * Fraction(q0))                 # one FMA: a single rounding of the exact remainder
+            inexact += Fraction(r) != fa - fb * Fraction(q0)
+            q = float(Fraction(q0) + Fraction(r) * Fraction(y))
+            assert q == float(fa / fb), (a.hex(), b.hex())
+            checked += 1
+    assert checked > 140000
+    print('inexact remainders', inexact, 'of', checked)
