@@ -831,9 +831,17 @@ __device__ __forceinline__ bool wait_for_slice(const KArgs &a, long slot, int se
     return v >= seg;
 }
 
+// Producer side of the hand-over, in the order MI355X_MICROARCH.md prescribes for plain payload stores: this wave's
+// stores drained (s_waitcnt vmcnt(0)) -> agent-scope release (buffer_wbl2 sc1: the XCD's L2 writes its dirty lines
+// back) -> s_waitcnt vmcnt(0) AGAIN, as inline asm -> relaxed agent-scope flag store.  The fence's own wait is one
+// hipcc (ROCm 7.2) drops when it can prove the wave's vmcnt scoreboard empty, and then the flag can overtake the
+// write-back; inline asm is invisible to that pass.  tests/test_handover_isa.py disassembles every sliced kernel of
+// the built library and checks that the wait is there (and the buffer_inv sc1 behind every poll).
 __device__ __forceinline__ void publish_slice(const KArgs &a, long slot, int seg, bool good)
 {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0)
         __hip_atomic_store(a.seg_flag + slot, good ? seg + 1 : -(seg + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
