@@ -468,6 +468,30 @@ def main():
                 'kernel': lean.describe(), 'launch_ms': l_ms, 'value': units_per_launch / (l_ms * 1e-3),
                 'unit': 'sample-timesteps/s'}
             del lean
+        if world == 1 and cfg == 3 and not args.no_flat and args.math == 'fast':
+            # the two report modes of the reference that are not interval means (structure.py:192-195 and :190 with a
+            # report every step), on the headline's runs and forcing, objective functions fused, no matrix stored.
+            # Round 3 ran both through the general step loop, unsliced (24.8 / 43.7 ms)
+            raw = engine.prepare_ensemble(d_params, d_forcing, AREA, dt, W, gap, obs=obs, gw_obs=GW_OBS, report='raw',
+                                          **dict(kw, want_discharge=False))
+            _, w_ms, _ = timed_steps(raw.launch, max(2, args.steps // 2), 1, device)
+            raw.verify()
+            line['raw_gap24'] = {
+                'what': "same runs with report='raw' (the outflow of each day's last hour, groundwater ratio from those "
+                        "steps only): the interval engine over 23 + 1 steps",
+                'kernel': raw.describe(), 'launch_ms': w_ms, 'value': units_per_launch / (w_ms * 1e-3),
+                'unit': 'sample-timesteps/s'}
+            del raw
+            every = engine.prepare_ensemble(d_params, d_forcing, AREA, dt, W, 1, obs=np.repeat(obs, gap),
+                                            gw_obs=GW_OBS, **dict(kw, want_discharge=False))
+            _, e_ms, _ = timed_steps(every.launch, max(2, args.steps // 2), 1, device)
+            every.verify()
+            line['gap1'] = {
+                'what': 'same runs with a report every step (hourly reports of the hourly run, %d observations): '
+                        'single-step arms with the objective-function moments between them' % (R * gap),
+                'kernel': every.describe(), 'launch_ms': e_ms, 'value': units_per_launch / (e_ms * 1e-3),
+                'unit': 'sample-timesteps/s'}
+            del every
         if not args.no_cpu_baseline:
             # rank 0's host cores and rank 0's GPU, whatever the world size (the other ranks wait at the barrier below)
             line['cpu_baseline'], line['parity'] = cpu_baseline_and_parity(forcing, W, gap, dt, device)

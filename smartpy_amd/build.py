@@ -23,6 +23,7 @@ UNITS = {
     'smart_fast_intervals.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
     'smart_fast_runs.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
     'smart_fast_steps.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
+    'smart_fast_reports.hip': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
     # ... except where the literal model lives inside the fast mode (the ill-conditioned rows and rows with NaN or
     # infinite parameters): NaNs honoured -- what a NaN does in the reference's compares is part of what it reproduces
     'smart_fast_guarded.hip': ['-ffp-contract=fast-honor-pragmas'],

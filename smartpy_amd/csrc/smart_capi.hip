@@ -279,13 +279,16 @@ static const void *fast_kernel(FastKernel k)
         return f;
     if (const void *f = fast_kernel_runs(k))
         return f;
+    if (const void *f = fast_kernel_reports(k))
+        return f;
     return fast_kernel_guarded(k);
 }
 
 static const char *const kFastKernelNames[kNumFastKernels] = {
     "smart_fast_intervals_exits", "smart_fast_intervals", "smart_fast_intervals_states", "smart_fast_steps",
     "smart_fast_steps_states", "smart_fast_plain", "smart_fast_stiff", "smart_fast_guard", "smart_fast_illcond",
-    "smart_fast_runs_exits", "smart_fast_runs", "smart_fast_runs_states"};
+    "smart_fast_runs_exits", "smart_fast_runs", "smart_fast_runs_states", "smart_fast_steps_raw",
+    "smart_fast_intervals_raw", "smart_fast_steps_every"};
 
 // dynamic LDS that lets exactly `per_cu` workgroups of kernel k be resident on a CU (0: no such size); d->mu held
 static size_t lds_for_residency(DeviceCtx *d, FastKernel k, int per_cu)
@@ -386,6 +389,24 @@ static int device_ready()
     return SMART_OK;
 }
 
+// Which of the merged (sliceable) families take the regular rows of a call (run_ensemble_merged<..., REPORT>):
+//   kReportMean   summary reports over intervals of two or more steps
+//   kReportLast   raw reports over whole intervals (W and T multiples of the gap), final state vector not asked for
+//   kReportEvery  a report every step (gap 1, either type), final state vector not asked for
+// -1: none (smart_fast_plain: raw reports over a ragged time axis; raw / every-step reports with the final state vector)
+static int merged_report(const SmartEnsemble *e)
+{
+    if (e->report_type == SMART_REPORT_SUMMARY && e->report_gap >= 2)
+        return kReportMean;
+    if (e->final_vars)
+        return -1;
+    if (e->report_gap == 1)
+        return kReportEvery;
+    if (e->report_type == SMART_REPORT_RAW && e->n_steps % e->report_gap == 0 && e->n_warm % e->report_gap == 0)
+        return kReportLast;
+    return -1;
+}
+
 // Time-sliced launch or not?  Whenever there are more blocks of 64 samples than SIMDs and the interval engine's
 // preconditions hold (summary report, merged variant): pinned to one SIMD for the whole run, B blocks on S SIMDs last
 // ceil(B / S) block-times -- 1e5 samples: 1,563 on 1,024 -> 2 against the 1.53 of a perfect split -- and above the
@@ -399,7 +420,7 @@ static int plan_time_slices(const SmartEnsemble *e, int n_simd, int *per_simd, d
     const long cap = (blocks + n_simd - 1) / n_simd;
     *per_simd = (int)(cap < 1 ? 1 : cap); // blocks of 64 samples per SIMD, rounded up
     *load = (double)blocks / (double)n_simd;
-    if (e->report_type != SMART_REPORT_SUMMARY || e->report_gap < 2)
+    if (merged_report(e) < 0)
         return 1;
     const long n_all = e->n_warm / e->report_gap + e->n_steps / e->report_gap;
     int forced = e->time_slices;
@@ -482,7 +503,8 @@ static KArgs kernel_args(const SmartEnsemble *e, const Workspace &w)
     a.fflags = nullptr;
     // the run lengths the forcing is tested for: the kMaxDiv largest divisors of the report gap, largest first, down
     // to 2 -- gap / q for q = 1, 2, 3, ... (at most sqrt(gap) trial divisions, whatever the gap)
-    if (a.report_type == SMART_REPORT_SUMMARY && a.gap >= 2 && a.gap <= 0x7fffffff) {
+    const int merged = merged_report(e);
+    if ((merged == kReportMean || merged == kReportLast) && a.gap <= 0x7fffffff) {
         for (long q = 1; q * q <= a.gap && a.n_div < kMaxDiv; ++q)
             if (a.gap % q == 0 && a.gap / q >= 2)
                 a.div[a.n_div++] = (int)(a.gap / q);
@@ -536,14 +558,16 @@ struct Decision {
     }
     int n_seg = 1, per_simd = 0, exits = 0;
     int class_mask = 0, pc_mask = 0;
-    bool intervals = false;
+    int report = -1;        // merged_report(): which merged family takes the regular rows (-1: smart_fast_plain)
+    bool intervals = false; // report == kReportMean
     double load = 0.0; // blocks of 64 samples per SIMD
 };
 
 static int decide(const SmartEnsemble *e, const DeviceCtx *d, const Workspace &w, Decision *out)
 {
     Decision &x = *out;
-    x.intervals = e->report_type == SMART_REPORT_SUMMARY && e->report_gap >= 2; // the merged summary kernels apply
+    x.report = merged_report(e);
+    x.intervals = x.report == kReportMean; // the merged summary kernels apply
     const int plan = (e->plan & SMART_PLAN_VALID) ? e->plan : (0x3f | SMART_PLAN_FORCING_RUNS);
     x.n_seg = plan_time_slices(e, d->n_simd, &x.per_simd, &x.load);
     // the hand-over buffer of a time-sliced launch sits behind the observation statistics in the caller's workspace;
@@ -573,6 +597,18 @@ static int decide(const SmartEnsemble *e, const DeviceCtx *d, const Workspace &w
                 x.push(e->final_vars ? kStepsStates : kSteps, true);
                 x.pc_mask |= 2;
             }
+        } else if (x.report == kReportLast) {
+            if (plan & SMART_PLAN_FORCING_PIECEWISE) {
+                x.push(kIntervalsRaw, true);
+                x.pc_mask |= 1;
+            }
+            if (plan & (SMART_PLAN_FORCING_RUNS | SMART_PLAN_FORCING_VARYING)) {
+                x.push(kStepsRaw, true);
+                x.pc_mask |= 6;
+            }
+        } else if (x.report == kReportEvery) {
+            x.push(kStepsEvery, true);
+            x.pc_mask = 7;
         } else {
             x.push(kPlain, false);
         }
@@ -640,7 +676,7 @@ static int run(const SmartEnsemble *e)
         // every fast launch looks at its forcing (the merged kernels for what the flags say about runs of equal
         // values; all of them for the NaN that belongs to the literal kernel: status word)
         scan_forcing(e, a, w, s);
-        if (x.intervals && (x.class_mask & SMART_PLAN_CLASS_REGULAR))
+        if (x.report >= 0 && (x.class_mask & SMART_PLAN_CLASS_REGULAR))
             a.fflags = a_sliced.fflags = w.fflags;
     }
 
@@ -748,7 +784,7 @@ static int make_plan(const SmartEnsemble *e, int32_t *plan)
     KArgs a = kernel_args(e, w);
     reset_workspace(w, e->n_catchments, nullptr, 0, s);
     hipLaunchKernelGGL(smart_classify_rows, dim3((unsigned)a.n_blocks, (unsigned)e->n_catchments), dim3(kWave), 0, s, a);
-    if (e->report_type == SMART_REPORT_SUMMARY && e->report_gap >= 2) {
+    if (merged_report(e) == kReportMean || merged_report(e) == kReportLast) {
         scan_forcing(e, a, w, s);
         a.fflags = w.fflags;
         hipLaunchKernelGGL(smart_classify_forcing, dim3((unsigned)((e->n_catchments + 255) / 256)), dim3(256), 0, s,

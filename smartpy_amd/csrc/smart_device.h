@@ -60,7 +60,7 @@ struct KArgs {
     int debug_drop = 0;          // test knob: slice 0 of block 0 never publishes (its successors must time out)
 };
 
-constexpr int kSegFields = 23;
+constexpr int kSegFields = 23; // 0-14 model states (13, 14: SPLIT only), 15 pending demand, 16 sum of outflows, 17-22 moments
 constexpr int kHdrInts = 64;      // workspace header: [0] status word, [1 + k] ticket counter of sliced kernel k
 constexpr int kHdrStatus = 0, kHdrTicket = 1;
 constexpr int kStatusSliceTimeout = 1, kStatusStalePlan = 2, kStatusNonFiniteForcing = 4; // = SMART_STATUS_* of include/smart_amd.h
@@ -284,7 +284,7 @@ __device__ __forceinline__ void time_loop_lazy(Model &m, const double2 *__restri
 // The walk of the instruction-level step loop (Model::step_arms: one of three asm arms per step, picked on the scalar
 // unit from the step's own forcing).  Same double-buffered scalar loads; the loop counter is 32 bits wide (there is no
 // 64-bit scalar less-than: hipcc went through a vector compare for it).
-template <bool QUICK, class Model, class ChunkEnd>
+template <bool QUICK, bool LAST = false, class Model, class ChunkEnd>
 __device__ __forceinline__ void time_loop_arms(Model &m, const double2 *__restrict__ f, long n, double &acc,
                                                ChunkEnd &&chunk_end)
 {
@@ -307,11 +307,11 @@ __device__ __forceinline__ void time_loop_arms(Model &m, const double2 *__restri
             nxt[j] = f[pre + j];
 #if SMART_CHUNK_THREADED
         static_assert(kChunk == 4, "SMART_A_CHUNK threads four steps");
-        m.template chunk_arms<QUICK>(cur, acc);
+        m.template chunk_arms<QUICK, LAST>(cur, acc);
 #else
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
-            m.template step_arms<QUICK>(cur[j], acc);
+            m.template step_arms<QUICK, LAST>(cur[j], acc);
 #endif
         chunk_end();
 #pragma unroll
@@ -319,7 +319,43 @@ __device__ __forceinline__ void time_loop_arms(Model &m, const double2 *__restri
             cur[j] = nxt[j];
     }
     for (long t = (long)n_chunks * kChunk; t < n; ++t)
-        m.template step_arms<QUICK>(f[t], acc);
+        m.template step_arms<QUICK, LAST>(f[t], acc);
+}
+
+// The same walk with something to do after EVERY step (a report every step: gap 1): single-step arms with the routing
+// of SMART_A_ROUTE_LAST, so that `acc` holds the outflow of the step just taken when step_end() looks at it.
+template <bool QUICK, class Model, class StepEnd>
+__device__ __forceinline__ void time_loop_arms_each(Model &m, const double2 *__restrict__ f, long n, double &acc,
+                                                    StepEnd &&step_end)
+{
+    const int n_chunks = (int)(n / kChunk);
+    double2 cur[kChunk], nxt[kChunk];
+    if (n_chunks > 0) {
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            cur[j] = f[j];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            asm volatile("" ::"s"(cur[j].x), "s"(cur[j].y));
+    }
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        const int pre = (ch + 1 < n_chunks ? ch + 1 : ch) * kChunk; // last chunk: harmless re-load of itself
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            nxt[j] = f[pre + j];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+            m.template step_arms<QUICK, true>(cur[j], acc);
+            step_end();
+        }
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+            cur[j] = nxt[j];
+    }
+    for (long t = (long)n_chunks * kChunk; t < n; ++t) {
+        m.template step_arms<QUICK, true>(f[t], acc);
+        step_end();
+    }
 }
 
 // A stretch of `n_iv` whole report intervals of `gap` steps, walked by the arm loop; interval_end() after each.
@@ -330,7 +366,7 @@ __device__ __forceinline__ void time_loop_arms(Model &m, const double2 *__restri
 // address is a pointer that is only ever incremented, and nothing is clamped: the stretch streams through all its
 // intervals but -- when it ends where the catchment's forcing ends -- the last one, which the clamped loop above
 // takes (a prefetch must never read past the array).
-template <bool QUICK, class Model, class IntervalEnd>
+template <bool QUICK, bool LAST = false, class Model, class IntervalEnd>
 __device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restrict__ f, long n_iv, long gap,
                                               bool ends_at_array_end, double &acc, IntervalEnd &&interval_end)
 {
@@ -367,19 +403,19 @@ __device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restric
 #pragma unroll
                 for (int j = 0; j < kChunk; ++j)
                     nxt[j] = p[j];
-                m.template chunk_arms<QUICK>(cur, acc);
+                m.template chunk_arms<QUICK, LAST>(cur, acc);
                 arrived(nxt);
                 p += kChunk;
 #pragma unroll
                 for (int j = 0; j < kChunk; ++j)
                     cur[j] = p[j];
-                m.template chunk_arms<QUICK>(nxt, acc);
+                m.template chunk_arms<QUICK, LAST>(nxt, acc);
             }
             interval_end();
         }
     }
     for (long iv = n_stream; iv < n_iv; ++iv) {
-        time_loop_arms<QUICK>(m, f + iv * gap, gap, acc, [] {});
+        time_loop_arms<QUICK, LAST>(m, f + iv * gap, gap, acc, [] {});
         interval_end();
     }
 }
@@ -856,7 +892,18 @@ __device__ __forceinline__ void publish_slice(const KArgs &a, long slot, int seg
 // Any other forcing: the step loop of run_ensemble(), cut at the same report-interval boundaries.
 // FORCING: kForcingIntervals, kForcingRuns (the same engine over runs of `run_len` steps, run_len a divisor of the gap:
 // gap / run_len runs make a report interval, whose mean accumulates across them) or kForcingVarying.
-template <class Model, int FORCING>
+// REPORT: what a report is (round 4 -- before, everything but the mean ran the general step loop of run_ensemble(),
+// unsliced):
+//   kReportMean   the mean of the interval's outflows (report='summary', gap >= 2; structure.py:189-191)
+//   kReportLast   the outflow of the interval's last step (report='raw', gap >= 2, W and T multiples of the gap;
+//                 :192-195), the groundwater ratio from the flows of those steps only.  Varying forcing: the arms with
+//                 SMART_A_ROUTE_LAST, same instruction count as the summary loop.  Piecewise-constant forcing: the
+//                 interval engine over n - 1 steps, a look at the reservoirs, the last step on its own.
+//   kReportEvery  a report every step (gap 1, either report type: a mean over one value is the value, and raw rows are
+//                 all rows): single-step arms with SMART_A_ROUTE_LAST and the report between them.
+constexpr int kReportMean = 0, kReportLast = 1, kReportEvery = 2;
+
+template <class Model, int FORCING, int REPORT = kReportMean>
 __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double2 *__restrict__ forcing,
                                                     const double *__restrict__ obs_all,
                                                     const double *__restrict__ ws_all, long block, long catchment,
@@ -864,6 +911,8 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
 {
     constexpr bool piecewise = FORCING != kForcingVarying; // a template parameter: the sides share no live value
     constexpr bool runs = FORCING == kForcingRuns;
+    static_assert(REPORT == kReportMean || (!Model::kSplit && !runs), "raw / every-step reports: merged model, no runs");
+    static_assert(REPORT != kReportEvery || !piecewise, "a report every step is a step loop");
     const LaneCtx x = lane_ctx(a, block, catchment);
     const long slot = catchment * a.n_blocks + block; // this block's place in seg_state / seg_flag
     Model m;
@@ -871,7 +920,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
     const long gap = a.gap;
     const long run_len = runs ? run_length(a, fflags) : gap; // steps advanced at a time by the interval engine
     if constexpr (piecewise)
-        m.setup_intervals(run_len);
+        m.setup_intervals(REPORT == kReportLast ? run_len - 1 : run_len); // (raw: the dry map stops ahead of the last step)
     const double2 *__restrict__ f = forcing + x.c * a.T;
 
     // A per-lane if / else: a wavefront whose lanes all fall on one side skips the other (s_cbranch_execz); in a mixed
@@ -919,6 +968,31 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         }
     };
 
+    // raw reports: the interval as n - 1 steps, the flows the last step starts from, the last step
+    [[maybe_unused]] auto interval_last = [&](const double2 v, double &qo, double &qg, double &qi) {
+        if constexpr (piecewise && REPORT == kReportLast && Model::kWetAsm) {
+            double sink = 0.0, n0 = 0.0, n1 = 0.0;
+            if (quick && __builtin_bit_cast(unsigned long long, v.x) == 0) {
+                if (__builtin_bit_cast(unsigned long long, v.y) == 0) {
+                    m.calm_interval(gap - 1, sink);
+                    m.last_step_flows(qo, qg, qi);
+                    m.calm_interval(1, sink);
+                } else {
+                    m.dry_interval_last(-v.y, gap, qo, qg, qi);
+                }
+                return;
+            }
+            const double ex = m.excess(v.x, v.y);
+            if (ex < 0.0) {
+                m.dry_interval_last(ex, gap, qo, qg, qi);
+            } else {
+                m.wet_interval(ex, gap - 1, sink, n0, n1, fits);
+                m.last_step_flows(qo, qg, qi);
+                m.wet_interval(ex, 1, sink, n0, n1, fits);
+            }
+        }
+    };
+
     // this workgroup's slice [g0, g1) of the W / gap warm-up intervals followed by the R report intervals
     // (n_seg == 1: everything).  Summary reports need W % gap == 0 (checked on the host, structure.py:190).
     const long n_warm = a.W / gap, n_all = n_warm + a.R;
@@ -930,6 +1004,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
     Reporter rep;
     rep.init(a, x, obs_all, ws_all);
     double num = 0.0, den = 0.0, q_out_total = 0.0;
+    [[maybe_unused]] double num_raw = 0.0, den_raw = 0.0; // raw reports: the two sums over the reported steps (structure.py:194-195)
     double *hand = a.seg_state + (slot * kSegFields) * kWave + x.lane;
     if (seg > 0) {
         if (!wait_for_slice(a, slot, seg)) {
@@ -955,7 +1030,12 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
             return;
         }
         m.load_state(hand, kWave);
-        q_out_total = hand[16 * kWave];
+        if constexpr (REPORT == kReportLast) {
+            num_raw = hand[16 * kWave];
+            den_raw = hand[13 * kWave]; // (fields 13, 14 carry the SPLIT models' extra states: free here)
+        } else {
+            q_out_total = hand[16 * kWave];
+        }
         rep.A = hand[17 * kWave];
         rep.B = hand[18 * kWave];
         rep.C1 = hand[19 * kWave];
@@ -1009,6 +1089,28 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                 ++r;
             }
         });
+    } else if constexpr (piecewise && REPORT == kReportLast) {
+        interval_loop(f, wa, wb, gap, [&](long, const double2 v) { interval_last(v, s0, s1, s2); });
+        if (starts_run)
+            m.begin_run();
+        if (rep.want_obj) {
+            interval_loop_obs(f, rep.obs, rep.ws + kWsHead, ra, rb, gap,
+                              [&](long r, const double2 v, const double e, const double w) {
+                                  double qo, qg, qi;
+                                  interval_last(v, qo, qg, qi);
+                                  rep.emit_prefetched(a, x, r, qo, e, w);
+                                  num_raw += qg;
+                                  den_raw += qi;
+                              });
+        } else {
+            interval_loop(f, ra, rb, gap, [&](long r, const double2 v) {
+                double qo, qg, qi;
+                interval_last(v, qo, qg, qi);
+                rep.emit(a, x, r, qo);
+                num_raw += qg;
+                den_raw += qi;
+            });
+        }
     } else if constexpr (piecewise) {
         interval_loop(f, wa, wb, gap, [&](long, const double2 v) { interval(v, s0, s1, s2); });
         if (starts_run)
@@ -1041,13 +1143,24 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         (void)k;
         double acc = 0.0;
         auto report = [&]() { // end of report interval r (wave-uniform)
-            rep.emit(a, x, r, acc * inv_gap);
-            ++r;
-            k = 0;
-            q_out_total += acc;
-            acc = 0.0;
-            if (Model::kSplit && r == a.R - 1)
-                park_state();
+            if constexpr (REPORT == kReportMean) {
+                rep.emit(a, x, r, acc * inv_gap);
+                ++r;
+                k = 0;
+                q_out_total += acc;
+                acc = 0.0;
+                if (Model::kSplit && r == a.R - 1)
+                    park_state();
+            } else if constexpr (REPORT == kReportLast) { // acc, q_gw, q_in: what SMART_A_ROUTE_LAST left of the last step
+                rep.emit(a, x, r, acc);
+                ++r;
+                num_raw += m.q_gw;
+                den_raw += m.q_in;
+            } else { // every step; the groundwater ratio from the balances, as for the means
+                rep.emit(a, x, r, acc);
+                ++r;
+                q_out_total += acc;
+            }
         };
 #if SMART_STEP_ARMS
         // The three asm arms of FastModel::step_arms.  The shortcuts of the dry and the calm arm need forcing without
@@ -1068,10 +1181,17 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                     if (Model::kSplit && ra == a.R - 1 && rb > ra)
                         park_state();
                 }
-                arm_intervals<Q>(m, f + i0 * gap, i1 - i0, gap, i1 * gap == a.T, acc, [&]() {
-                    if (stretch == 1)
-                        report();
-                });
+                if constexpr (REPORT == kReportEvery) { // (gap == 1: intervals are steps)
+                    if (stretch == 0)
+                        time_loop_arms<Q, true>(m, f + i0, i1 - i0, acc, [] {});
+                    else
+                        time_loop_arms_each<Q>(m, f + i0, i1 - i0, acc, report);
+                } else {
+                    arm_intervals<Q, REPORT == kReportLast>(m, f + i0 * gap, i1 - i0, gap, i1 * gap == a.T, acc, [&]() {
+                        if (stretch == 1)
+                            report();
+                    });
+                }
             }
         };
         if (quick)
@@ -1115,7 +1235,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
 
     if (last) {
         m.balance_sums(q_out_total, num, den);
-        double gw = num / den;
+        double gw = REPORT == kReportLast ? num_raw / den_raw : num / den;
         if constexpr (Model::kSplit) { // replay the last report interval from the parked state, step by step
             double flows[7];
             Model m0 = m;
@@ -1138,7 +1258,12 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         }
     } else {
         m.save_state(hand, kWave);
-        hand[16 * kWave] = q_out_total;
+        if constexpr (REPORT == kReportLast) {
+            hand[16 * kWave] = num_raw;
+            hand[13 * kWave] = den_raw;
+        } else {
+            hand[16 * kWave] = q_out_total;
+        }
         hand[17 * kWave] = rep.A;
         hand[18 * kWave] = rep.B;
         hand[19 * kWave] = rep.C1;

@@ -45,6 +45,18 @@
     "v_fma_f64 %[t0], %[cs], %[ys], %[t0]\n\t"                                                                         \
     "v_add_f64 %[acc], %[acc], %[riv]\n\t"                                                                             \
     "v_fma_f64 %[riv], %[riv], %[oma], %[t0]\n\t"
+// ... for reports that want the river's outflow of ONE step -- raw reports (structure.py:192-195: the last step of each
+// interval) and a report every step (gap 1) -- instead of the interval's sum: the same five instructions, but `acc`
+// ends up holding the outflow of the step just taken (the river's state ahead of its update) and the routing temporary
+// is kept in registers of its own: qi = dt/rk * (the step's inflow to the river, sum of the five catchment outflows),
+// qg = dt/rk * (its groundwater part) -- the two sums behind the groundwater ratio of raw reports (:194-195; the
+// common factor dt/rk cancels in the ratio).  The river update rounds exactly as in SMART_A_ROUTE.
+#define SMART_A_ROUTE_LAST                                                                                             \
+    "v_mul_f64 %[qg], %[cg], %[yg]\n\t"                                                                                \
+    "v_fma_f64 %[qi], %[cf], %[yf], %[qg]\n\t"                                                                         \
+    "v_fma_f64 %[qi], %[cs], %[ys], %[qi]\n\t"                                                                         \
+    "v_mov_b64 %[acc], %[riv]\n\t"                                                                                     \
+    "v_fma_f64 %[riv], %[riv], %[oma], %[qi]\n\t"
 // deferred evaporation cascade over the active lanes (flush_pending): t = d - l; l = max(-t, 0); d = max(C t, 0)
 #define SMART_A_CASCADE                                                                                                \
     "v_add_f64 %[l0], %[pend], -%[l0]\n\t"                                                                             \
@@ -155,18 +167,19 @@
     "v_fma_f64 %[dp], %[l5], %[" SMART_S1 "], %[dp]\n\t"
 #define SMART_A_TOT_XG SMART_A_LSUM("tot") "v_add_f64 %[xg], %[ai], -%[tot]\n\t"
 
-// ---- the three arms.  pe / rn: names of the SGPR operands that hold the step's forcing; casc: the hook of the
-// deferred cascade (SMART_A_CASC_*); deep / split / zeros / drain: what the SPLIT models add ("" otherwise)
-#define SMART_A_DRY(pe, split)                                                                                         \
-    SMART_A_ROUTE "v_add_f64 %[pend], %[pend], %[" pe "]\n\t"                                                          \
+// ---- the three arms.  route: SMART_A_ROUTE (interval sums) or SMART_A_ROUTE_LAST; pe / rn: names of the SGPR operands
+// that hold the step's forcing; casc: the hook of the deferred cascade (SMART_A_CASC_*); deep / split / zeros / drain:
+// what the SPLIT models add ("" otherwise)
+#define SMART_A_DRY(route, pe, split)                                                                                  \
+    route "v_add_f64 %[pend], %[pend], %[" pe "]\n\t"                                                          \
                   "v_fma_f64 %[ys], %[ys], %[ds], 0\n\t"                                                               \
                   "v_fma_f64 %[yf], %[yf], %[df], 0\n\t"                                                               \
                   "v_fma_f64 %[yg], %[yg], %[dg], 0\n\t" split
 #define SMART_A_DRY_SPLIT                                                                                              \
     "v_fma_f64 %[yd], %[yd], %[ds], 0\n\t"                                                                             \
     "v_fma_f64 %[ydg], %[ydg], %[dg], 0\n\t"
-#define SMART_A_CALM(casc, deep, split)                                                                                \
-    "v_cmp_lt_f64 vcc, 0, %[pend]\n\t" SMART_A_ROUTE casc SMART_A_LEAKS(deep) "v_add_f64 %[xf], %[tot], -%[ai]\n\t"    \
+#define SMART_A_CALM(route, casc, deep, split)                                                                         \
+    "v_cmp_lt_f64 vcc, 0, %[pend]\n\t" route casc SMART_A_LEAKS(deep) "v_add_f64 %[xf], %[tot], -%[ai]\n\t"            \
         SMART_A_TOT_XG "v_fma_f64 %[ys], %[ys], %[ds], 0\n\t"                                                          \
                        "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                                      \
                        "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                                      \
@@ -174,11 +187,11 @@
 #define SMART_A_CALM_SPLIT                                                                                             \
     "v_fma_f64 %[yd], %[yd], %[ds], 0\n\t"                                                                             \
     "v_fma_f64 %[ydg], %[ydg], %[dg], %[dp]\n\t"
-#define SMART_A_RAIN(rn, pe, casc, zeros, fill, deep, split)                                                           \
+#define SMART_A_RAIN(route, rn, pe, casc, zeros, fill, deep, split)                                                    \
     "v_mov_b64 %[t1], %[" pe "]\n\t"                                                                                   \
     "v_fma_f64 %[ex], %[" rn "], %[pt], -%[t1]\n\t"                                                                    \
     "v_cmp_le_f64 %[wm], 0, %[ex]\n\t"                                                                                 \
-    "v_cmp_lt_f64 %[tmp], 0, %[pend]\n\t" SMART_A_ROUTE "v_max_f64 %[t1], -%[ex], 0\n\t"                               \
+    "v_cmp_lt_f64 %[tmp], 0, %[pend]\n\t" route "v_max_f64 %[t1], -%[ex], 0\n\t"                                       \
                                                         "v_add_f64 %[pend], %[pend], %[t1]\n\t"                        \
                                                         "v_mov_b64 %[xs], 0\n\t"                                       \
                                                         "v_mov_b64 %[xf], 0\n\t"                                       \
@@ -218,18 +231,18 @@
 // ---- one step ---------------------------------------------------------------------------------------------------
 // dispatch, calm arm (entered by falling through), rain arm, dry arm (left by falling through): one taken branch per
 // calm or dry step, two per rain step
-#define SMART_A_STEP(deep, calm_split, zeros, drain, rain_split, dry_split)                                            \
+#define SMART_A_STEP(route, deep, calm_split, zeros, drain, rain_split, dry_split)                                     \
     "s_cmp_eq_u64 %[rn0], 0\n\t"                                                                                       \
     "s_cbranch_scc0 5f\n\t"                                                                                            \
     "s_cmp_eq_u64 %[pe0], 0\n\t"                                                                                       \
-    "s_cbranch_scc0 7f\n\t" SMART_A_CALM(SMART_A_CASC_CALM("9"), deep, calm_split) "s_branch 9f\n\t"                   \
-        SMART_A_CASC_CALM_OOL("9") "5:\n\t" SMART_A_RAIN("rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros,                  \
+    "s_cbranch_scc0 7f\n\t" SMART_A_CALM(route, SMART_A_CASC_CALM("9"), deep, calm_split) "s_branch 9f\n\t"            \
+        SMART_A_CASC_CALM_OOL("9") "5:\n\t" SMART_A_RAIN(route, "rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros,           \
                                                          SMART_A_FILL_QUICK(drain), deep, rain_split)                  \
             "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL("9")                                                               \
-            "7:\n\t" SMART_A_DRY("pe0", dry_split) "9:\n\t"
+            "7:\n\t" SMART_A_DRY(route, "pe0", dry_split) "9:\n\t"
 // the rain arm alone (waves that may not take the shortcuts)
-#define SMART_A_STEP_RAIN(deep, zeros, drain, rain_split)                                                              \
-    SMART_A_RAIN("rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros, SMART_A_FILL(drain), deep, rain_split)                   \
+#define SMART_A_STEP_RAIN(route, deep, zeros, drain, rain_split)                                                       \
+    SMART_A_RAIN(route, "rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros, SMART_A_FILL(drain), deep, rain_split)            \
     "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL("9") "9:\n\t"
 
 // ---- a chunk of four steps, threaded ---------------------------------------------------------------------------
@@ -253,28 +266,30 @@
     "s_cbranch_scc0 12" j "b\n\t"                                                                                      \
     "s_cmp_eq_u64 %[pe" j "], 0\n\t"                                                                                   \
     "s_cbranch_scc1 10" j "b\n\t"
-#define SMART_A_CALM_J(j, deep, split) "10" j ":\n\t" SMART_A_CALM(SMART_A_CASC_CALM(j), deep, split)
-#define SMART_A_DRY_J(j, split) "11" j ":\n\t" SMART_A_DRY("pe" j, split)
-#define SMART_A_RAIN_J(j, zeros, fill, deep, split)                                                                    \
-    "12" j ":\n\t" SMART_A_RAIN("rn" j, "pe" j, SMART_A_CASC_RAIN(j), zeros, fill, deep, split)
-#define SMART_A_CHUNK(deep, calm_split, zeros, drain, rain_split, dry_split)                                           \
-    SMART_A_NEXT_FROM_CALM("0") SMART_A_CALM_J("0", deep, calm_split) SMART_A_NEXT_FROM_CALM("1")                      \
-    SMART_A_CALM_J("1", deep, calm_split) SMART_A_NEXT_FROM_CALM("2") SMART_A_CALM_J("2", deep, calm_split)            \
-    SMART_A_NEXT_FROM_CALM("3") SMART_A_CALM_J("3", deep, calm_split) "s_branch 130f\n\t"                              \
+#define SMART_A_CALM_J(route, j, deep, split) "10" j ":\n\t" SMART_A_CALM(route, SMART_A_CASC_CALM(j), deep, split)
+#define SMART_A_DRY_J(route, j, split) "11" j ":\n\t" SMART_A_DRY(route, "pe" j, split)
+#define SMART_A_RAIN_J(route, j, zeros, fill, deep, split)                                                             \
+    "12" j ":\n\t" SMART_A_RAIN(route, "rn" j, "pe" j, SMART_A_CASC_RAIN(j), zeros, fill, deep, split)
+#define SMART_A_CHUNK(route, deep, calm_split, zeros, drain, rain_split, dry_split)                                    \
+    SMART_A_NEXT_FROM_CALM("0") SMART_A_CALM_J(route, "0", deep, calm_split) SMART_A_NEXT_FROM_CALM("1")               \
+    SMART_A_CALM_J(route, "1", deep, calm_split) SMART_A_NEXT_FROM_CALM("2")                                           \
+    SMART_A_CALM_J(route, "2", deep, calm_split) SMART_A_NEXT_FROM_CALM("3")                                           \
+    SMART_A_CALM_J(route, "3", deep, calm_split) "s_branch 130f\n\t"                                                   \
     SMART_A_CASC_CALM_OOL("0") SMART_A_CASC_CALM_OOL("1") SMART_A_CASC_CALM_OOL("2") SMART_A_CASC_CALM_OOL("3")        \
-    SMART_A_RAIN_J("0", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) SMART_A_NEXT_FROM_RAIN("1")                \
-    SMART_A_RAIN_J("1", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) SMART_A_NEXT_FROM_RAIN("2")                \
-    SMART_A_RAIN_J("2", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) SMART_A_NEXT_FROM_RAIN("3")                \
-    SMART_A_RAIN_J("3", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) "s_branch 130f\n\t"                        \
+    SMART_A_RAIN_J(route, "0", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) SMART_A_NEXT_FROM_RAIN("1")         \
+    SMART_A_RAIN_J(route, "1", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) SMART_A_NEXT_FROM_RAIN("2")         \
+    SMART_A_RAIN_J(route, "2", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) SMART_A_NEXT_FROM_RAIN("3")         \
+    SMART_A_RAIN_J(route, "3", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) "s_branch 130f\n\t"                 \
     SMART_A_CASC_RAIN_OOL("0") SMART_A_CASC_RAIN_OOL("1") SMART_A_CASC_RAIN_OOL("2") SMART_A_CASC_RAIN_OOL("3")        \
-    SMART_A_DRY_J("0", dry_split) SMART_A_NEXT_FROM_DRY("1") SMART_A_DRY_J("1", dry_split) SMART_A_NEXT_FROM_DRY("2")  \
-    SMART_A_DRY_J("2", dry_split) SMART_A_NEXT_FROM_DRY("3") SMART_A_DRY_J("3", dry_split) "130:\n\t"
+    SMART_A_DRY_J(route, "0", dry_split) SMART_A_NEXT_FROM_DRY("1") SMART_A_DRY_J(route, "1", dry_split)               \
+    SMART_A_NEXT_FROM_DRY("2") SMART_A_DRY_J(route, "2", dry_split) SMART_A_NEXT_FROM_DRY("3")                         \
+    SMART_A_DRY_J(route, "3", dry_split) "130:\n\t"
 // not QUICK: the rain arm four times
-#define SMART_A_CHUNK_RAIN(deep, zeros, drain, rain_split)                                                             \
-    SMART_A_RAIN_J("0", zeros, SMART_A_FILL(drain), deep, rain_split)                                                  \
-    SMART_A_RAIN_J("1", zeros, SMART_A_FILL(drain), deep, rain_split)                                                  \
-    SMART_A_RAIN_J("2", zeros, SMART_A_FILL(drain), deep, rain_split)                                                  \
-    SMART_A_RAIN_J("3", zeros, SMART_A_FILL(drain), deep, rain_split)                                                  \
+#define SMART_A_CHUNK_RAIN(route, deep, zeros, drain, rain_split)                                                      \
+    SMART_A_RAIN_J(route, "0", zeros, SMART_A_FILL(drain), deep, rain_split)                                           \
+    SMART_A_RAIN_J(route, "1", zeros, SMART_A_FILL(drain), deep, rain_split)                                           \
+    SMART_A_RAIN_J(route, "2", zeros, SMART_A_FILL(drain), deep, rain_split)                                           \
+    SMART_A_RAIN_J(route, "3", zeros, SMART_A_FILL(drain), deep, rain_split)                                           \
     "s_branch 130f\n\t" SMART_A_CASC_RAIN_OOL("0") SMART_A_CASC_RAIN_OOL("1") SMART_A_CASC_RAIN_OOL("2")               \
     SMART_A_CASC_RAIN_OOL("3") "130:\n\t"
 

@@ -15,7 +15,11 @@
 //   smart_fast_runs_states       k >= 2 a divisor of the gap (e.g. 6-hourly data, hourly steps)     ... SPLIT
 //   smart_fast_steps             class 0, summary, gap >= 2, forcing varying inside the interval step loop, merged
 //   smart_fast_steps_states      same, final state vector asked for                              step loop, SPLIT
-//   smart_fast_plain             class 0, raw reports or gap 1                                   step loop
+//   smart_fast_steps_raw         class 0, raw reports, gap >= 2 (W, T multiples of it)           step loop, last-step routing
+//   smart_fast_intervals_raw     same over piecewise-constant forcing                            interval engine, n - 1 + 1 steps
+//   smart_fast_steps_every       class 0, a report every step (gap 1)                            single-step arms + report
+//   smart_fast_plain             class 0, what is left: raw reports over a ragged time axis, raw   step loop (unsliced)
+//                                or every-step reports with the final state vector
 //   smart_fast_stiff             class 1: some k * 3600 < dt (clamps, 95 % rule reachable)        step loop, STIFF
 //   smart_fast_guard             class 2: S outside [0, 0.5], C < 0 or Z <= 0                     step loop, GUARD
 //   smart_fast_illcond           class 3: dt / (RK * 3600) > 2 (the river only)                   literal model, divisions
@@ -39,11 +43,17 @@ enum FastKernel : int {
     kRunsExits,
     kRuns,
     kRunsStates,
+    kStepsRaw,
+    kIntervalsRaw,
+    kStepsEvery,
     kNumFastKernels
 };
 
-// ticket counters of the two families of time-sliced kernels (workspace header, claim_work)
-constexpr int kTicketIntervals = 0, kTicketSteps = 1, kTicketRuns = 2;
+// ticket counters of the families of time-sliced kernels (workspace header, claim_work): at most one kernel of a
+// family runs in a call
+constexpr int kTicketIntervals = 0, kTicketSteps = 1, kTicketRuns = 2, kTicketStepsRaw = 3, kTicketIntervalsRaw = 4,
+              kTicketEvery = 5;
+static_assert(kHdrTicket + kTicketEvery < 8, "the plan word of smart_plan_ensemble sits at header int 8");
 
 // Do this block's 64 rows belong to the kernel of class CLS?  A block whose class has no kernel in this call (the
 // caller's plan is stale) is reported through the status word by whichever kernel meets it first.
@@ -73,18 +83,31 @@ __device__ __forceinline__ bool forcing_is_mine(const KArgs &a, int fflags, cons
     return false;
 }
 
-template <class Model, int FORCING>
+template <class Model, int FORCING, int REPORT = kReportMean>
 __device__ __forceinline__ void merged_kernel(const KArgs &a, const double2 *__restrict__ forcing,
                                               const double *__restrict__ obs, const double *__restrict__ ws)
 {
-    const Work w = claim_work(a, FORCING == kForcingIntervals ? kTicketIntervals
-                                                               : (FORCING == kForcingVarying ? kTicketSteps : kTicketRuns));
+    constexpr int ticket = REPORT == kReportEvery  ? kTicketEvery
+                           : REPORT == kReportLast ? (FORCING == kForcingIntervals ? kTicketIntervalsRaw : kTicketStepsRaw)
+                           : FORCING == kForcingIntervals ? kTicketIntervals
+                                                          : (FORCING == kForcingVarying ? kTicketSteps : kTicketRuns);
+    const Work w = claim_work(a, ticket);
     if (!block_is_mine<0>(a, w))
         return;
     const int fflags = forcing_flags(a, forcing, w.c);
-    if (!forcing_is_mine<FORCING>(a, fflags, w))
-        return;
-    run_ensemble_merged<Model, FORCING>(a, forcing, obs, ws, w.block, w.c, w.seg, fflags);
+    if constexpr (REPORT == kReportLast && FORCING == kForcingVarying) {
+        // the step loop of raw reports takes every forcing the interval engine does not (varying, and constant over runs
+        // shorter than the report interval: there is no run engine for raw reports)
+        if (forcing_kind(a, fflags) == kForcingIntervals) {
+            if (w.seg == 0 && !(a.pc_mask & 1))
+                raise_status(a, kStatusStalePlan);
+            return;
+        }
+    } else if constexpr (REPORT != kReportEvery) { // (a report every step: one kernel whatever the forcing)
+        if (!forcing_is_mine<FORCING>(a, fflags, w))
+            return;
+    }
+    run_ensemble_merged<Model, FORCING, REPORT>(a, forcing, obs, ws, w.block, w.c, w.seg, fflags);
 }
 
 #define SMART_FAST_KERNEL(name)                                                                                        \
@@ -96,5 +119,6 @@ const void *fast_kernel_intervals(FastKernel k);
 const void *fast_kernel_steps(FastKernel k);
 const void *fast_kernel_guarded(FastKernel k);
 const void *fast_kernel_runs(FastKernel k);
+const void *fast_kernel_reports(FastKernel k);
 
 } // namespace smart

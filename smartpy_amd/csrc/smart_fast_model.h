@@ -838,33 +838,47 @@ struct FastModel {
     unsigned long long wm, sv, tmp
 
     // One step.  QUICK: the forcing is sane and no layer of this wave is above capacity -- dispatch over the three
-    // arms; otherwise the rain arm.
-    template <bool QUICK>
+    // arms; otherwise the rain arm.  LAST: the routing of SMART_A_ROUTE_LAST -- `acc` = the river's outflow of this step,
+    // q_gw / q_in = dt/rk times its groundwater inflow / its whole inflow (raw reports, a report every step).
+#define SMART_ARM_LAST [qg] "=&v"(q_gw), [qi] "=&v"(q_in)
+    template <bool QUICK, bool LAST = false>
     __device__ __forceinline__ void step_arms(const double2 v, double &acc)
     {
         SMART_ARM_LOCALS;
-        if constexpr (SPLIT) {
+        if constexpr (LAST) {
+            static_assert(!SPLIT, "raw reports / a report every step with the final state vector take smart_fast_plain");
+            if constexpr (QUICK)
+                asm volatile(SMART_A_STEP(SMART_A_ROUTE_LAST, "", "", "", "", "", "")
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_LAST
+                             : SMART_ARM_CONSTS, [rn0] "s"(v.x), [pe0] "s"(v.y)
+                             : "vcc", "scc");
+            else
+                asm volatile(SMART_A_STEP_RAIN(SMART_A_ROUTE_LAST, "", "", "", "")
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_LAST
+                             : SMART_ARM_CONSTS, [rn0] "s"(v.x), [pe0] "s"(v.y)
+                             : "vcc", "scc");
+        } else if constexpr (SPLIT) {
             double xd, dp;
             if constexpr (QUICK)
-                asm volatile(SMART_A_STEP(SMART_A_DEEP, SMART_A_CALM_SPLIT, SMART_A_RAIN_ZEROS_SPLIT,
+                asm volatile(SMART_A_STEP(SMART_A_ROUTE, SMART_A_DEEP, SMART_A_CALM_SPLIT, SMART_A_RAIN_ZEROS_SPLIT,
                                           SMART_A_RAIN_DRAIN_SPLIT, SMART_A_RAIN_SPLIT, SMART_A_DRY_SPLIT)
                              : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_SPLIT
                              : SMART_ARM_CONSTS, [rn0] "s"(v.x), [pe0] "s"(v.y)
                              : "vcc", "scc");
             else
-                asm volatile(SMART_A_STEP_RAIN(SMART_A_DEEP, SMART_A_RAIN_ZEROS_SPLIT, SMART_A_RAIN_DRAIN_SPLIT,
-                                               SMART_A_RAIN_SPLIT)
+                asm volatile(SMART_A_STEP_RAIN(SMART_A_ROUTE, SMART_A_DEEP, SMART_A_RAIN_ZEROS_SPLIT,
+                                               SMART_A_RAIN_DRAIN_SPLIT, SMART_A_RAIN_SPLIT)
                              : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_SPLIT
                              : SMART_ARM_CONSTS, [rn0] "s"(v.x), [pe0] "s"(v.y)
                              : "vcc", "scc");
         } else {
             if constexpr (QUICK)
-                asm volatile(SMART_A_STEP("", "", "", "", "", "")
+                asm volatile(SMART_A_STEP(SMART_A_ROUTE, "", "", "", "", "", "")
                              : SMART_ARM_STATES, SMART_ARM_TEMPS
                              : SMART_ARM_CONSTS, [rn0] "s"(v.x), [pe0] "s"(v.y)
                              : "vcc", "scc");
             else
-                asm volatile(SMART_A_STEP_RAIN("", "", "", "")
+                asm volatile(SMART_A_STEP_RAIN(SMART_A_ROUTE, "", "", "", "")
                              : SMART_ARM_STATES, SMART_ARM_TEMPS
                              : SMART_ARM_CONSTS, [rn0] "s"(v.x), [pe0] "s"(v.y)
                              : "vcc", "scc");
@@ -875,32 +889,44 @@ struct FastModel {
 #define SMART_ARM_CHUNK_IN                                                                                             \
     [rn0] "s"(c[0].x), [pe0] "s"(c[0].y), [rn1] "s"(c[1].x), [pe1] "s"(c[1].y), [rn2] "s"(c[2].x), [pe2] "s"(c[2].y), \
         [rn3] "s"(c[3].x), [pe3] "s"(c[3].y)
-    template <bool QUICK>
+    template <bool QUICK, bool LAST = false>
     __device__ __forceinline__ void chunk_arms(const double2 (&c)[4], double &acc)
     {
         SMART_ARM_LOCALS;
-        if constexpr (SPLIT) {
+        if constexpr (LAST) {
+            static_assert(!SPLIT, "raw reports / a report every step with the final state vector take smart_fast_plain");
+            if constexpr (QUICK)
+                asm volatile(SMART_A_CHUNK(SMART_A_ROUTE_LAST, "", "", "", "", "", "")
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_LAST
+                             : SMART_ARM_CONSTS, SMART_ARM_CHUNK_IN
+                             : "vcc", "scc");
+            else
+                asm volatile(SMART_A_CHUNK_RAIN(SMART_A_ROUTE_LAST, "", "", "", "")
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_LAST
+                             : SMART_ARM_CONSTS, SMART_ARM_CHUNK_IN
+                             : "vcc", "scc");
+        } else if constexpr (SPLIT) {
             double xd, dp;
             if constexpr (QUICK)
-                asm volatile(SMART_A_CHUNK(SMART_A_DEEP, SMART_A_CALM_SPLIT, SMART_A_RAIN_ZEROS_SPLIT,
+                asm volatile(SMART_A_CHUNK(SMART_A_ROUTE, SMART_A_DEEP, SMART_A_CALM_SPLIT, SMART_A_RAIN_ZEROS_SPLIT,
                                            SMART_A_RAIN_DRAIN_SPLIT, SMART_A_RAIN_SPLIT, SMART_A_DRY_SPLIT)
                              : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_SPLIT
                              : SMART_ARM_CONSTS, SMART_ARM_CHUNK_IN
                              : "vcc", "scc");
             else
-                asm volatile(SMART_A_CHUNK_RAIN(SMART_A_DEEP, SMART_A_RAIN_ZEROS_SPLIT, SMART_A_RAIN_DRAIN_SPLIT,
-                                                SMART_A_RAIN_SPLIT)
+                asm volatile(SMART_A_CHUNK_RAIN(SMART_A_ROUTE, SMART_A_DEEP, SMART_A_RAIN_ZEROS_SPLIT,
+                                                SMART_A_RAIN_DRAIN_SPLIT, SMART_A_RAIN_SPLIT)
                              : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_SPLIT
                              : SMART_ARM_CONSTS, SMART_ARM_CHUNK_IN
                              : "vcc", "scc");
         } else {
             if constexpr (QUICK)
-                asm volatile(SMART_A_CHUNK("", "", "", "", "", "")
+                asm volatile(SMART_A_CHUNK(SMART_A_ROUTE, "", "", "", "", "", "")
                              : SMART_ARM_STATES, SMART_ARM_TEMPS
                              : SMART_ARM_CONSTS, SMART_ARM_CHUNK_IN
                              : "vcc", "scc");
             else
-                asm volatile(SMART_A_CHUNK_RAIN("", "", "", "")
+                asm volatile(SMART_A_CHUNK_RAIN(SMART_A_ROUTE, "", "", "", "")
                              : SMART_ARM_STATES, SMART_ARM_TEMPS
                              : SMART_ARM_CONSTS, SMART_ARM_CHUNK_IN
                              : "vcc", "scc");
@@ -977,6 +1003,46 @@ struct FastModel {
             u_dra *= P_q;
             u_dgw *= P_g;
         }
+    }
+
+    // ---- raw reports over piecewise-constant forcing (smart_fast_intervals_raw) -----------------------------------
+    // A raw report is the river's outflow of the LAST step of its interval (structure.py:192-195), and the groundwater
+    // ratio of a raw run sums the flows of those steps only: the interval engine advances n - 1 steps at once (the
+    // coefficients of the dry map are then built for n - 1 steps: setup_intervals(n - 1)), looks at the reservoirs --
+    // outflows of a step are the states it starts from (:427, :487) -- and takes the last step on its own.
+    // qo: the river's outflow; qi / qg: dt/rk times the river's inflow / its groundwater part (the common factor
+    // cancels in the ratio), the same quantities SMART_A_ROUTE_LAST leaves behind in the step loop.
+    __device__ __forceinline__ void last_step_flows(double &qo, double &qg, double &qi) const
+    {
+        qg = car_g * u_sgw;
+        qi = fma(car_s, u_ove, fma(car_f, u_int, qg));
+        qo = u_riv;
+    }
+
+    // `n` consecutive dry steps with the same demand; the routing as the map of n - 1 steps + the last step
+    __device__ __forceinline__ void dry_interval_last(double ex, long n, double &qo, double &qg, double &qi)
+    {
+        static_assert(!SPLIT && MERGE && !STIFF, "the merged regular variant");
+        double d = -ex * (double)n; // the evaporation cascade composes additively: dry_interval()
+        dry(l0, d, pC);
+        if (!kExits || __builtin_amdgcn_ballot_w64(d > 0.0) != 0) {
+            dry(l1, d, pC);
+            if (!kExits || __builtin_amdgcn_ballot_w64(d > 0.0) != 0) {
+                dry(l2, d, pC);
+                dry(l3, d, pC);
+                dry(l4, d, pC);
+                dry(l5, d, pC);
+            }
+        }
+        u_riv = fma(P_r, u_riv, fma(A_q, u_ove, fma(A_i, u_int, A_g * u_sgw)));
+        u_ove *= P_q;
+        u_int *= P_i;
+        u_sgw *= P_g;
+        last_step_flows(qo, qg, qi);
+        fma_in_place(u_riv, om_ar, qi);
+        u_ove *= dec_s;
+        u_int *= dec_f;
+        u_sgw *= dec_g;
     }
 };
 

@@ -119,6 +119,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert abs(d['value'] - 20000 * 96432 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
     r6 = d['runs_of_6']           # 6-hourly data in the hourly run: the interval engine over runs of six steps
     assert 'smart_fast_runs' in r6['kernel'] and 0 < r6['value'] < d['value'] * 1.05
+    # round 4: raw reports and a report every step have kernels of their own (round 3: smart_fast_plain, unsliced)
+    assert 'smart_fast_intervals_raw' in d['raw_gap24']['kernel'] and d['raw_gap24']['value'] > 0.5 * d['value']
+    assert 'smart_fast_steps_every' in d['gap1']['kernel'] and d['gap1']['value'] > 0.25 * d['value']
     st = d['strong_1e6']          # config 4 beside config 3, one command for both series
     assert st['runs_total'] == st['runs_per_gpu'] == 1000000 and 'smart_fast_intervals_exits' in st['kernel']
     assert d['ranks']['world_size'] == 1 and len(d['ranks']['devices']) == 1

@@ -413,11 +413,16 @@ def test_headline_size_properties(eng):
 
 
 @pytest.mark.parametrize('leg, kernel', [('runs_of_6', 'smart_fast_runs[16 slices'),
-                                         ('flat_forcing', 'smart_fast_steps[16 slices')])
+                                         ('flat_forcing', 'smart_fast_steps[16 slices'),
+                                         ('raw_gap24', 'smart_fast_intervals_raw[16 slices'),
+                                         ('raw_gap24_flat', 'smart_fast_steps_raw[16 slices'),
+                                         ('gap1', 'smart_fast_steps_every[16 slices')])
 def test_bench_legs_at_full_size(eng, leg, kernel):
-    """The two other legs of the bench line at their full size: the headline's 1e5 LHS rows x hourly 10 years on
-    6-hourly values (the run engine, two-mode wet intervals over runs of six steps) and on forcing that varies inside
-    the day (the step loop's asm arms).  Same properties as test_headline_size_properties: bit-identical under a
+    """The other legs of the bench line at their full size: the headline's 1e5 LHS rows x hourly 10 years on
+    6-hourly values (the run engine, two-mode wet intervals over runs of six steps), on forcing that varies inside
+    the day (the step loop's asm arms), under raw reports (the outflow of each day's last hour: the interval engine
+    over n - 1 + 1 steps on the headline's forcing, the last-step arms on the varying one) and under a report every
+    step (hourly reports of the hourly run).  Same properties as test_headline_size_properties: bit-identical under a
     permutation of the rows; 32 rows against the oracle -- discharge series, objective functions, groundwater ratio;
     physical ranges."""
     import torch
@@ -425,28 +430,92 @@ def test_bench_legs_at_full_size(eng, leg, kernel):
     N = 100000
     params = lhs_oracle.lhs_params(N, seed=2718)
     base, rng = bench.synthetic_forcing(0, hourly=True)
-    f = bench.six_hourly_forcing(base) if leg == 'runs_of_6' else bench.hourly_varying_forcing(base)
+    f = {'runs_of_6': bench.six_hourly_forcing, 'flat_forcing': bench.hourly_varying_forcing,
+         'raw_gap24_flat': bench.hourly_varying_forcing}.get(leg, lambda x: x)(base)
+    gap = 1 if leg == 'gap1' else 24
+    report, code = ('raw', so.REPORT_RAW) if leg.startswith('raw') else ('summary', so.REPORT_SUMMARY)
+    store = gap > 1                         # hourly reports of 1e5 runs would be a 70 GB matrix
     T, W = f.shape[0], 8760
-    obs = np.abs(rng.normal(2.0, 1.0, T // 24))
-    obs[rng.random(T // 24) < 0.12] = np.nan
+    obs = np.abs(rng.normal(2.0, 1.0, T // gap))
+    obs[rng.random(T // gap) < 0.12] = np.nan
     dev_p = torch.from_numpy(params).cuda()
-    kw = dict(extra=bench.EXTRA, obs=obs, gw_obs=0.12667)
-    out = eng.run_ensemble(dev_p, f, bench.AREA, 3600.0, W, 24, **kw)
+    kw = dict(extra=bench.EXTRA, obs=obs, gw_obs=0.12667, report=report)
+    out = eng.run_ensemble(dev_p, f, bench.AREA, 3600.0, W, gap, want_discharge=store, **kw)
     assert kernel in out._prepared.describe()                               # the kernel the bench leg names
     perm = torch.randperm(N, device='cuda', generator=torch.Generator(device='cuda').manual_seed(2))
-    out_p = eng.run_ensemble(dev_p[perm], f, bench.AREA, 3600.0, W, 24, want_discharge=False, **kw)
+    out_p = eng.run_ensemble(dev_p[perm], f, bench.AREA, 3600.0, W, gap, want_discharge=False, **kw)
     assert torch.equal(out.objfn[perm], out_p.objfn) and torch.equal(out.gw[perm], out_p.gw)
     gw, obj = out.gw.cpu().numpy(), out.objfn.cpu().numpy()
     assert np.all(np.isfinite(obj)) and np.all((gw >= 0) & (gw <= 1)) and np.all(obj[:, 0] <= 1)
     rows = np.sort(np.random.default_rng(13).choice(N, 32, replace=False))
     dis, gwo, _ = so.run_batch(bench.AREA, 3600.0, T, W, f[:, 0].copy(), f[:, 1].copy(), params[rows], bench.EXTRA,
-                               so.REPORT_SUMMARY, 24)
-    got = out.discharge[torch.from_numpy(rows).cuda()].cpu().numpy()
-    assert got.shape == dis.shape == (32, T // 24)
+                               code, gap)
+    if store:
+        got = out.discharge[torch.from_numpy(rows).cuda()].cpu().numpy()
+    else:       # the 32 rows on their own, matrix stored: another launch geometry (one block, unsliced), the same bits
+        few = eng.run_ensemble(params[rows], f, bench.AREA, 3600.0, W, gap, **kw)
+        assert torch.equal(few.objfn, out.objfn[torch.from_numpy(rows).cuda()])
+        got = few.discharge.cpu().numpy()
+    assert got.shape == dis.shape == (32, T // gap)
     assert rel(got, dis) < REL_FAST
     want = objfn_oracle.objective_matrix(dis, obs, gwo, 0.12667)
     assert rel(obj[rows, :7], want[:, :7]) < 1e-9 and np.array_equal(obj[rows, 7], want[:, 7])
     assert rel(gw[rows], gwo) < 1e-10
+
+
+@pytest.mark.parametrize('forcing_kind', ['daily_spread', 'six_hourly', 'varying'])
+@pytest.mark.parametrize('report, gap', [('raw', 24), ('raw', 6), ('raw', 1), ('summary', 1)])
+def test_raw_and_every_step_reports_through_the_merged_kernels(eng, forcing_kind, report, gap):
+    """Round 4: report='raw' over whole intervals and a report every step leave smart_fast_plain for kernels with the
+    summary path's machinery (structure.py:192-195 and :190 with gap 1).  Against the oracle: discharge, groundwater
+    ratio (raw: the flows of the reported steps only), the fused objective functions; time-sliced and whole launches
+    bit-identical; a row's result independent of its neighbours."""
+    import torch
+    import bench
+    base = bench.synthetic_forcing(2, hourly=True)[0][:24 * 260]
+    f = {'daily_spread': lambda x: x, 'six_hourly': bench.six_hourly_forcing,
+         'varying': bench.hourly_varying_forcing}[forcing_kind](base)
+    T, W, N = f.shape[0], 24 * 20, 300
+    params = lhs_oracle.lhs_params(N, seed=41)
+    rng = np.random.default_rng(8)
+    obs = np.abs(rng.normal(2.0, 1.0, T // gap))
+    obs[rng.random(T // gap) < 0.12] = np.nan
+    kw = dict(extra=bench.EXTRA, obs=obs, gw_obs=0.2, report=report)
+    whole = eng.prepare_ensemble(params, f, bench.AREA, 3600.0, W, gap, time_slices=1, **kw)
+    want_kernel = 'smart_fast_steps_every' if gap == 1 else (
+        'smart_fast_intervals_raw' if forcing_kind == 'daily_spread' or (forcing_kind == 'six_hourly' and gap == 6)
+        else 'smart_fast_steps_raw')
+    assert want_kernel in whole.describe() and 'plain' not in whole.describe(), whole.describe()
+    out = whole.launch()
+    assert whole.status() == 0
+    code = so.REPORT_RAW if report == 'raw' else so.REPORT_SUMMARY
+    dis, gwo, _ = so.run_batch(bench.AREA, 3600.0, T, W, f[:, 0].copy(), f[:, 1].copy(), params, bench.EXTRA, code, gap)
+    assert rel(out.discharge.cpu().numpy(), dis) < REL_FAST
+    assert rel(out.gw.cpu().numpy(), gwo) < 1e-10
+    want = objfn_oracle.objective_matrix(dis, obs, gwo, 0.2)
+    obj = out.objfn.cpu().numpy()
+    assert rel(obj[:, :7], want[:, :7]) < 1e-9 and np.array_equal(obj[:, 7], want[:, 7])
+    keep = (out.discharge.clone(), out.gw.clone(), out.objfn.clone())
+    for n_slices in (3, 7):
+        cut = eng.prepare_ensemble(params, f, bench.AREA, 3600.0, W, gap, time_slices=n_slices, **kw)
+        assert '%d slices' % n_slices in cut.describe()
+        got = cut.launch()
+        assert cut.status() == 0
+        assert torch.equal(got.discharge, keep[0]) and torch.equal(got.gw, keep[1]) and torch.equal(got.objfn, keep[2])
+    perm = np.random.default_rng(3).permutation(N)
+    mixed = eng.run_ensemble(params[perm], f, bench.AREA, 3600.0, W, gap, **kw)
+    assert torch.equal(mixed.discharge, keep[0][torch.from_numpy(perm).cuda()])
+    assert torch.equal(mixed.objfn, keep[2][torch.from_numpy(perm).cuda()])
+    # without observations, and (raw) with a warm-up that is not a whole number of intervals: smart_fast_plain's case
+    bare = eng.run_ensemble(params, f, bench.AREA, 3600.0, W, gap, extra=bench.EXTRA, report=report)
+    assert torch.equal(bare.discharge, keep[0]) and torch.equal(bare.gw, keep[1])
+    if report == 'raw' and gap > 1:
+        odd = eng.prepare_ensemble(params, f, bench.AREA, 3600.0, W + 5, gap, extra=bench.EXTRA, report=report)
+        assert 'smart_fast_plain' in odd.describe()
+        d2, g2, _ = so.run_batch(bench.AREA, 3600.0, T, W + 5, f[:, 0].copy(), f[:, 1].copy(), params, bench.EXTRA,
+                                 code, gap)
+        res = odd.launch()
+        assert rel(res.discharge.cpu().numpy(), d2) < REL_FAST and rel(res.gw.cpu().numpy(), g2) < 1e-10
 
 
 def test_config4_size_one_million_samples(eng):

@@ -21,7 +21,8 @@ pytestmark = pytest.mark.skipif(not os.path.exists(OBJDUMP), reason='needs llvm-
 
 # every __global__ that calls run_ensemble_merged / a sliced body (smart_fast_entry.h)
 SLICED = ['smart_fast_intervals_exits', 'smart_fast_intervals', 'smart_fast_intervals_states', 'smart_fast_runs_exits',
-          'smart_fast_runs', 'smart_fast_runs_states', 'smart_fast_steps', 'smart_fast_steps_states']
+          'smart_fast_runs', 'smart_fast_runs_states', 'smart_fast_steps', 'smart_fast_steps_states',
+          'smart_fast_steps_raw', 'smart_fast_intervals_raw', 'smart_fast_steps_every']
 
 
 def _all_fast_kernels():

@@ -1,0 +1,40 @@
+#!/bin/bash
+# The GPU sessions of a round, one script (round 3 had gpu_r03_a.sh ... gpu_r03_v.sh).  Run through gpurun:
+#   gpurun --timeout N -- 'bash tools/gpu_round.sh <stage> [args]'
+# stages
+#   quick [-k EXPR]    the GPU tests selected by EXPR (default: the round's new ones), then tools/debug/gap1_hourly.py
+#   suite              the whole GPU suite
+#   bench [args]       bench.py with the driver's K / W (--steps 20 --warmup 5) and a one-line digest of the legs
+#   ab LIB...          interleaved A/B of library variants (tools/ab_variants.sh)
+#   profile TAG [bench args]   tools/profile.sh (kernel trace + PMC passes of the bench command)
+#   final              what the driver runs at round end (tools/gpu_final_check.sh)
+# Everything a stage prints also lands in gpurun_out/<stage>_*.log.
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+STAGE=${1:-quick}; shift
+case $STAGE in
+quick)
+    EXPR=${2:-"raw_and_every or bench_legs or without_a_plan or bare_command"}
+    timeout 2400 python -m pytest tests -m gpu -x -q -k "$EXPR" > gpurun_out/quick_pytest.log 2>&1; tail -15 gpurun_out/quick_pytest.log
+    python tools/debug/gap1_hourly.py 2>&1 | tee gpurun_out/quick_gap1.log | tail -8
+    ;;
+suite)
+    timeout 3000 python -m pytest tests -m gpu -x -q > gpurun_out/suite_pytest.log 2>&1; tail -15 gpurun_out/suite_pytest.log
+    ;;
+bench)
+    python bench.py --steps 20 --warmup 5 "$@" > gpurun_out/bench_round.log 2>&1
+    grep '^{' gpurun_out/bench_round.log | python tools/bench_digest.py
+    ;;
+ab)
+    bash tools/ab_variants.sh "$@" 2>&1 | tee gpurun_out/ab_round.log | tail -40
+    ;;
+profile)
+    bash tools/profile.sh "$@"
+    ;;
+final)
+    bash tools/gpu_final_check.sh
+    ;;
+*)
+    echo "unknown stage $STAGE"; exit 2
+    ;;
+esac

@@ -9,7 +9,8 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 UNITS = {'smart_fast_intervals': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
          'smart_fast_runs': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
          'smart_fast_steps': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
-         'smart_fast_guarded': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
+         'smart_fast_reports': ['-ffp-contract=fast-honor-pragmas', '-fno-honor-nans'],
+         'smart_fast_guarded': ['-ffp-contract=fast-honor-pragmas'],
          'smart_literal': ['-ffp-contract=off'], 'smart_capi': []}
 ver = subprocess.check_output(['/opt/rocm/bin/hipcc', '--version']).decode().splitlines()[0]
 print('hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage (%s)' % ver)
