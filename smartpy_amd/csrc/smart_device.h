@@ -96,6 +96,15 @@ __device__ __forceinline__ bool is_nan_bits(double x)
 }
 constexpr int kWsHead = 8;
 
+// The same test spelt in 32-bit pieces, for values that live in scalar registers (an observation of a report): there is
+// no 64-bit scalar greater-than, and hipcc answers the form above with a vector compare.
+__device__ __forceinline__ bool is_nan_scalar(double x)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned hi = (unsigned)(u >> 32) & 0x7fffffffu, lo = (unsigned)u;
+    return hi > 0x7ff00000u || (hi == 0x7ff00000u && lo != 0u);
+}
+
 // a quiet NaN that does not trip -fno-honor-nans diagnostics (the fast kernels never do arithmetic on one)
 __host__ __device__ __forceinline__ double quiet_nan() { return __builtin_bit_cast(double, 0x7ff8000000000000ull); }
 
@@ -322,18 +331,35 @@ __device__ __forceinline__ void time_loop_arms(Model &m, const double2 *__restri
         m.template step_arms<QUICK, LAST>(f[t], acc);
 }
 
-// The same walk with something to do after EVERY step (a report every step: gap 1): single-step arms with the routing
-// of SMART_A_ROUTE_LAST, so that `acc` holds the outflow of the step just taken when step_end() looks at it.
-template <bool QUICK, class Model, class StepEnd>
-__device__ __forceinline__ void time_loop_arms_each(Model &m, const double2 *__restrict__ f, long n, double &acc,
-                                                    StepEnd &&step_end)
+// Data that nothing writes during the launch (observations, their deviations), read through the CONSTANT address space:
+// a uniform load from there is a scalar load whatever stores the loop around it makes -- __restrict__ on a pointer that
+// has passed through a struct or a lambda does not get hipcc that far.
+typedef const double __attribute__((address_space(4))) *const_f64;
+__device__ __forceinline__ const_f64 as_constant(const double *p) { return (const_f64)(unsigned long long)p; }
+
+// The same walk with a report after EVERY step (gap 1): single-step arms with the routing of SMART_A_ROUTE_LAST, so that
+// `acc` holds the outflow of the step just taken when step_end(t, e, w) looks at it.  OBS: the observation e of each
+// step's report and its deviation w from the mean travel with the forcing -- scalar loads, a chunk of four steps ahead
+// (left to the reporter, each step waits for two VECTOR loads of its own, issued behind the step: hipcc cannot prove
+// that the discharge stores leave the observations alone once the pointers live in a struct; that alone was a third of
+// the first version's 31.5 ms at 1e5 samples).  obs / dev point at the first step's entries.
+template <bool QUICK, bool OBS, class Model, class StepEnd>
+__device__ __forceinline__ void time_loop_arms_each(Model &m, const double2 *__restrict__ f, const double *obs_,
+                                                    const double *dev_, long n, double &acc, StepEnd &&step_end)
 {
+    const const_f64 obs = as_constant(obs_), dev = as_constant(dev_);
     const int n_chunks = (int)(n / kChunk);
     double2 cur[kChunk], nxt[kChunk];
+    double e_cur[kChunk] = {}, e_nxt[kChunk] = {}, w_cur[kChunk] = {}, w_nxt[kChunk] = {};
     if (n_chunks > 0) {
 #pragma unroll
-        for (int j = 0; j < kChunk; ++j)
+        for (int j = 0; j < kChunk; ++j) {
             cur[j] = f[j];
+            if constexpr (OBS) {
+                e_cur[j] = obs[j];
+                w_cur[j] = dev[j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
             asm volatile("" ::"s"(cur[j].x), "s"(cur[j].y));
@@ -341,20 +367,31 @@ __device__ __forceinline__ void time_loop_arms_each(Model &m, const double2 *__r
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int pre = (ch + 1 < n_chunks ? ch + 1 : ch) * kChunk; // last chunk: harmless re-load of itself
 #pragma unroll
-        for (int j = 0; j < kChunk; ++j)
+        for (int j = 0; j < kChunk; ++j) {
             nxt[j] = f[pre + j];
+            if constexpr (OBS) {
+                e_nxt[j] = obs[pre + j];
+                w_nxt[j] = dev[pre + j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) {
             m.template step_arms<QUICK, true>(cur[j], acc);
-            step_end();
+            step_end((long)ch * kChunk + j, e_cur[j], w_cur[j]);
         }
 #pragma unroll
-        for (int j = 0; j < kChunk; ++j)
+        for (int j = 0; j < kChunk; ++j) {
             cur[j] = nxt[j];
+            e_cur[j] = e_nxt[j];
+            w_cur[j] = w_nxt[j];
+        }
     }
     for (long t = (long)n_chunks * kChunk; t < n; ++t) {
         m.template step_arms<QUICK, true>(f[t], acc);
-        step_end();
+        if constexpr (OBS)
+            step_end(t, obs[t], dev[t]);
+        else
+            step_end(t, 0.0, 0.0);
     }
 }
 
@@ -1003,6 +1040,10 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
 
     Reporter rep;
     rep.init(a, x, obs_all, ws_all);
+    // this catchment's observations and their deviations from the mean, as pointers of this function's own (the loops
+    // that fetch them with scalar loads take them as __restrict__ parameters)
+    [[maybe_unused]] const double *__restrict__ obs_c = obs_all ? obs_all + x.c * a.R : nullptr;
+    [[maybe_unused]] const double *__restrict__ dev_c = ws_all ? ws_all + x.c * (kWsHead + a.R) + kWsHead : nullptr;
     double num = 0.0, den = 0.0, q_out_total = 0.0;
     [[maybe_unused]] double num_raw = 0.0, den_raw = 0.0; // raw reports: the two sums over the reported steps (structure.py:194-195)
     double *hand = a.seg_state + (slot * kSegFields) * kWave + x.lane;
@@ -1156,11 +1197,29 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                 ++r;
                 num_raw += m.q_gw;
                 den_raw += m.q_in;
-            } else { // every step; the groundwater ratio from the balances, as for the means
-                rep.emit(a, x, r, acc);
-                ++r;
-                q_out_total += acc;
             }
+        };
+        // a report every step: e, w = the observation of this report and its deviation from the mean, fetched with the
+        // forcing (time_loop_arms_each); the groundwater ratio from the balances, as for the means.  The discharge row
+        // of a report is one uniform pointer that moves on by ld, the lane adds its own place.
+        [[maybe_unused]] double *row = a.discharge ? a.discharge + (x.c * a.R + ra) * a.ld : nullptr;
+        [[maybe_unused]] auto report_every = [&](long, const double e, const double w) {
+            const double val = acc;
+            if (row) {
+                if (x.live)
+                    row[x.n] = val;
+                row += a.ld;
+            }
+            if (rep.want_obj && !is_nan_scalar(e)) { // montecarlo.py:195-196
+                const double d = val - e;
+                const double u = val - rep.shift;
+                rep.A += d;
+                rep.B += d * d;
+                rep.C1 += u;
+                rep.C2 += u * u;
+                rep.C3 += w * u;
+            }
+            q_out_total += val;
         };
 #if SMART_STEP_ARMS
         // The three asm arms of FastModel::step_arms.  The shortcuts of the dry and the calm arm need forcing without
@@ -1182,10 +1241,22 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                         park_state();
                 }
                 if constexpr (REPORT == kReportEvery) { // (gap == 1: intervals are steps)
-                    if (stretch == 0)
+                    if (stretch == 0) {
                         time_loop_arms<Q, true>(m, f + i0, i1 - i0, acc, [] {});
-                    else
-                        time_loop_arms_each<Q>(m, f + i0, i1 - i0, acc, report);
+                    } else {
+                        long first = i0;
+                        if (i0 == 0 && i1 > 0) { // report 0 on its own: it sets the constant the moments are taken about
+                            m.template step_arms<Q, true>(f[0], acc);
+                            rep.shift = acc;
+                            report_every(0, rep.want_obj ? obs_c[0] : 0.0, rep.want_obj ? dev_c[0] : 0.0);
+                            first = 1;
+                        }
+                        if (rep.want_obj)
+                            time_loop_arms_each<Q, true>(m, f + first, obs_c + first, dev_c + first, i1 - first, acc,
+                                                         report_every);
+                        else
+                            time_loop_arms_each<Q, false>(m, f + first, nullptr, nullptr, i1 - first, acc, report_every);
+                    }
                 } else {
                     arm_intervals<Q, REPORT == kReportLast>(m, f + i0 * gap, i1 - i0, gap, i1 * gap == a.T, acc, [&]() {
                         if (stretch == 1)
