@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SMART_AMD_ABI_VERSION 4
+#define SMART_AMD_ABI_VERSION 5
 
 /* report_type, as structure.py:65-70 maps report='summary' / 'raw' */
 #define SMART_REPORT_SUMMARY 1
@@ -182,16 +182,26 @@ int smart_describe_launch(const SmartEnsemble *e, char *text, int64_t len);
 
 /*
  * smartcpp.allsteps -- same arguments and results as run_all_steps (structure.py:149-152,197).
- * HOST pointers; synchronous (copies in, runs one sample on the GPU in SMART_MATH_LITERAL, copies out).
+ * HOST pointers; synchronous (copies in, runs one sample on the GPU, copies out).
  *   nd_rain / nd_peva hold at least length_simu values (the warm-up call passes the full series with a
  *   shorter length, structure.py:118-121); nd_parameters[10]; nd_initial[19];
  *   discharge[smart_n_reports(length_simu, report_gap, report_type)]; *groundwater_component;
  *   final_vars[19].
+ * Arithmetic: SMART_MATH_LITERAL (the reference's operation order; bit-identical to the ensemble's literal mode) unless
+ * the environment says SMART_ALLSTEPS_MATH=fast (the fast kernels for the one sample: <= 1e-9 relative, a tenth of the
+ * time).  The library keeps its device buffers and the uploaded series between calls (ABI v5): the reference calls this
+ * twice per SMART.simulate() with the same series (structure.py:118-121,143-146), a calibration loop thousands of
+ * times -- a call whose series starts with what is on the device uploads only what lies beyond it.  One caller at a
+ * time (serialised inside).
  */
 int smart_allsteps_hip(double area_m2, double delta_sec, int64_t length_simu, const double *nd_rain,
                        const double *nd_peva, const double *nd_parameters, const double *nd_initial,
                        int32_t report_type, int64_t report_gap, double *discharge,
                        double *groundwater_component, double *final_vars);
+
+/* Counters of the smartcpp.allsteps stand-in, for tests and logs: counters[0..n) of { calls, device allocations made,
+ * bytes of forcing uploaded, calls served in fast arithmetic } since the library was loaded (n <= 4). */
+int smart_hook_counters(int64_t *counters, int64_t n);
 
 /*
  * smartcpp.onestep -- run_one_step (structure.py:200-264): 2 constants, 2 forcings, 10 parameters and

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get('SMART_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libsm
 
 REPORT_SUMMARY, REPORT_RAW = 1, 2
 MATH_LITERAL, MATH_FAST = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 PLAN_VALID = 0x100
 PLAN_CLASS_BITS = {0: 0x01, 1: 0x02, 2: 0x04, 3: 0x08}     # regular, stiff, guard, ill-conditioned
 PLAN_FORCING_PIECEWISE, PLAN_FORCING_VARYING, PLAN_FORCING_RUNS = 0x10, 0x20, 0x80
@@ -48,6 +48,7 @@ SYMBOLS = {
     'smart_describe_launch': (ctypes.c_int, [ctypes.POINTER(SmartEnsemble), ctypes.c_char_p, ctypes.c_int64]),
     'smart_allsteps_hip': (ctypes.c_int, [ctypes.c_double, ctypes.c_double, ctypes.c_int64, _dp, _dp, _dp, _dp,
                                           ctypes.c_int32, ctypes.c_int64, _dp, _dp, _dp]),
+    'smart_hook_counters': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int64), ctypes.c_int64]),
     'smart_onestep_hip': (ctypes.c_int, [ctypes.c_int64, _dp, _dp]),
     'smart_river_step_hip': (ctypes.c_int, [ctypes.c_int64, _dp, _dp]),
     'smart_objfn_hip': (ctypes.c_int, [ctypes.c_int64, ctypes.c_int64, _dp, ctypes.c_int64, _dp, _dp,

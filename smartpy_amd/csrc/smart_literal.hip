@@ -21,6 +21,21 @@ __global__ __launch_bounds__(kWave) void smart_ensemble_literal(KArgs a, const d
         run_ensemble<LiteralModel, false>(a, forcing, obs, ws, lds, (long)blockIdx.x, (long)blockIdx.y);
 }
 
+// The kernel behind smartcpp.allsteps (smart_allsteps_hip: one sample, a latency chain of one wavefront): the same loop
+// with the divisions by per-sample constants through cached reciprocals + correction step -- the division's bits
+// (smart_literal_model.h, RECIP), a quarter fewer instructions per step.  The ensemble's literal mode above keeps the
+// true divisions: it is the anchor the reciprocal path is compared with.
+__global__ __launch_bounds__(kWave) void smart_ensemble_literal_recip(KArgs a, const double2 *__restrict__ forcing,
+                                                                      const double *__restrict__ obs,
+                                                                      const double *__restrict__ ws)
+{
+    extern __shared__ double lds[];
+    if (a.np_mean)
+        run_ensemble<LiteralModelRecip, true>(a, forcing, obs, ws, lds, (long)blockIdx.x, (long)blockIdx.y);
+    else
+        run_ensemble<LiteralModelRecip, false>(a, forcing, obs, ws, lds, (long)blockIdx.x, (long)blockIdx.y);
+}
+
 // smartcpp.onestep stand-in: n independent single steps (structure.py:200-264)
 __global__ __launch_bounds__(kWave) void smart_onestep_literal(long n, const double *in, double *out)
 {
@@ -65,9 +80,14 @@ void launch_river(long n, const double *in, double *out, hipStream_t s)
     hipLaunchKernelGGL(smart_river_literal, dim3((unsigned)((n + kWave - 1) / kWave)), dim3(kWave), 0, s, n, in, out);
 }
 
-void launch_literal(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s)
+void launch_literal(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s, bool recip)
 {
-    hipLaunchKernelGGL(smart_ensemble_literal, grid, dim3(kWave), lds_bytes, s, a, reinterpret_cast<const double2 *>(a.forcing), a.obs, a.ws);
+    if (recip)
+        hipLaunchKernelGGL(smart_ensemble_literal_recip, grid, dim3(kWave), lds_bytes, s, a,
+                           reinterpret_cast<const double2 *>(a.forcing), a.obs, a.ws);
+    else
+        hipLaunchKernelGGL(smart_ensemble_literal, grid, dim3(kWave), lds_bytes, s, a,
+                           reinterpret_cast<const double2 *>(a.forcing), a.obs, a.ws);
 }
 
 void launch_onestep(long n, const double *in, double *out, hipStream_t s)

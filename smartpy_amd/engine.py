@@ -496,6 +496,14 @@ def allsteps(area_m2, delta_sec, length_simu, nd_rain, nd_peva, nd_parameters, n
     return dis, gw.value, fin
 
 
+def hook_counters():
+    """{calls, allocations, forcing_bytes_uploaded, fast_calls} of the smartcpp.allsteps stand-in since the library
+    was loaded (smart_hook_counters)."""
+    c = (ctypes.c_int64 * 4)()
+    _lib.check(_lib.lib().smart_hook_counters(c, 4))
+    return dict(zip(('calls', 'allocations', 'forcing_bytes_uploaded', 'fast_calls'), (int(v) for v in c)))
+
+
 def onestep(*args):
     """smartcpp.onestep: the 26 positional floats of run_one_step (structure.py:200-206) -> 19 floats."""
     if len(args) != 26:

@@ -218,6 +218,64 @@ def test_allsteps_is_interchangeable_with_run_all_steps(eng, example):
     assert rel(fin_wu[7:], k1['initial_run'][7:]) < 1e-12
 
 
+def test_allsteps_keeps_its_buffers_and_the_series_between_calls(eng, example, monkeypatch):
+    """The reference calls smartcpp.allsteps twice per simulate() with the same series (warm-up over its first W steps,
+    then the run: structure.py:118-121,143-146) and a calibration loop repeats that thousands of times.  The library
+    keeps its device buffers and the uploaded series: the second simulate() allocates nothing and uploads nothing, a
+    changed series is noticed (compared, not assumed), and SMART_ALLSTEPS_MATH=fast serves the same call from the
+    fast kernels."""
+    import time
+    k1 = load_golden('kat1_hourly.npz')
+    rain, peva = example['rain_hourly'].copy(), example['peva_hourly'].copy()
+    L, W = len(rain), 8760
+
+    def simulate():
+        _, _, fin = eng.allsteps(example['area'], 3600.0, W, rain, peva, example['params'], k1['initial_warmup'], 1, 24)
+        return eng.allsteps(example['area'], 3600.0, L, rain, peva, example['params'], fin, 1, 24)
+
+    first = simulate()
+    c0 = eng.hook_counters()
+    t0 = time.perf_counter()
+    second = simulate()
+    literal_s = time.perf_counter() - t0
+    c1 = eng.hook_counters()
+    assert c1['calls'] == c0['calls'] + 2 and c1['allocations'] == c0['allocations']
+    assert c1['forcing_bytes_uploaded'] == c0['forcing_bytes_uploaded']
+    assert bits_equal(first[0], second[0]) and first[1] == second[1] and bits_equal(first[2], second[2])
+    assert bits_equal(first[0], k1['discharge_summary']) or rel(first[0], k1['discharge_summary']) < 1e-11
+    # the literal hook is the literal ensemble kernel's arithmetic, divisions through reciprocals included: the oracle's bits
+    d0, g0, f0 = so.all_steps(example['area'], 3600.0, 24 * 90, rain, peva, example['params'], k1['initial_run'], 1, 24,
+                              pow_mode=so.POW_MUL, sum_mode=so.SUM_GPU)
+    d1, g1, f1 = eng.allsteps(example['area'], 3600.0, 24 * 90, rain, peva, example['params'], k1['initial_run'], 1, 24)
+    assert bits_equal(d1, d0) and bits_equal(f1, f0) and g1 == g0
+    # a series that differs somewhere is uploaded again from there on ... and gives another answer
+    rain[5000] += 0.25
+    changed = simulate()
+    c2 = eng.hook_counters()
+    assert c2['forcing_bytes_uploaded'] > c1['forcing_bytes_uploaded'] and c2['allocations'] == c1['allocations']
+    assert not bits_equal(changed[0], first[0])
+    rain[5000] -= 0.25
+    assert bits_equal(simulate()[0], first[0])
+    # the same calls in fast arithmetic
+    monkeypatch.setenv('SMART_ALLSTEPS_MATH', 'fast')
+    simulate()
+    t0 = time.perf_counter()
+    quick = simulate()
+    fast_s = time.perf_counter() - t0
+    assert eng.hook_counters()['fast_calls'] >= 4
+    assert rel(quick[0], first[0]) <= REL_FAST and abs(quick[1] - first[1]) <= 1e-10
+    assert rel(quick[2][7:], first[2][7:], floor=1e-290) <= 1e-8
+    print('allsteps per simulate(): literal %.1f ms, fast %.1f ms' % (literal_s * 1e3, fast_s * 1e3))
+    assert fast_s < 0.03 and literal_s < 0.12
+    # raw reports through the hook as well (fast: smart_fast_plain, the final row is asked for)
+    for mode in ('fast', 'literal'):
+        monkeypatch.setenv('SMART_ALLSTEPS_MATH', mode)
+        d, g, f = eng.allsteps(example['area'], 3600.0, 24 * 50 + 5, rain, peva, example['params'], k1['initial_run'], 2, 24)
+        dr, gr, fr = so.all_steps(example['area'], 3600.0, 24 * 50 + 5, rain, peva, example['params'], k1['initial_run'],
+                                  2, 24)
+        assert d.shape == dr.shape == (51,) and rel(d, dr) <= REL_FAST and abs(g - gr) <= 1e-10
+
+
 def test_chained_runs_equal_one_run(eng, example):
     """final states of a run are a valid `initial` for the next (checkpoint / resume property)."""
     params = load_golden('kat4_batch.npz')['params']
