@@ -6,6 +6,7 @@
 #   suite              the whole GPU suite
 #   bench [args]       bench.py with the driver's K / W (--steps 20 --warmup 5) and a one-line digest of the legs
 #   ab LIB...          interleaved A/B of library variants (tools/ab_variants.sh)
+#   bits LIB           tools/debug/steps_bits.py: every output of the merged kernels, variant LIB against the default build
 #   profile TAG [bench args]   tools/profile.sh (kernel trace + PMC passes of the bench command)
 #   final              what the driver runs at round end (tools/gpu_final_check.sh)
 # Everything a stage prints also lands in gpurun_out/<stage>_*.log.
@@ -27,6 +28,11 @@ bench)
     ;;
 ab)
     bash tools/ab_variants.sh "$@" 2>&1 | tee gpurun_out/ab_round.log | tail -40
+    ;;
+bits)   # bits LIB: outputs of the merged kernels from library variant LIB and from the default build, bit for bit
+    SMART_AMD_LIB=$PWD/$1 python tools/debug/steps_bits.py dump /tmp/bits_a.npz > /dev/null
+    python tools/debug/steps_bits.py dump /tmp/bits_b.npz > /dev/null
+    python tools/debug/steps_bits.py compare /tmp/bits_a.npz /tmp/bits_b.npz 2>&1 | tee gpurun_out/bits_$(basename $1 .so).log | tail -5
     ;;
 profile)
     bash tools/profile.sh "$@"
