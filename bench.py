@@ -135,6 +135,24 @@ def pmc_summary(pmc_key, path=None, source_hash=None):
     return pmc, pmc.get('source', 'profiles/traffic_latest.json')
 
 
+def isa_model_summary(pmc_key, path=None, source_hash=None):
+    """The vector-instruction count of one workload as tools/isa_model.py derives it from the TREE (hipcc's assembly of
+    the hot loops weighed with the workload's path frequencies; cross-compiled, no GPU) -> (figures, source); like the
+    PMC summary only for the kernel sources it was derived from."""
+    path = path or os.path.join(ROOT, 'profiles', 'isa_model_latest.json')
+    if not os.path.exists(path):
+        return {}, 'no instruction model (profiles/isa_model_latest.json)'
+    with open(path) as fh:
+        model = json.load(fh).get('workloads', {}).get(pmc_key)
+    if model is None:
+        return {}, 'no instruction model for workload %s' % pmc_key
+    now = source_hash or kernel_source_hash()
+    if model.get('source_hash') != now:
+        return {}, 'profiles/isa_model_latest.json was derived from other kernel sources (hash %s, now %s): not quoted' \
+                   % (model.get('source_hash'), now)
+    return model, model.get('source', 'profiles/isa_model_latest.json')
+
+
 def cpu_baseline_and_parity(forcing, n_warm, gap, dt, device, budget_s=12.0):
     """(1) The oracle's OpenMP batch runner (a C port of the reference loop) on the host cores, on a bounded sample of
     the same workload: reported next to the GPU number, never part of the timed GPU region.  (2) The same rows through
@@ -276,9 +294,13 @@ def main():
     ranges = Parameters().ranges
     d_forcing = torch.from_numpy(forcing).to(device)
 
-    # observations: discharge of the "truth" parameter set (computed by the engine itself) x lognormal noise, 12 % NaN
-    truth = engine.run_ensemble(np.array([TRUTH]), d_forcing, AREA, dt, W, gap, extra=EXTRA, device=device)
-    obs = truth.discharge[0].cpu().numpy() * np.exp(rng.normal(0.0, 0.2, R))
+    # observations: the CPU twin's discharge of the "truth" parameter set x lognormal noise, 12 % NaN.
+    # Input data of the benchmark, made before anything is timed by the same checker the cpu_baseline leg times (round 3
+    # took them from a run of the engine itself: circular)
+    from oracle import smart_oracle as so
+    truth = so.run_batch(AREA, dt, T, W, np.ascontiguousarray(forcing[:, 0]), np.ascontiguousarray(forcing[:, 1]),
+                         np.array([TRUTH]), EXTRA, so.REPORT_SUMMARY, gap, want_discharge=True, n_threads=1)[0]
+    obs = truth[0] * np.exp(rng.normal(0.0, 0.2, R))
     obs[rng.random(R) < 0.12] = np.nan
 
     store = not args.no_discharge and cfg in (2, 3)     # configs 4 and 5 gather objective functions only
@@ -366,7 +388,13 @@ def main():
         pmc, pmc_note = pmc_summary(pmc_key)
         traffic, insts = pmc.get('hbm_bytes_per_launch'), pmc.get('valu_insts_per_launch')
         held_clock, held_frac = pmc.get('held_clock_hz'), pmc.get('issue_frac_at_held_clock')
-        fp64_share = pmc.get('fp64_share_of_valu')
+        model, model_note = isa_model_summary(pmc_key)
+        insts_model = model.get('valu_insts_per_launch')
+        # the share of the vector instructions that are fp64 ARITHMETIC (fma / add / mul / min / max / ldexp): the
+        # instruction model's, from the compiler's assembly; the PMC summary's figure (the same model over the MEASURED
+        # instruction count) when there is no model for this build.  The counters' own share (FMA + ADD + MUL classes
+        # only: min / max / ldexp are in none of them) is executed_flops' business, not this one's.
+        fp64_share = model.get('fp64_share_of_valu', pmc.get('fp64_share_of_valu'))
         flops = pmc.get('fp64_flops_per_launch')
         issue = None if insts is None else insts * VALU_ISSUE_CYCLES / (N_SIMD * kern_s * CLOCK_HZ)
         roofline = {
@@ -393,6 +421,14 @@ def main():
             'frac_at_held_clock': held_frac, 'held_clock_hz': held_clock,
             'valu_insts_per_launch': insts,
             'valu_insts_per_wave_step': None if insts is None else insts / (blocks_local * steps_per_run),
+            # the same count derived from the tree alone (tools/isa_model.py): the two agree within 3 % or the fraction
+            # above is not to be trusted (tests/test_isa_model.py holds them against each other)
+            'valu_insts_model': insts_model,
+            'valu_insts_model_per_wave_step': None if insts_model is None else insts_model / (blocks_local * steps_per_run),
+            'valu_insts_model_vs_pmc': None if insts is None or insts_model is None else insts_model / insts,
+            'frac_from_model': None if insts_model is None else
+            insts_model * VALU_ISSUE_CYCLES / (N_SIMD * kern_s * CLOCK_HZ),
+            'model_source': model_note,
             'kernel': kernels, 'launch_ms': launch_ms, 'traffic': traffic, 'pmc_key': pmc_key, 'pmc_source': pmc_note,
             # the reference's literal operation count against the fp64 vector peak: NOT a bound (the kernel executes
             # fewer operations than the reference writes down), kept as the algorithmic ratio

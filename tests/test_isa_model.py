@@ -39,15 +39,23 @@ def test_the_headline_wet_step_is_73_fp64_instructions_and_the_count_matches_the
     short = m['absorbed_step']
     assert short['fp64'] == 56 and short['VALU'] == 57 and short['scalar'] == 1
     assert 0.3 < m['absorbed_share'] < 0.5
-    assert 0.80 <= m['fp64_share_of_valu'] <= 1.0          # a lower bound: hipcc's glue counted on both sides of its branches
+    assert 0.90 <= m['fp64_share_of_valu'] <= 1.0
+    # hipcc's code around the asm loops, block by block, weighed with the workload's path frequencies: between the wet
+    # steps alone and round 3's bound (every block for every interval)
+    assert m['fp64_in_wet_steps_per_wave_step'] < m['valu_per_wave_step'] < m['valu_per_wave_step_upper']
+    assert 40 < m['glue_per_interval']['VALU'] < 80
+    # the model that bench.py quotes (profiles/isa_model_latest.json) is this one, for these kernel sources
+    sys.path.insert(0, ROOT)
+    import bench
+    quoted, note = bench.isa_model_summary('config3:runs_per_gpu=100000:discharge=1:math=fast')
+    if quoted:
+        assert abs(quoted['valu_insts_per_launch'] - m['valu_insts_per_launch']) < 1e-6 * m['valu_insts_per_launch']
     entry, note = measured('config3:runs_per_gpu=100000:discharge=1:math=fast')
     if not entry:
         pytest.skip('no PMC summary for the current kernel sources: ' + note)
     per_wave_step = entry['valu_insts_per_launch'] / m['wave_steps']
-    # the model's figure is an upper bound (both sides of hipcc's wet / dry branch around the asm are counted for
-    # every interval), the wet steps alone a lower one: the measured count lies between them
-    assert m['fp64_in_wet_steps_per_wave_step'] <= per_wave_step <= m['valu_per_wave_step_upper'] * 1.01, \
-        (m['fp64_in_wet_steps_per_wave_step'], per_wave_step, m['valu_per_wave_step_upper'])
+    # round-3 verdict, item 5: the count derived from the tree within 3 % of the one the counters measured
+    assert abs(m['valu_per_wave_step'] - per_wave_step) <= 0.03 * per_wave_step, (m['valu_per_wave_step'], per_wave_step)
 
 
 def test_the_arms_of_the_step_loop_have_the_documented_sizes(tmp_path):

@@ -3,14 +3,16 @@
 workloads -> expected instructions per wave-step, per class, to hold against the PMC counters (SQ_INSTS_VALU /
 SQ_INSTS_SALU of profiles/r03_*.md).  Needs hipcc (cross-compiles without a GPU), no GPU.
 
-    python tools/isa_model.py steps      [profiles/r03_isa_model_steps]        the flat_forcing leg (smart_fast_steps)
-    python tools/isa_model.py intervals  [profiles/r03_isa_model_intervals]    the headline run (smart_fast_intervals)
+    python tools/isa_model.py steps      [profiles/r04_isa_model_steps]        the flat_forcing leg (smart_fast_steps)
+    python tools/isa_model.py intervals  [profiles/r04_isa_model_intervals]    the headline run (smart_fast_intervals)
 
 The hot loops are `asm` statements (smartpy_amd/csrc/smart_fast_arms.h): in hipcc -S output they stand between
 ;;#ASMSTART / ;;#ASMEND with their local labels intact, so every arm is delimited by its label (100: calm, 110: dry,
 120: rain arm of step 0, ... 130: end of chunk; 5: / 6: the two loops of the wet interval).  The classes are those of
 tools/isa_report.py.  What is NOT in an asm (the glue hipcc writes around the chunks and the intervals) is counted
-from the enclosing loop of the same listing.
+from the enclosing loop of the same listing: every basic block of it, weighed with the share of the workload's
+(wavefront, interval) pairs that run it (round 4: glue_per_interval; round 3 counted both sides of every branch).  The
+intervals model also lands in profiles/isa_model_latest.json, which bench.py quotes as roofline.valu_insts_model.
 """
 import json
 import os
@@ -85,6 +87,91 @@ def segments(body):
         else:
             seg[cur].append(op)
     return seg
+
+
+def loop_blocks(lines, blocks):
+    """The basic blocks hipcc wrote, grouped by the innermost compiler loop LLVM's comments assign them to
+    (`.LBBx_y:  ; in Loop: Header=BBx_z` / `; %bb.N:  ; in Loop: ...`, the header itself `; =>This ... Loop Header`)
+    -> {header: [block]}, block = {'ops': [opcodes outside asm], 'asm': 'wet' | 'calm' | None, 'pre': ops of the block
+    that falls into it}.  An asm statement is a block of its own."""
+    in_asm = {}
+    for a, b, body in blocks:
+        labs = {lab for lab, _ in body}
+        kind = 'wet' if {'5', '6', '7', '9'} <= labs else ('calm' if len(body) > 60 else 'other')
+        for i in range(a, b + 1):
+            in_asm[i] = (a, kind)
+    loops, header, cur = {}, None, None
+
+    def start(h):
+        nonlocal cur
+        if cur is not None and not cur['ops'] and not cur['asm'] and loops.get(h) and loops[h][-1] is cur:
+            return                                   # (nothing in the block at hand yet: it is the new one)
+        cur = {'ops': [], 'asm': None}
+        loops.setdefault(h, []).append(cur)
+
+    for i, ln in enumerate(lines):
+        m = re.match(r'^(?:\.LBB(\d+_\d+):|; %bb\.\d+:)\s*;\s*(=>\s*This (?:Inner )?Loop Header|in Loop: Header=BB(\d+_\d+))', ln)
+        if m:
+            header = m.group(1) if m.group(2).startswith('=>') else m.group(3)
+            start(header)
+            continue
+        if re.match(r'^(\.LBB\d+_\d+:|; %bb\.\d+:)', ln):          # a block outside every loop
+            header, cur = None, None
+            continue
+        if cur is None:
+            continue
+        if i in in_asm:
+            if in_asm[i][0] == i:
+                start(header)
+                cur['asm'] = in_asm[i][1]
+                start(header)
+            continue
+        t = ln.split(';')[0].strip()
+        if not t or t.startswith('.') or t.endswith(':'):
+            continue
+        op = t.split()[0]
+        cur['ops'].append(op)
+        if op.startswith(('s_cbranch', 's_branch')):
+            start(header)
+    return loops
+
+
+def glue_per_interval(blks, p):
+    """Expected vector / scalar instructions per report interval of hipcc's code AROUND the asm loops of one compiler loop
+    (unrolled over kGroup = 4 intervals): every basic block weighed with how often the workload runs it, told from what
+    the block holds --
+      the evaporation cascade + the dry map (>= 10 v_max_f64): the dry side of the per-lane branch (the block behind
+          s_andn2_saveexec) or its copy for rainless intervals, picked on the scalar unit
+      the block that falls into a wet / a calm asm loop (layer sum, e_h): that loop's share
+      the objective-function moments (a handful of fma on a branch of their own): the share of observed reports
+      anything else (the loop, the tests, the store): every interval."""
+    n_asm = sum(1 for b in blks if b['asm'] == 'wet')
+    assert n_asm and n_asm % 4 == 0 or n_asm == 4, n_asm
+    tot = Counter()
+    detail = Counter()
+    for k, b in enumerate(blks):
+        if b['asm']:
+            continue
+        h = hist(b['ops'])
+        nxt = blks[k + 1]['asm'] if k + 1 < len(blks) else None
+        prev_ops = blks[k - 1]['ops'] if k else []
+        n_max = b['ops'].count('v_max_f64')
+        n_fma = sum(1 for o in b['ops'] if o.startswith(('v_fma', 'v_fmac')))
+        if n_max >= 10:
+            cls = 'dry_lanes' if 's_andn2_saveexec_b64' in prev_ops else 'dry_scalar'
+        elif nxt == 'wet':
+            cls = 'wet'
+        elif nxt == 'calm':
+            cls = 'calm'
+        elif n_fma >= 3 and n_max == 0 and h['VALU'] <= 14:
+            cls = 'moments'
+        else:
+            cls = 'always'
+        w = p[cls]
+        for c in ('VALU', 'fp64', 'scalar'):
+            tot[c] += h[c] * w
+        detail[cls] += h['VALU']
+    return {c: tot[c] / n_asm for c in tot}, {c: v / n_asm for c, v in detail.items()}
 
 
 def fill_paths(workload):
@@ -271,26 +358,7 @@ def intervals_model(out):
               '- steps in the absorbed prefix of their interval: %.3f of the wet wave-steps; intervals that change '
               'mode: %.2f of the wet ones (tools/fill_paths.py, %d rows)' % (share, paths['mode_switches_per_wet_run'],
                                                                           paths['rows']), '']
-    # per-interval glue: everything of the run loop (the compiler loop around the asm statements of the report
-    # intervals) that is not inside an asm, per interval of the loop body (4 intervals per turn: kGroup)
-    # -> counted from the listing between the first and the last wet asm of the group that emits with prefetched
-    #    observations; reported as an upper bound (both sides of the wet / dry branch)
-    grp = wet[-4:] if len(wet) >= 4 else wet
-    span = lines[grp[0][0] - 60:grp[-1][1] + 60]
-    outside = []
-    inside = False
-    for ln in span:
-        if 'ASMSTART' in ln:
-            inside = True
-        elif 'ASMEND' in ln:
-            inside = False
-        elif not inside:
-            outside.append(ln)
-    glue = hist([op for lab, op in insts(outside) if op])
-    per_iv = {c: glue[c] / len(grp) for c in glue}
-    report.append('- hipcc\'s code around the wet asm, per interval, BOTH sides of the wet / dry branch, emit included '
-                  '(upper bound): VALU %.1f (fp64 %.1f), scalar %.1f' % (per_iv['VALU'], per_iv.get('fp64', 0),
-                                                                         per_iv['scalar']))
+    # ---- what the workload does, per (wavefront, interval): 1e5 LHS rows as drawn, 64 per wavefront
     base = bench.synthetic_forcing(0, True)[0]
     f = np.concatenate([base[:bench.WARM_DAYS * 24], base])[::24]
     rain, pe = f[:, 0], f[:, 1]
@@ -298,28 +366,62 @@ def intervals_model(out):
     pad = (-len(T)) % 64
     Tw = np.concatenate([T, np.full(pad, T[-1])]).reshape(-1, 64)
     tmin, tmax = Tw.min(1), Tw.max(1)
+    scalar_dry = (rain == 0) & (pe > 0)              # decided on the scalar unit (QUICK waves: all of them here)
+    scalar_calm = (rain == 0) & (pe == 0)
+    lanes = ~(scalar_dry | scalar_calm)
     with np.errstate(divide='ignore', invalid='ignore'):
-        thr = np.where(rain > 0, pe / rain, np.where(pe > 0, np.inf, -np.inf))
-    any_wet = tmax[:, None] >= thr[None, :]
-    any_dry = tmin[:, None] < thr[None, :]
+        thr = np.where(rain > 0, pe / rain, np.inf)
+    any_wet = (tmax[:, None] >= thr[None, :]) & lanes[None, :]
+    any_dry = (tmin[:, None] < thr[None, :]) & lanes[None, :]
     n_waves, n_iv = any_wet.shape
     ws = n_waves * n_iv * 24
     n_wet, n_dry = int(any_wet.sum()), int(any_dry.sum())
+    rng = bench.synthetic_forcing(0, True)[1]         # the bench's observations: 12 % missing (bench.py main())
+    rng.normal(0.0, 0.2, n_iv - bench.WARM_DAYS)
+    observed = 1.0 - float((rng.random(n_iv - bench.WARM_DAYS) < 0.12).mean())
+    share_of = {'dry_lanes': n_dry / (n_waves * n_iv), 'dry_scalar': float(scalar_dry.mean()),
+                'wet': n_wet / (n_waves * n_iv), 'calm': float(scalar_calm.mean()), 'moments': observed, 'always': 1.0}
+    # ---- hipcc's code around the asm loops: the compiler loops that hold four wet asm statements (kGroup = 4 intervals a
+    # turn): the run loop is the one with the discharge stores and the moments, the warm-up loop the one without stores
+    loops = loop_blocks(lines, blocks)
+    cands = {h: b for h, b in loops.items() if sum(1 for x in b if x['asm'] == 'wet') == 4}
+    stores = {h: sum(x['ops'].count('global_store_dwordx2') for x in b) for h, b in cands.items()}
+    fmas = {h: sum(sum(1 for o in x['ops'] if o.startswith('v_fmac')) for x in b if not x['asm']) for h, b in cands.items()}
+    run_h = max((h for h in cands if stores[h] >= 4), key=lambda h: fmas[h])
+    warm_h = max((h for h in cands if stores[h] == 0), key=lambda h: len(cands[h]))
+    glue_run, detail_run = glue_per_interval(cands[run_h], share_of)
+    glue_warm, _ = glue_per_interval(cands[warm_h], dict(share_of, moments=0.0))
+    upper_run, _ = glue_per_interval(cands[run_h], {k: 1.0 for k in share_of})
+    w_warm = bench.WARM_DAYS / n_iv
+    per_iv = {c: (1 - w_warm) * glue_run[c] + w_warm * glue_warm[c] for c in glue_run}
+    report.append('- hipcc\'s code around the asm loops, per interval: every basic block of the run loop (.LBB%s) and of the '
+                  'warm-up loop (.LBB%s) weighed with the share of the (wavefront, interval) pairs that run it -- dry side of '
+                  'the per-lane branch %.3f, rainless intervals picked on the scalar unit %.3f, wet side %.3f, observed '
+                  'reports %.3f: VALU %.1f (fp64 %.1f), scalar %.1f; with every block counted for every interval (round '
+                  '3\'s upper bound): VALU %.1f' % (run_h, warm_h, share_of['dry_lanes'], share_of['dry_scalar'],
+                                                    share_of['wet'], observed, per_iv['VALU'], per_iv.get('fp64', 0),
+                                                    per_iv['scalar'], upper_run['VALU']))
+    report.append('  (vector instructions of the run loop\'s blocks by kind, per interval, unweighed: %s)' % ', '.join(
+        '%s %.1f' % kv for kv in sorted(detail_run.items())))
     mean = {c: share * absorbed[c] + (1 - share) * step[c] for c in ('VALU', 'fp64', 'scalar')}
     # (the step that changes mode runs the absorbed head, its compare and the full rest: one instruction more)
-    valu = n_wet * (24 * mean['VALU'] + paths['mode_switches_per_wet_run'] + entry['VALU']) + n_waves * n_iv * per_iv['VALU']
+    valu_wet = n_wet * (24 * mean['VALU'] + paths['mode_switches_per_wet_run'] + entry['VALU'])
+    valu = valu_wet + n_waves * n_iv * per_iv['VALU']
+    valu_upper = valu_wet + n_waves * n_iv * upper_run['VALU']
     fp64_wet = n_wet * 24 * mean['fp64']
     fp64 = fp64_wet + n_waves * n_iv * per_iv.get('fp64', 0)
     scal = n_wet * (24 * (loop_tail['scalar'] + mean['scalar']) + entry['scalar']) + n_waves * n_iv * per_iv['scalar']
     report += ['', '## headline run (1e5 LHS rows as drawn, %d wavefronts x %d intervals of 24 steps)' % (n_waves, n_iv), '',
-               '- intervals with a wet lane in the wave: %.4f; with a dry lane: %.4f (both: %.4f)' % (
-                   n_wet / (n_waves * n_iv), n_dry / (n_waves * n_iv), (any_wet & any_dry).mean()),
-               '- expected per wave-step: vector instructions <= %.2f, of them fp64 arithmetic >= %.2f in the wet steps '
-               'alone (%.3f of the vector instructions); scalar ALU + branches <= %.2f' % (
-                   valu / ws, fp64_wet / ws, fp64_wet / valu, scal / ws), '']
-    result = {'kernel': 'smart_fast_intervals', 'wave_steps': ws, 'valu_per_wave_step_upper': valu / ws,
-              'fp64_in_wet_steps_per_wave_step': fp64_wet / ws, 'fp64_upper': fp64 / ws,
-              'fp64_share_of_valu': fp64_wet / valu, 'scalar_per_wave_step_upper': scal / ws,
+               '- intervals with a wet lane in the wave: %.4f; with a dry lane: %.4f (of them rainless: %.4f)' % (
+                   n_wet / (n_waves * n_iv), n_dry / (n_waves * n_iv) + share_of['dry_scalar'], share_of['dry_scalar']),
+               '- expected per wave-step: vector instructions %.2f (every block of the glue for every interval: <= %.2f), '
+               'of them fp64 arithmetic %.2f (%.3f of the vector instructions; %.2f in the wet steps alone); scalar ALU + '
+               'branches %.2f' % (valu / ws, valu_upper / ws, fp64 / ws, fp64 / valu, fp64_wet / ws, scal / ws), '']
+    result = {'kernel': 'smart_fast_intervals', 'wave_steps': ws, 'valu_per_wave_step': valu / ws,
+              'valu_per_wave_step_upper': valu_upper / ws, 'valu_insts_per_launch': valu,
+              'fp64_in_wet_steps_per_wave_step': fp64_wet / ws, 'fp64_per_wave_step': fp64 / ws,
+              'fp64_share_of_valu': fp64 / valu, 'scalar_per_wave_step': scal / ws, 'glue_per_interval': per_iv,
+              'workload': 'config3:runs_per_gpu=100000:discharge=1:math=fast', 'source_hash': bench.kernel_source_hash(),
               'wet_step': dict(step), 'absorbed_step': dict(absorbed), 'absorbed_share': share,
               'wet_interval_fraction': n_wet / (n_waves * n_iv)}
     finish(out, report, result)
@@ -332,6 +434,18 @@ def finish(out, report, result):
             fh.write('\n'.join(report) + '\n')
         with open(out + '.json', 'w') as fh:
             json.dump(result, fh, indent=1)
+        if 'workload' in result and os.path.dirname(os.path.abspath(out)) == os.path.join(ROOT, 'profiles'):
+            # what bench.py quotes next to the PMC count (roofline.valu_insts_model), keyed like profiles/traffic_latest.json
+            latest = os.path.join(ROOT, 'profiles', 'isa_model_latest.json')
+            table = json.load(open(latest)) if os.path.exists(latest) else {'workloads': {}}
+            table['workloads'][result['workload']] = {
+                'kernel': result['kernel'], 'source_hash': result['source_hash'],
+                'valu_insts_per_launch': result['valu_insts_per_launch'],
+                'valu_per_wave_step': result['valu_per_wave_step'], 'fp64_share_of_valu': result['fp64_share_of_valu'],
+                'source': 'profiles/%s.md: tools/isa_model.py (the compiler\'s assembly of the hot loops weighed with the '
+                          'workload\'s path frequencies; no GPU involved)' % os.path.basename(out)}
+            with open(latest, 'w') as fh:
+                json.dump(table, fh, indent=1)
 
 
 if __name__ == '__main__':

@@ -40,12 +40,16 @@ def fp64_share(kernel, measured_valu=None, workload=''):
     around the asm loops is counted on both sides of its branches); for the workload the model describes (the headline
     run) the fp64 instructions of the wet steps over the MEASURED vector instructions"""
     name = kernel.split('::')[-1]
-    path = os.path.join(os.path.dirname(dst) or '.', 'r03_isa_model_%s.json' % name.replace('smart_fast_', ''))
-    if not os.path.exists(path):
+    found = sorted(glob.glob(os.path.join(os.path.dirname(dst) or '.', 'r0?_isa_model_%s.json'
+                                          % name.replace('smart_fast_', ''))))
+    if not found:
         return None
-    model = json.load(open(path))
-    if measured_valu and workload.startswith('config3:runs_per_gpu=100000') and 'fp64_in_wet_steps_per_wave_step' in model:
-        return model['fp64_in_wet_steps_per_wave_step'] * model['wave_steps'] / measured_valu
+    model = json.load(open(found[-1]))              # the latest round's
+    if measured_valu and workload.startswith('config3:runs_per_gpu=100000'):
+        if 'fp64_per_wave_step' in model:          # round 4: the glue's arithmetic included
+            return model['fp64_per_wave_step'] * model['wave_steps'] / measured_valu
+        if 'fp64_in_wet_steps_per_wave_step' in model:
+            return model['fp64_in_wet_steps_per_wave_step'] * model['wave_steps'] / measured_valu
     share = model.get('fp64_share_of_valu')
     return min(share) if isinstance(share, list) else share
 
