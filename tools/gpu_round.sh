@@ -8,6 +8,8 @@
 #   ab LIB...          interleaved A/B of library variants (tools/ab_variants.sh)
 #   bits LIB           tools/debug/steps_bits.py: every output of the merged kernels, variant LIB against the default build
 #   profile TAG [bench args]   tools/profile.sh (kernel trace + PMC passes of the bench command)
+#   soak               tools/gpu_soak.sh: thousands of sliced launches against the unsliced one, competitors beside them
+#   slices             4 / 8 / 16 time slices on configs 4 and 5 (where the hand-over is the only HBM traffic)
 #   final              what the driver runs at round end (tools/gpu_final_check.sh)
 # Everything a stage prints also lands in gpurun_out/<stage>_*.log.
 export TMPDIR=/tmp
@@ -36,6 +38,15 @@ bits)   # bits LIB: outputs of the merged kernels from library variant LIB and f
     ;;
 profile)
     bash tools/profile.sh "$@"
+    ;;
+soak)
+    bash tools/gpu_soak.sh 2>&1 | tee gpurun_out/soak_round.log | tail -40
+    ;;
+slices) # slice counts at the loads where the hand-over is the only HBM traffic (configs 4 and 5 on one GPU)
+    for cfg in 4 5; do for rep in 1 2; do for k in default 4 8 16; do
+        if [ $k = default ]; then unset SMART_TIME_SLICES; else export SMART_TIME_SLICES=$k; fi
+        echo -n "config $cfg slices $k: "; timeout 600 python bench.py --config $cfg --steps 4 --warmup 1 --no-cpu-baseline --no-flat 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.3f ms  %s' % (d['roofline']['launch_ms'], d['roofline']['kernel']))"
+    done; done; done 2>&1 | tee gpurun_out/slices_round.log
     ;;
 final)
     bash tools/gpu_final_check.sh
