@@ -1,0 +1,27 @@
+#!/bin/bash
+# condense what tools/gpu_profile_r04.sh brought back into profiles/ (run in the build container, after the gpurun call)
+S=tools/summarize_profile.py
+# the instruction models first: the summaries quote their fp64 shares (needs profiles/r03_fill_paths.json: tools/fill_paths.py)
+python tools/isa_model.py intervals profiles/r04_isa_model_intervals > /dev/null 2>&1
+python tools/isa_model.py steps profiles/r04_isa_model_steps > /dev/null 2>&1
+python $S gpurun_out/prof_r04_config3 profiles/r04_config3 "config3:runs_per_gpu=100000:discharge=1:math=fast" > /dev/null
+python $S gpurun_out/prof_r04_config4_shard profiles/r04_config4_shard "config4:runs_per_gpu=125000:discharge=0:math=fast" > /dev/null
+python $S gpurun_out/prof_r04_config4_1gpu profiles/r04_config4_1gpu "config4:runs_per_gpu=1000000:discharge=0:math=fast" > /dev/null
+python $S gpurun_out/prof_r04_config5_1gpu profiles/r04_config5_1gpu "config5:runs_per_gpu=640000:discharge=0:math=fast" > /dev/null
+python $S gpurun_out/prof_r04_config2 profiles/r04_config2 "config2:runs_per_gpu=10000:discharge=1:math=fast" > /dev/null
+for t in flat_forcing flat_forcing_1e6 runs_of_6 raw_gap24 raw_gap24_flat gap1; do python $S gpurun_out/prof_r04_$t profiles/r04_$t > /dev/null; done
+# the three kernels that took over from smart_fast_plain, side by side (the verdict's profiles/r04_plain.md)
+{ echo "# Raw reports and a report every step (round 4): the kernels that took over from smart_fast_plain"; echo
+  echo "1e5 LHS samples x hourly 10 yr + 1 yr warm-up, objective functions fused, no discharge matrix (tools/debug/reports_only.py);"
+  echo "round 3 ran these through smart_fast_plain, the general step loop, unsliced: 24.8 ms (raw, gap 24) and 43.7 ms (gap 1)."
+  for t in raw_gap24 raw_gap24_flat gap1; do echo; echo "## $t"; echo; sed -n '/kernel stats/,$p' profiles/r04_$t.md; done; } > profiles/r04_plain.md
+cp gpurun_out/r04_recip_bits.txt profiles/
+[ -f gpurun_out/soak_round.log ] && cp gpurun_out/soak_round.log profiles/r04_time_slice_soak.txt
+for c in "" _c2 _c4 _c5 _c4shard; do grep '^{' gpurun_out/bench_r04$c.log > profiles/r04_bench_${c#_}.jsonl; done
+mv profiles/r04_bench_.jsonl profiles/r04_bench_config3.jsonl
+for k in steps intervals steps_every intervals_raw; do python tools/isa_report.py smart_fast_$k profiles/r04_isa_$k --hot > /dev/null; done
+python tools/kernel_resources.py > profiles/r04_kernel_resources.txt 2>/dev/null
+for t in config3 flat_forcing flat_forcing_1e6 runs_of_6 raw_gap24 raw_gap24_flat gap1 config2 config4_1gpu config4_shard config5_1gpu; do
+  echo "== $t"; grep -A4 "clock held and issue" profiles/r04_$t.md | tail -2; grep "timed steps\|traffic (corrected)" profiles/r04_$t.md; done
+tail -1 profiles/r04_recip_bits.txt
+cat gpurun_out/prof_r04_config3/source_hash.txt; python -c "import bench; print(bench.kernel_source_hash())"
