@@ -299,7 +299,7 @@ def main():
     # took them from a run of the engine itself: circular)
     from oracle import smart_oracle as so
     truth = so.run_batch(AREA, dt, T, W, np.ascontiguousarray(forcing[:, 0]), np.ascontiguousarray(forcing[:, 1]),
-                         np.array([TRUTH]), EXTRA, so.REPORT_SUMMARY, gap, want_discharge=True, n_threads=1)[0]
+                         np.array([TRUTH]), EXTRA, so.REPORT_SUMMARY, gap, want_discharge=True)[0]
     obs = truth[0] * np.exp(rng.normal(0.0, 0.2, R))
     obs[rng.random(R) < 0.12] = np.nan
 

@@ -1155,14 +1155,30 @@ def test_randomized_interval_engine(eng, monkeypatch):
     assert run_interval_cases(eng, setenv, 20261003, 45) < 1e-10
 
 
-def run_interval_cases(eng, setenv, seed, n_cases):
-    """-> largest relative discharge error seen (tools/debug/fuzz_wide.py runs more seeds of this)."""
+def test_randomized_raw_and_every_step_reports(eng, monkeypatch):
+    """The same family under report='raw' (30 set-ups: smart_fast_intervals_raw / smart_fast_steps_raw, or
+    smart_fast_plain when the final row is asked for) and under a report every step (15 set-ups, summary or raw at
+    gap 1: smart_fast_steps_every)."""
+    def setenv(name, val):
+        if val:
+            monkeypatch.setenv(name, str(val))
+        else:
+            monkeypatch.delenv(name, raising=False)
+    assert run_interval_cases(eng, setenv, 20261004, 30, mode='raw') < 1e-10
+    assert run_interval_cases(eng, setenv, 20261005, 15, mode='every') < 1e-10
+
+
+def run_interval_cases(eng, setenv, seed, n_cases, mode='summary'):
+    """-> largest relative discharge error seen (tools/debug/fuzz_wide.py runs more seeds of this).
+    mode: 'summary' (interval means), 'raw' (the last step of each interval), 'every' (gap 1, either report type)."""
     rng = np.random.default_rng(seed)
     worst = 0.0
     for case in range(n_cases):
         dt = float(rng.choice([900.0, 3600.0, 10800.0]))
         gap = int(rng.choice([2, 3, 4, 8, 12, 24, 48]))    # (4, 12: whole chunks of four steps, but an odd number of them)
         n_rep = int(rng.integers(64, 200))
+        if mode == 'every':         # the forcing is still made of intervals of `gap` steps; the REPORT is every step
+            n_rep = int(rng.integers(16, 60))
         T = n_rep * gap
         W = int(rng.integers(0, n_rep // 2 + 1)) * gap if rng.random() < 0.7 else 0
         scale = dt / 86400.0 * gap
@@ -1196,21 +1212,35 @@ def run_interval_cases(eng, setenv, seed, n_cases):
         params = lhs_oracle.lhs_params(max(n, 2), seed=int(rng.integers(1 << 30)))[:n]
         extra = {'aar': float(rng.uniform(600, 2500)), 'r-o_ratio': float(rng.uniform(0.2, 0.7)),
                  'r-o_split': tuple(rng.dirichlet(np.ones(5)))} if rng.random() < 0.7 else None
-        obs = rng.random(n_rep) * 3
-        obs[rng.random(n_rep) < 0.15] = np.nan
+        report, rtype = 'summary', so.REPORT_SUMMARY
+        if mode == 'raw' or (mode == 'every' and rng.random() < 0.5):
+            report, rtype = 'raw', so.REPORT_RAW
+        if mode == 'every':
+            gap = 1
+        n_out = T // gap
+        obs = rng.random(n_out) * 3
+        obs[rng.random(n_out) < 0.15] = np.nan
         slices, exits = rng.choice(['', '0', '3', '9']), rng.choice(['', '0', '1'])
-        want_final = bool(rng.random() < 0.5)
+        want_final = bool(rng.random() < (0.5 if mode == 'summary' else 0.2))
         setenv('SMART_TIME_SLICES', slices)
         setenv('SMART_EXITS', exits)
         fast = eng.run_ensemble(params, forcing_of(rain, peva), area, dt, W, gap, extra=extra, obs=obs, gw_obs=0.2,
-                                want_final=want_final)
+                                want_final=want_final, report=report)
         kernels = fast._prepared.describe()
-        if any(k in kernels for k in ('smart_fast_intervals', 'smart_fast_steps', 'smart_fast_runs')):  # regular rows
+        regular = [k.split('[')[0] for k in kernels.split(' + ') if not k.startswith(
+            ('smart_fast_stiff', 'smart_fast_guard', 'smart_fast_illcond'))]
+        if regular and mode == 'summary':
             assert ('smart_fast_steps' in kernels) == (varying and not run_len) and \
                 ('smart_fast_runs' in kernels) == bool(run_len) and ('_states' in kernels) == want_final, kernels
-        d1, g1, f1 = so.run_batch(area, dt, T, W, rain, peva, params, extra, so.REPORT_SUMMARY, gap, want_final=True)
-        tag = 'seed %d case %d: dt=%g gap=%d T=%d W=%d n=%d extra=%s slices=%r exits=%r final=%r varying=%r run=%d' % (
-            seed, case, dt, gap, T, W, n, extra is not None, slices, exits, want_final, varying, run_len)
+        elif regular and want_final:                                # the final row with these reports: the general step loop
+            assert regular == ['smart_fast_plain'], kernels
+        elif regular and mode == 'raw':     # (no run engine for raw reports: runs shorter than the interval take the step loop)
+            assert regular == (['smart_fast_steps_raw'] if (varying or run_len) else ['smart_fast_intervals_raw']), kernels
+        elif regular:
+            assert regular == ['smart_fast_steps_every'], kernels
+        d1, g1, f1 = so.run_batch(area, dt, T, W, rain, peva, params, extra, rtype, gap, want_final=True)
+        tag = 'seed %d case %d: %s %s dt=%g gap=%d T=%d W=%d n=%d extra=%s slices=%r exits=%r final=%r varying=%r run=%d' % (
+            seed, case, mode, report, dt, gap, T, W, n, extra is not None, slices, exits, want_final, varying, run_len)
         good = ~(params[:, 9] * 3600.0 < 0.5 * dt)          # dt / RK <= 2: not the literal model's
         if good.any():
             got = fast.discharge.cpu().numpy()[good]
