@@ -59,7 +59,9 @@ __device__ inline double block_sum(double v, double *sh)
 }
 
 // statistics of one observation series (NaN = missing, montecarlo.py:195-196): st[0..4] = n, mean, sum,
-// sum((e-mean)^2), sum(e-mean); dev[r] = e[r] - mean (0 where missing) when dev != null
+// sum((e-mean)^2), sum(e-mean); dev[r] = e[r] - mean when dev != null -- and kMissingObs where e[r] is missing: a NaN of a
+// payload no arithmetic produces, so that a kernel with a report every step can tell a missing observation by ONE 32-bit
+// scalar compare on the deviation it loads anyway (Reporter's other users test e itself and never read dev then)
 __device__ inline void obs_stats(const double *obs, long R, double *st, double *dev, double *sh)
 {
     double cnt = 0.0, s = 0.0;
@@ -76,11 +78,12 @@ __device__ inline void obs_stats(const double *obs, long R, double *st, double *
     double s2 = 0.0, s1 = 0.0;
     for (long r = threadIdx.x; r < R; r += blockDim.x) {
         const double e = obs[r];
-        const double d = !is_nan_bits(e) ? e - mean : 0.0;
+        const bool missing = is_nan_bits(e);
+        const double d = !missing ? e - mean : 0.0;
         s2 += d * d;
         s1 += d;
         if (dev)
-            dev[r] = d;
+            dev[r] = missing ? __builtin_bit_cast(double, kMissingObs) : d;
     }
     s2 = block_sum(s2, sh);
     s1 = block_sum(s1, sh);

@@ -96,13 +96,15 @@ __device__ __forceinline__ bool is_nan_bits(double x)
 }
 constexpr int kWsHead = 8;
 
-// The same test spelt in 32-bit pieces, for values that live in scalar registers (an observation of a report): there is
-// no 64-bit scalar greater-than, and hipcc answers the form above with a vector compare.
-__device__ __forceinline__ bool is_nan_scalar(double x)
+// What smart_obs_prepare writes for the deviation e - mean of a MISSING observation: a NaN whose payload no arithmetic
+// produces (a computed NaN is the canonical 0x7ff8000000000000, or carries the payload of an input NaN -- and an
+// observation that is a NaN is missing whatever its payload).  A report every step tells a missing observation from the
+// upper half of the deviation it has in a scalar register anyway: one s_cmp_eq_u32 (the exact NaN test of the
+// observation itself in 32-bit pieces was eleven scalar instructions a step in hipcc's hands).
+constexpr unsigned long long kMissingObs = 0x7ff8dead00000000ull;
+__device__ __forceinline__ bool is_missing_mark(double w)
 {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-    const unsigned hi = (unsigned)(u >> 32) & 0x7fffffffu, lo = (unsigned)u;
-    return hi > 0x7ff00000u || (hi == 0x7ff00000u && lo != 0u);
+    return (unsigned)(__builtin_bit_cast(unsigned long long, w) >> 32) == (unsigned)(kMissingObs >> 32);
 }
 
 // a quiet NaN that does not trip -fno-honor-nans diagnostics (the fast kernels never do arithmetic on one)
@@ -1202,15 +1204,16 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         // a report every step: e, w = the observation of this report and its deviation from the mean, fetched with the
         // forcing (time_loop_arms_each); the groundwater ratio from the balances, as for the means.  The discharge row
         // of a report is one uniform pointer that moves on by ld, the lane adds its own place.
+        // (store or not, observations or not: decided once per launch, outside the loop -- four instances of it)
         [[maybe_unused]] double *row = a.discharge ? a.discharge + (x.c * a.R + ra) * a.ld : nullptr;
-        [[maybe_unused]] auto report_every = [&](long, const double e, const double w) {
-            const double val = acc;
-            if (row) {
+        [[maybe_unused]] auto report_every = [&](auto store_tag, auto obs_tag, const double e, const double w) {
+            const double val = acc; // (the outflow of the step just taken: SMART_A_ROUTE_LAST)
+            if constexpr (decltype(store_tag)::value) {
                 if (x.live)
                     row[x.n] = val;
                 row += a.ld;
             }
-            if (rep.want_obj && !is_nan_scalar(e)) { // montecarlo.py:195-196
+            if (decltype(obs_tag)::value && !is_missing_mark(w)) { // montecarlo.py:195-196 (e is a number: smart_obs_prepare)
                 const double d = val - e;
                 const double u = val - rep.shift;
                 rep.A += d;
@@ -1244,18 +1247,29 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                     if (stretch == 0) {
                         time_loop_arms<Q, true>(m, f + i0, i1 - i0, acc, [] {});
                     } else {
-                        long first = i0;
-                        if (i0 == 0 && i1 > 0) { // report 0 on its own: it sets the constant the moments are taken about
-                            m.template step_arms<Q, true>(f[0], acc);
-                            rep.shift = acc;
-                            report_every(0, rep.want_obj ? obs_c[0] : 0.0, rep.want_obj ? dev_c[0] : 0.0);
-                            first = 1;
-                        }
-                        if (rep.want_obj)
-                            time_loop_arms_each<Q, true>(m, f + first, obs_c + first, dev_c + first, i1 - first, acc,
-                                                         report_every);
+                        auto run_steps = [&](auto store_tag, auto obs_tag) {
+                            constexpr bool OBS = decltype(obs_tag)::value;
+                            long first = i0;
+                            if (i0 == 0 && i1 > 0) { // report 0 on its own: it sets the constant the moments are taken about
+                                m.template step_arms<Q, true>(f[0], acc);
+                                rep.shift = acc;
+                                report_every(store_tag, obs_tag, OBS ? obs_c[0] : 0.0, OBS ? dev_c[0] : 0.0);
+                                first = 1;
+                            }
+                            time_loop_arms_each<Q, OBS>(m, f + first, OBS ? obs_c + first : nullptr,
+                                                        OBS ? dev_c + first : nullptr, i1 - first, acc,
+                                                        [&](long, const double e, const double w) {
+                                                            report_every(store_tag, obs_tag, e, w);
+                                                        });
+                        };
+                        if (row && rep.want_obj)
+                            run_steps(std::true_type{}, std::true_type{});
+                        else if (row)
+                            run_steps(std::true_type{}, std::false_type{});
+                        else if (rep.want_obj)
+                            run_steps(std::false_type{}, std::true_type{});
                         else
-                            time_loop_arms_each<Q, false>(m, f + first, nullptr, nullptr, i1 - first, acc, report_every);
+                            run_steps(std::false_type{}, std::false_type{});
                     }
                 } else {
                     arm_intervals<Q, REPORT == kReportLast>(m, f + i0 * gap, i1 - i0, gap, i1 * gap == a.T, acc, [&]() {
