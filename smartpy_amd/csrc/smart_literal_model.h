@@ -116,6 +116,9 @@ struct LiteralModelT {
     __device__ __forceinline__ static bool in_range(double x)
     {
         const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+#ifdef SMART_RECIP_RANGE_R03 // (debug builds only: round 3's [2^-800, 2^800))
+        return u == 0 || u - 0x0df0000000000000ull < 0x6400000000000000ull;
+#endif
         return u == 0 || u - 0x26f0000000000000ull < 0x3200000000000000ull;
     }
 
@@ -248,6 +251,7 @@ struct LiteralModelT {
             const double hp = pH * dv<Q>(tot, pZ, y_z); // :363
             of = hp * ex;
             ex -= of;
+            [[maybe_unused]] const double ex_in = ex; // what the filling starts from: NEGATIVE when H tot / Z > 1 (soil above capacity)
 #pragma unroll
             for (int i = 0; i < 6; ++i) { // :367-374
                 const double sp = z - l[i];
@@ -281,9 +285,20 @@ struct LiteralModelT {
             // RN(l f) can equal l, on the other one).  Measured: 4.60 -> 4.38 ms for config 2.
             // (Also measured, and slower, 4.68 ms: running only the wet or only the dry side when every lane of the
             // wave agrees, instead of the per-lane if / else.)
+            // ... and as long as no level is NEGATIVE: for l < 0 the reference's guard is false (l f > l) and nothing leaks,
+            // where the unguarded update would take l f all the same.  Levels are >= 0 when a chunk starts (in_range) and
+            // stay so through the evaporation cascade and the leaks; the one way below zero is a negative excess handed to
+            // the filling -- the overland share H tot / Z of the excess exceeds one when the soil stands above its
+            // capacity (a negative C, which class 3 takes too when dt / RK > 2, or a caller's initial state) -- and the
+            // reference then takes it out of the top layer (:367-370, `lvl + excess`).  Found by the fuzzer in round 4
+            // (seeds 9001, 9040, 9055 of tools/debug/fuzz_wide.py: one row in 190 off by 1e-5, amplified by the river):
+            // a step that meets one keeps its guards, and so does the rest of its chunk (begin_chunk() looks again).
             bool unguarded = false;
-            if constexpr (Q)
-                unguarded = __builtin_amdgcn_ballot_w64(!(s1 <= 0.75 && s1 >= 0.0)) == 0;
+            if constexpr (Q) {
+                unguarded = __builtin_amdgcn_ballot_w64(!(s1 <= 0.75 && s1 >= 0.0 && ex_in >= 0.0)) == 0;
+                if (!unguarded)
+                    quick = false;
+            }
             auto take = [](double &level, double f, double &into) {
                 const double lk = level * f;
                 if (lk < level) {

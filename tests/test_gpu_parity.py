@@ -999,6 +999,18 @@ def test_randomized_wide_parameter_ranges(eng):
     assert seen & {'smart_fast_intervals_states', 'smart_fast_steps_states'}, seen
 
 
+def test_ill_conditioned_rows_with_soil_above_capacity(eng):
+    """Round 4's fuzzer (tools/debug/fuzz_wide.py, seeds 9001 / 9040 / 9055) found rows of class 3 whose fast-mode
+    results left the literal kernel's by 1e-5 (and, amplified by the river, by 1e-3): a negative C had left the second
+    soil layer above its capacity, the overland share H tot / Z of a rainy step's excess exceeded one, the reference
+    took the negative remainder out of the top layer (structure.py:367-370), and the reciprocal path's unguarded leak
+    passes then took from a level below zero where the reference's guard `lk < l` lets nothing leak.  Such a step now
+    keeps its guards.  The three set-ups, replayed (the family's own assertions: class-3 rows bit-identical to the
+    literal kernel)."""
+    for seed, upto in ((9001, 4), (9040, 6), (9055, 1)):
+        run_wide_cases(eng, seed, upto)
+
+
 def run_wide_cases(eng, seed, n_cases):
     """Seeded set-ups with parameters far outside the default sampling ranges -- S up to 0.9 and C below 0 (the GUARD
     kernel: the `leak < level` guards and the sign of the evaporation decay matter), routing constants from minutes

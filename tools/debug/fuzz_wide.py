@@ -1,6 +1,6 @@
 """More seeds of tests/test_gpu_parity.py::run_wide_cases (parameters far outside the default ranges, every arithmetic
-class, final rows) and ::run_interval_cases (interval engine and step loop, slices and exits at random) than the test
-suite runs.  usage: python tools/debug/fuzz_wide.py <first seed> <n seeds> [cases]"""
+class, final rows) and ::run_interval_cases (interval engine and step loop, slices and exits at random; round 4: also
+under report='raw' and under a report every step) than the test suite runs.  usage: python tools/debug/fuzz_wide.py <first seed> <n seeds> [cases]"""
 import os
 import sys
 import traceback
@@ -15,8 +15,10 @@ for seed in range(first, first + count):
     try:
         t.run_wide_cases(engine, seed, cases)
         t.run_batch_cases(engine, seed, cases)
-        t.run_interval_cases(engine, lambda k, v: os.environ.__setitem__(k, str(v)) if v else os.environ.pop(k, None),
-                             seed, cases)
+        setenv = lambda k, v: os.environ.__setitem__(k, str(v)) if v else os.environ.pop(k, None)     # noqa: E731
+        t.run_interval_cases(engine, setenv, seed, cases)
+        t.run_interval_cases(engine, setenv, seed, cases, mode='raw')         # round 4: the raw / every-step kernels
+        t.run_interval_cases(engine, setenv, seed, max(cases // 2, 1), mode='every')
     except (AssertionError, Exception):
         bad += 1
         tb = traceback.format_exc().splitlines()
