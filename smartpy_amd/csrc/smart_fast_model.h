@@ -1088,8 +1088,19 @@ __device__ inline int wave_class(const KArgs &a, long block, long catchment)
         if (!wild) { // (finite numbers in; the quotient can still be a NaN -- area 0, 0 * inf -- and this function is
                      // compiled with and without -fno-honor-nans: the NaN is tested on its bit pattern, like the host does
                      // by `~(s <= 0.5)` on honest IEEE arithmetic)
-            const double s_init = p[4] * (lay / a.area[catchment] * 1e3) / p[5];
+            const double fill = (lay / a.area[catchment] * 1e3) / p[5]; // tot / Z of the first step
+            const double s_init = p[4] * fill;
+            // ... or that the overland share H tot / Z of a rainy step's excess starts beyond one: the reference then hands
+            // a NEGATIVE excess to the filling and takes it out of the top layer (structure.py:363-370), which may go
+            // below zero -- where its guard `leak < level` lets nothing leak and the fast arithmetic's unguarded leaks
+            // would (round 4; the same hole the fuzzer found in the reciprocal path, smart_literal_model.h)
+            const double h_init = p[2] * fill;
+#ifdef SMART_NO_HINIT // measurement builds only: what the fast arithmetic makes of such a start
             wild = is_nan_bits(s_init) || !(s_init <= 0.5);
+            (void)h_init;
+#else
+            wild = is_nan_bits(s_init) || !(s_init <= 0.5) || is_nan_bits(h_init) || !(h_init <= 1.0);
+#endif
         }
     }
     const bool any_stiff = __builtin_amdgcn_ballot_w64(stiff) != 0;

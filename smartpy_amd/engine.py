@@ -95,7 +95,8 @@ def variant_classes(params, delta_sec, initial=None, area=None):
     (S outside [0, 0.5], C < 0 or Z <= 0), 3 ill-conditioned (dt / (RK*3600) > 2, the river: literal arithmetic) --
     and any row with a NaN or an infinite parameter, for the literal arithmetic to decide what comes of it; likewise a
     row whose INITIAL states (initial [C, N, 12] or [N, 12], with the catchments' areas) hold a NaN, an infinity, a
-    negative volume, or soil so far above its capacity that S * sum(levels) / Z starts beyond 0.5 (in any catchment)."""
+    negative volume, or soil so far above its capacity that S * sum(levels) / Z starts beyond 0.5 or H * sum(levels) / Z
+    beyond 1 (in any catchment)."""
     k = params[:, 6:10] * 3600.0
     cls = torch.zeros(params.shape[0], dtype=torch.int64, device=params.device)
     cls[~(k >= delta_sec).all(dim=1)] = 1
@@ -109,8 +110,10 @@ def variant_classes(params, delta_sec, initial=None, area=None):
         lay = torch.zeros_like(st[:, :, 5])         # summed in wave_class()'s order: 0.0 + ly1 + ... + ly6, left to right
         for i in range(5, 11):
             lay = lay + st[:, :, i]
-        s_init = params[:, 4].unsqueeze(0) * (lay / ar * 1e3) / params[:, 5].unsqueeze(0)
-        bad = bad | ~(s_init <= 0.5)
+        fill = (lay / ar * 1e3) / params[:, 5].unsqueeze(0)                    # tot / Z of the first step
+        s_init = params[:, 4].unsqueeze(0) * fill
+        h_init = params[:, 2].unsqueeze(0) * fill     # the overland share of the first rainy step's excess: beyond one it
+        bad = bad | ~(s_init <= 0.5) | ~(h_init <= 1.0)     # leaves the filling a negative excess (wave_class has the story)
         cls[bad.any(dim=0)] = 3
     return cls
 

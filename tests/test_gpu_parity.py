@@ -836,6 +836,13 @@ def test_initial_states_above_capacity(eng, example, monkeypatch):
     level[::3, 2] = 1.6 * z[::3]                 # third layer 60 % above capacity, top layers with room to spare
     level[1::4, 4] = 2.5 * z[1::4]
     level[5::7, :] = 1.2 * z[5::7, None]
+    # soil at five times its capacity (an empty top layer, the others at six times theirs) under a large H: the overland share H tot / Z of the first rainy step's excess is
+    # beyond one, the reference hands the filling a NEGATIVE excess and takes it out of the top layer (round 4: such a
+    # row is for the literal arithmetic, wave_class)
+    level[2::9, :] = 6.0 * z[2::9, None]
+    level[2::9, 0] = 0.0                        # (an empty top layer: the negative excess drives it below zero)
+    params[2::9, 2] = 0.28
+    params[2::9, 9] = np.maximum(params[2::9, 9], 30.0)        # (well-conditioned also on daily steps: compared below)
     init[:, 5:11] = level / 1e3 * area
     for hourly, report, exits, final in ((True, 'summary', '1', False), (True, 'summary', '0', False),
                                          (True, 'summary', '1', True), (True, 'raw', '1', False),

@@ -440,6 +440,12 @@ def test_rows_are_classified_and_grouped_by_arithmetic_variant():
     init[3, 0], init[9, 7], init[17, 11], init[25, 6], init[33, 4] = np.nan, np.inf, -1.0, 1e13, -0.0
     got = engine.variant_classes(torch.from_numpy(q), 3600.0, torch.from_numpy(init), [175.46e6]).numpy()
     assert (got[[3, 9, 17, 25]] == 3).all() and (np.delete(got, [3, 9, 17, 25]) == 0).all()
+    # ... or that the overland share H tot / Z of the first rainy step's excess is beyond one (round 4): with Z = 100 mm and
+    # H = 0.3, soil of more than 333 mm -- here 6 x 1e5 m3 on 1e6 m2 = 600 mm
+    h = lhs_oracle.lhs_params(64, seed=12)
+    h[:, 2], h[:, 5], h[40, 2] = 0.1, 100.0, 0.3
+    got_h = engine.variant_classes(torch.from_numpy(h), 3600.0, torch.from_numpy(np.full((64, 12), 1e5)), [1e6]).numpy()
+    assert got_h[40] == 3 and (np.delete(got_h, 40) == 0).all()
     two = np.stack([np.full((64, 12), 1e5), init])            # [C = 2, N, 12]: wild in any catchment counts
     assert np.array_equal(engine.variant_classes(torch.from_numpy(q), 3600.0, torch.from_numpy(two), [1e8, 175.46e6]).numpy(), got)
 
