@@ -917,8 +917,12 @@ def test_parameter_and_forcing_corner_cases(eng, example):
             assert excess(out.final_vars.cpu().numpy()[good], f1[good], 1e-8) <= 1.0, tag
 
 
-def run_batch_cases(eng, seed, n_cases):
-    """Seeded set-ups of the batched entry's own dimensions: 1..4 catchments (areas, forcings, observations and
+def run_batch_cases(eng, seed, n_cases, stress_initial=False):
+    """stress_initial (round 4): every run starts from given states, the soil anywhere between empty and eight times its
+    capacity layer by layer, H up to 0.9 -- starts whose overland share H tot / Z is beyond one, whose top layer the
+    first rainy step drives below zero, whose lower layers spill for several steps: the rules that send a row to the
+    literal arithmetic (wave_class) and the over-capacity handling of the fast kernels, against the oracle.
+    Seeded set-ups of the batched entry's own dimensions: 1..4 catchments (areas, forcings, observations and
     groundwater constraints of their own), parameters shared or per catchment, runs started from given states (some
     with layers above capacity) or from the educated guess, summary / raw, with or without the final row, forced time
     slices -- every (catchment, row) against the oracle started from the same states."""
@@ -946,8 +950,10 @@ def run_batch_cases(eng, seed, n_cases):
         per_catchment = bool(rng.random() < 0.5)
         params = np.stack([lhs_oracle.lhs_params(max(n, 2), seed=int(rng.integers(1 << 30)))[:n]
                            for _ in range(C if per_catchment else 1)])
-        use_initial = bool(rng.random() < 0.6)
+        use_initial = bool(rng.random() < 0.6) or stress_initial
         initial = None
+        if stress_initial:
+            params[:, :, 2] = rng.uniform(0.0, 0.9, params.shape[:2])
         if use_initial:
             initial = np.zeros((C, n, 12))
             for c in range(C):
@@ -956,6 +962,9 @@ def run_batch_cases(eng, seed, n_cases):
                 initial[c, :, 11] = rng.uniform(0.0, 5e4, n)
                 lev = (p[:, 5:6] / 6.0) * rng.uniform(0.0, 1.0, (n, 6))
                 lev[rng.random((n, 6)) < 0.05] *= 2.5               # a few layers above capacity
+                if stress_initial:
+                    kind = rng.random((n, 6))
+                    lev = np.where(kind < 0.2, 0.0, np.where(kind < 0.7, lev, (p[:, 5:6] / 6.0) * rng.uniform(1.0, 8.0, (n, 6))))
                 initial[c, :, 5:11] = lev / 1e3 * areas[c]
         extra = None if use_initial else {'aar': float(rng.uniform(600, 2500)), 'r-o_ratio': float(rng.uniform(0.2, 0.7)),
                                           'r-o_split': tuple(rng.dirichlet(np.ones(5)))}
@@ -998,6 +1007,7 @@ def run_batch_cases(eng, seed, n_cases):
 
 def test_randomized_batches_catchments_and_initial_states(eng):
     run_batch_cases(eng, 4242, 20)
+    run_batch_cases(eng, 4243, 12, stress_initial=True)
 
 
 def test_randomized_wide_parameter_ranges(eng):

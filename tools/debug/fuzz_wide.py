@@ -15,6 +15,7 @@ for seed in range(first, first + count):
     try:
         t.run_wide_cases(engine, seed, cases)
         t.run_batch_cases(engine, seed, cases)
+        t.run_batch_cases(engine, seed + 1000003, cases, stress_initial=True)   # round 4: starts far above capacity, large H
         setenv = lambda k, v: os.environ.__setitem__(k, str(v)) if v else os.environ.pop(k, None)     # noqa: E731
         t.run_interval_cases(engine, setenv, seed, cases)
         t.run_interval_cases(engine, setenv, seed, cases, mode='raw')         # round 4: the raw / every-step kernels
