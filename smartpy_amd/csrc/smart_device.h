@@ -82,6 +82,29 @@ __device__ __forceinline__ void raise_status(const KArgs &a, int bit)
 #ifndef SMART_CHUNK_THREADED
 #define SMART_CHUNK_THREADED 1 // the four steps of a chunk as one threaded asm (0: four single-step asms; A/B builds)
 #endif
+// code placement of a hot loop: onto a 64-byte line, `phase` dwords (s_nop) behind it
+#define SMART_NOPS_0 ""
+#define SMART_NOPS_1 "s_nop 0\n\t"
+#define SMART_NOPS_2 SMART_NOPS_1 SMART_NOPS_1
+#define SMART_NOPS_4 SMART_NOPS_2 SMART_NOPS_2
+#define SMART_NOPS_8 SMART_NOPS_4 SMART_NOPS_4
+#define SMART_NOPS_3 SMART_NOPS_2 SMART_NOPS_1
+#define SMART_NOPS_5 SMART_NOPS_4 SMART_NOPS_1
+#define SMART_NOPS_6 SMART_NOPS_4 SMART_NOPS_2
+#define SMART_NOPS_7 SMART_NOPS_4 SMART_NOPS_3
+#define SMART_NOPS_9 SMART_NOPS_8 SMART_NOPS_1
+#define SMART_NOPS_10 SMART_NOPS_8 SMART_NOPS_2
+#define SMART_NOPS_11 SMART_NOPS_8 SMART_NOPS_3
+#define SMART_NOPS_12 SMART_NOPS_8 SMART_NOPS_4
+#define SMART_NOPS_13 SMART_NOPS_8 SMART_NOPS_5
+#define SMART_NOPS_14 SMART_NOPS_8 SMART_NOPS_6
+#define SMART_NOPS_15 SMART_NOPS_8 SMART_NOPS_7
+#define SMART_NOPS_(n) SMART_NOPS_##n
+#define SMART_NOPS(n) SMART_NOPS_(n)
+#define SMART_PLACE_LOOP(phase) asm volatile(".p2align 6\n\t" SMART_NOPS(phase))
+#ifndef SMART_STEPS_PHASE
+#define SMART_STEPS_PHASE 1
+#endif
 #ifndef SMART_STEP_ARMS
 #define SMART_STEP_ARMS 1 // the step loop of sub-daily forcing as three asm arms (0: the compiled step_lazy of round 2)
 #endif
@@ -434,6 +457,12 @@ __device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restric
         // Two chunks per turn, the two buffers swapping roles: no copy from one to the other (the clamped loop above
         // pays 8 scalar moves a chunk for that).  Every half turn: wait for the chunk at hand, request the next one
         // into the other buffer, run the chunk.  11 scalar instructions per 8 steps.
+        // WHERE the loop lies counts (round 4): the two chunks are 6 KB of code with two dozen branch targets, and their
+        // phase against the 64-byte instruction-cache lines moved the launch by 5 % when an edit in a cold function
+        // shifted it (13.85 -> 14.5 ms at 1e5 samples; same instructions, same registers).  The loop is therefore put on
+        // a line boundary of its own, SMART_STEPS_PHASE dwords behind it: the phase measured best (tools/gpu_round.sh
+        // phases), and no longer a matter of what is compiled in front of it.  Executed once per stretch.
+        SMART_PLACE_LOOP(SMART_STEPS_PHASE);
         for (long iv = 0; iv < n_stream; ++iv) {
 #pragma nounroll
             for (int c = 0; c < cpi; c += 2) {

@@ -39,6 +39,13 @@
 #pragma once
 
 // ---- pieces ---------------------------------------------------------------------------------------------------
+// onto an 8-byte boundary (at most one s_nop): fp64 instructions are 64-bit encodings, and a run of them that starts at
+// 4 mod 8 straddles a 32-byte fetch line every fourth instruction (SMART_A_WET_INTERVAL has the story and the numbers)
+#define SMART_A_ALIGN8 ".p2align 3\n\t"
+// ... onto 4 mod 8: what the RAIN arm wants for its first instruction -- a 4-byte v_mov_b64, behind which its first ten
+// instructions then lie on the boundary; the three 4-byte v_mov_b64 and four scalar instructions that follow leave the
+// seven of the filling's head at 4 mod 8, and the fill exit's s_cbranch puts the arm's other 59 back on the boundary
+#define SMART_A_ALIGN8_ODD ".p2align 3\n\ts_nop 0\n\t"
 #define SMART_A_ROUTE                                                                                                  \
     "v_mul_f64 %[t0], %[cg], %[yg]\n\t"                                                                                \
     "v_fma_f64 %[t0], %[cf], %[yf], %[t0]\n\t"                                                                         \
@@ -232,17 +239,18 @@
 // dispatch, calm arm (entered by falling through), rain arm, dry arm (left by falling through): one taken branch per
 // calm or dry step, two per rain step
 #define SMART_A_STEP(route, deep, calm_split, zeros, drain, rain_split, dry_split)                                     \
-    "s_cmp_eq_u64 %[rn0], 0\n\t"                                                                                       \
+    SMART_A_ALIGN8 "s_cmp_eq_u64 %[rn0], 0\n\t"                                                                                       \
     "s_cbranch_scc0 5f\n\t"                                                                                            \
     "s_cmp_eq_u64 %[pe0], 0\n\t"                                                                                       \
     "s_cbranch_scc0 7f\n\t" SMART_A_CALM(route, SMART_A_CASC_CALM("9"), deep, calm_split) "s_branch 9f\n\t"            \
-        SMART_A_CASC_CALM_OOL("9") "5:\n\t" SMART_A_RAIN(route, "rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros,           \
-                                                         SMART_A_FILL_QUICK(drain), deep, rain_split)                  \
-            "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL("9")                                                               \
+        SMART_A_CASC_CALM_OOL("9") SMART_A_ALIGN8_ODD "5:\n\t" SMART_A_RAIN(route, "rn0", "pe0", SMART_A_CASC_RAIN("9"), \
+                                                                            zeros, SMART_A_FILL_QUICK(drain), deep,    \
+                                                                            rain_split)                                \
+            "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL("9") SMART_A_ALIGN8                                                \
             "7:\n\t" SMART_A_DRY(route, "pe0", dry_split) "9:\n\t"
 // the rain arm alone (waves that may not take the shortcuts)
 #define SMART_A_STEP_RAIN(route, deep, zeros, drain, rain_split)                                                       \
-    SMART_A_RAIN(route, "rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros, SMART_A_FILL(drain), deep, rain_split)            \
+    SMART_A_ALIGN8 SMART_A_RAIN(route, "rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros, SMART_A_FILL(drain), deep, rain_split)            \
     "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL("9") "9:\n\t"
 
 // ---- a chunk of four steps, threaded ---------------------------------------------------------------------------
@@ -270,23 +278,29 @@
 #define SMART_A_DRY_J(route, j, split) "11" j ":\n\t" SMART_A_DRY(route, "pe" j, split)
 #define SMART_A_RAIN_J(route, j, zeros, fill, deep, split)                                                             \
     "12" j ":\n\t" SMART_A_RAIN(route, "rn" j, "pe" j, SMART_A_CASC_RAIN(j), zeros, fill, deep, split)
+// (alignment: the chunk -- its calm lane -- and the dry lane start on an 8-byte boundary, the rain lane at 4 mod 8; the two
+// lie behind unconditional branches, their padding is never executed.  With the dispatches 16 bytes each, a dry step's
+// nine instructions, a calm step's 45 behind its hook, and a rain step's first 10 and last 59 then lie on the boundary:
+// the layout the fast builds of round 3 happened to have; a build whose chunk started at 4 mod 8 was 4.5 % slower)
 #define SMART_A_CHUNK(route, deep, calm_split, zeros, drain, rain_split, dry_split)                                    \
-    SMART_A_NEXT_FROM_CALM("0") SMART_A_CALM_J(route, "0", deep, calm_split) SMART_A_NEXT_FROM_CALM("1")               \
+    SMART_A_ALIGN8 SMART_A_NEXT_FROM_CALM("0") SMART_A_CALM_J(route, "0", deep, calm_split) SMART_A_NEXT_FROM_CALM("1")               \
     SMART_A_CALM_J(route, "1", deep, calm_split) SMART_A_NEXT_FROM_CALM("2")                                           \
     SMART_A_CALM_J(route, "2", deep, calm_split) SMART_A_NEXT_FROM_CALM("3")                                           \
     SMART_A_CALM_J(route, "3", deep, calm_split) "s_branch 130f\n\t"                                                   \
     SMART_A_CASC_CALM_OOL("0") SMART_A_CASC_CALM_OOL("1") SMART_A_CASC_CALM_OOL("2") SMART_A_CASC_CALM_OOL("3")        \
+    SMART_A_ALIGN8_ODD                                                                                                 \
     SMART_A_RAIN_J(route, "0", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) SMART_A_NEXT_FROM_RAIN("1")         \
     SMART_A_RAIN_J(route, "1", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) SMART_A_NEXT_FROM_RAIN("2")         \
     SMART_A_RAIN_J(route, "2", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) SMART_A_NEXT_FROM_RAIN("3")         \
     SMART_A_RAIN_J(route, "3", zeros, SMART_A_FILL_QUICK(drain), deep, rain_split) "s_branch 130f\n\t"                 \
     SMART_A_CASC_RAIN_OOL("0") SMART_A_CASC_RAIN_OOL("1") SMART_A_CASC_RAIN_OOL("2") SMART_A_CASC_RAIN_OOL("3")        \
+    SMART_A_ALIGN8                                                                                                     \
     SMART_A_DRY_J(route, "0", dry_split) SMART_A_NEXT_FROM_DRY("1") SMART_A_DRY_J(route, "1", dry_split)               \
     SMART_A_NEXT_FROM_DRY("2") SMART_A_DRY_J(route, "2", dry_split) SMART_A_NEXT_FROM_DRY("3")                         \
     SMART_A_DRY_J(route, "3", dry_split) "130:\n\t"
 // not QUICK: the rain arm four times
 #define SMART_A_CHUNK_RAIN(route, deep, zeros, drain, rain_split)                                                      \
-    SMART_A_RAIN_J(route, "0", zeros, SMART_A_FILL(drain), deep, rain_split)                                           \
+    SMART_A_ALIGN8 SMART_A_RAIN_J(route, "0", zeros, SMART_A_FILL(drain), deep, rain_split)                                           \
     SMART_A_RAIN_J(route, "1", zeros, SMART_A_FILL(drain), deep, rain_split)                                           \
     SMART_A_RAIN_J(route, "2", zeros, SMART_A_FILL(drain), deep, rain_split)                                           \
     SMART_A_RAIN_J(route, "3", zeros, SMART_A_FILL(drain), deep, rain_split)                                           \
@@ -341,14 +355,25 @@
     "s_cmp_lg_u32 %[cnt], 0\n\t"                                                                                       \
     "s_cbranch_scc1 5b\n\t"
 #elif SMART_WET_MODES == 1
-// cnt counts up from -n: s_add_u32 carries out (SCC) when it reaches zero
+// cnt counts up from -n: s_add_u32 carries out (SCC) when it reaches zero.
+// WHERE the 8-byte instructions lie counts (round 4).  Every fp64 instruction is a 64-bit encoding; one that starts at
+// 4 mod 8 straddles a 32-byte fetch line every fourth time, and a wavefront that has its SIMD to itself waits for the
+// second half (a same-instructions, same-registers shift of the step loop by 4 bytes moved its launch by 4.5 %:
+// profiles/r04_placement_phases.txt).  Scalar instructions are 4 bytes, so the parity of a run of vector instructions is
+// the parity of the number of scalar ones in front of it -- here, by hand:
+//   the asm starts on an 8-byte boundary (SMART_A_ALIGN8: at most one s_nop, once per interval);
+//   the three entry instructions put label 5 at 4 mod 8: the 10 instructions of the absorbed step's head straddle, the
+//   s_cbranch_vccnz behind them puts its other 47 on the boundary, counter and back-edge (8 bytes) keep it there;
+//   an s_nop behind `s_branch 9f` (never executed) puts label 6 -- the loop of full steps, 73 instructions and 8 bytes
+//   of scalar ones a turn -- on the boundary as a whole.  Round 3's build had it at 4 mod 8 in the run loop.
 #define SMART_A_WET_INTERVAL                                                                                           \
-    "s_sub_u32 %[cnt], 0, %[n]\n\t"                                                                                    \
+    SMART_A_ALIGN8 "s_sub_u32 %[cnt], 0, %[n]\n\t"                                                                     \
     "s_cmp_eq_u32 %[ok], 0\n\t"                                                                                        \
     "s_cbranch_scc1 6f\n\t"                                                                                            \
     "5:\n\t" SMART_A_WET_ABSORBED("7") "s_add_u32 %[cnt], %[cnt], 1\n\t"                                               \
     "s_cbranch_scc0 5b\n\t"                                                                                            \
     "s_branch 9f\n\t"                                                                                                  \
+    "s_nop 0\n\t"                                                                                                      \
     "6:\n\t" SMART_A_WET_FULL("7") "s_add_u32 %[cnt], %[cnt], 1\n\t"                                                   \
     "s_cbranch_scc0 6b\n\t"                                                                                            \
     "9:\n\t"
@@ -376,7 +401,7 @@
     "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                                                         \
     "v_add_f64 %[xgs], %[xgs], %[xg]\n\t"
 #define SMART_A_CALM_INTERVAL                                                                                          \
-    "s_add_i32 %[cnt], %[n], 1\n\t"                                                                                    \
+    SMART_A_ALIGN8 "s_add_i32 %[cnt], %[n], 1\n\t"                                                                                    \
     "s_lshr_b32 %[cnt], %[cnt], 1\n\t"                                                                                 \
     "s_bitcmp1_b32 %[n], 0\n\t"                                                                                        \
     "s_cbranch_scc1 6f\n\t"                                                                                            \

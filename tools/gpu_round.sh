@@ -8,6 +8,7 @@
 #   ab LIB...          interleaved A/B of library variants (tools/ab_variants.sh)
 #   bits LIB           tools/debug/steps_bits.py: every output of the merged kernels, variant LIB against the default build
 #   profile TAG [bench args]   tools/profile.sh (kernel trace + PMC passes of the bench command)
+#   phases SCRIPT ...  code-placement scan: the leg SCRIPT (e.g. tools/debug/flat_only.py 100000 6) under every phase variant
 #   soak               tools/gpu_soak.sh: thousands of sliced launches against the unsliced one, competitors beside them
 #   slices             4 / 8 / 16 time slices on configs 4 and 5 (where the hand-over is the only HBM traffic)
 #   final              what the driver runs at round end (tools/gpu_final_check.sh)
@@ -38,6 +39,11 @@ bits)   # bits LIB: outputs of the merged kernels from library variant LIB and f
     ;;
 profile)
     bash tools/profile.sh "$@"
+    ;;
+phases) # phases SCRIPT [args]: every tools/variants/libsmart_amd_p<N>.so (build_variants.py pN=-DSMART_..._PHASE=N) on one leg
+    for rep in 1 2; do for f in $(ls tools/variants/libsmart_amd_p*.so | sort -V); do
+        echo -n "$(basename $f .so | sed s/libsmart_amd_//): "; SMART_AMD_LIB=$PWD/$f python "$@" 2>/dev/null | grep " ms" | sort -n | head -3 | tr '\n' ' '; echo
+    done; done 2>&1 | tee gpurun_out/phases_round.log
     ;;
 soak)
     bash tools/gpu_soak.sh 2>&1 | tee gpurun_out/soak_round.log | tail -40

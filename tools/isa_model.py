@@ -343,6 +343,8 @@ def intervals_model(out):
     # 5: the loop of steps whose excess the top layer takes in every lane (ends with its counter, its back-edge and the
     # jump over the other loop); 6: head of a full step, 7: where the first step that leaves something over joins
     # it; 9: end
+    if seg['5'][-1] == 's_nop':         # (the padding behind `s_branch 9f` that puts the loop of full steps on an 8-byte
+        seg['5'].pop()                  # boundary: never executed)
     assert seg['5'][-3:] == ['s_add_u32', 's_cbranch_scc0', 's_branch'] and seg['7'][-2:] == ['s_add_u32', 's_cbranch_scc0']
     absorbed = hist(seg['5'][:-3])
     step = hist(seg['6'] + seg['7'][:-2])
