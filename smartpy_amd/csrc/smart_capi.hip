@@ -199,6 +199,21 @@ __global__ void smart_forcing_scan(KArgs a, const double2 *__restrict__ forcing)
         wild = wild || (__builtin_bit_cast(unsigned long long, v.x) & top) == top ||
                (__builtin_bit_cast(unsigned long long, v.y) & top) == top;
     }
+    // the kinds of the steps, chunk by chunk, as the code words of the pair blocks (smart_device.h: pair_code); the
+    // entries beyond the last whole chunk are requested (two chunks ahead) but never acted on: block 0's
+    if (a.codes) {
+        uint2 *codes = const_cast<uint2 *>(a.codes) + (long)blockIdx.y * code_chunks(a.T);
+        for (long ch = (long)blockIdx.x * blockDim.x + threadIdx.x; ch < code_chunks(a.T);
+             ch += (long)gridDim.x * blockDim.x) {
+            uint2 w = make_uint2(0u, 0u);
+            if ((ch + 1) * kChunk <= a.T) {
+                const double2 *__restrict__ v = f + ch * kChunk;
+                w.x = pair_code(ch, 0, step_kind(v[0]), step_kind(v[1]));
+                w.y = pair_code(ch, 1, step_kind(v[2]), step_kind(v[3]));
+            }
+            codes[ch] = w;
+        }
+    }
     if (bad)
         __hip_atomic_fetch_or(a.fflags + blockIdx.y, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // a NaN or an infinity in the forcing: the fast kernels are not made for it (what the reference's branches do with
@@ -318,7 +333,8 @@ static size_t lds_for_residency(DeviceCtx *d, FastKernel k, int per_cu)
     return d->lds_size[k][per_cu];
 }
 
-// ---- workspace layout: header | [C][8 + R] observation statistics (if objfn) | time-slice hand-over | slice flags
+// ---- workspace layout: header | [C][8 + R] observation statistics (if objfn) | time-slice hand-over | slice flags |
+// code words of the pair blocks (fast summary / raw runs over whole intervals of a multiple of eight steps)
 static size_t header_bytes(int64_t n_catchments)
 {
     return ((size_t)(kHdrInts + n_catchments) * sizeof(int) + 255) / 256 * 256;
@@ -336,6 +352,38 @@ static size_t slice_bytes(int64_t n_samples, int64_t n_catchments)
 {
     const size_t blocks = (size_t)((n_samples + kWave - 1) / kWave) * (size_t)n_catchments;
     return blocks * kSegFields * kWave * sizeof(double) + (blocks + 1) / 2 * 2 * sizeof(int);
+}
+
+static int merged_report(const SmartEnsemble *e);
+static int plan_time_slices(const SmartEnsemble *e, int n_simd, int *per_simd, double *load);
+
+// SMART_PAIR_BLOCKS=0 in the environment: the threaded chunks instead of the pair blocks (A/B runs of the tools)
+static bool pair_blocks_wanted()
+{
+    const char *env = getenv("SMART_PAIR_BLOCKS");
+    return !(env && atoi(env) == 0);
+}
+
+// what a sliced launch of this call needs for its hand-over (0: the call is not sliced, or no device to ask)
+static size_t slices_need(const SmartEnsemble *e)
+{
+    if (e->math_mode != SMART_MATH_FAST)
+        return 0;
+    int per_simd = 0, n_dev = 0;
+    double load = 0.0;
+    DeviceCtx *d = hipGetDeviceCount(&n_dev) == hipSuccess && n_dev > 0 ? device_ctx() : nullptr;
+    return d && plan_time_slices(e, d->n_simd, &per_simd, &load) > 1 ? slice_bytes(e->n_samples, e->n_catchments) : 0;
+}
+
+// the code words of the pair blocks: for the calls whose regular rows may take the streaming step loop
+static size_t codes_bytes(const SmartEnsemble *e)
+{
+    if (e->math_mode != SMART_MATH_FAST || e->report_gap % (2 * kChunk) != 0)
+        return 0;
+    const int merged = merged_report(e);
+    if (merged != kReportMean && merged != kReportLast)
+        return 0;
+    return ((size_t)e->n_catchments * (size_t)code_chunks(e->n_steps) * sizeof(uint2) + 255) / 256 * 256;
 }
 
 static int check(const SmartEnsemble *e)
@@ -453,6 +501,7 @@ struct Workspace {
     double *stats = nullptr;
     char *slices = nullptr;
     size_t slice_room = 0;
+    uint2 *codes = nullptr; // at the end of the workspace, when it has the room smart_workspace_bytes() asks for
 };
 
 static Workspace carve(const SmartEnsemble *e)
@@ -468,6 +517,13 @@ static Workspace carve(const SmartEnsemble *e)
         w.stats = sb ? (double *)(base + hb) : nullptr;
         w.slices = base + hb + sb;
         w.slice_room = (size_t)e->workspace_bytes - hb - sb;
+        const size_t cb = codes_bytes(e);
+        if (cb && w.slice_room >= slices_need(e) + cb) {
+            w.slice_room -= cb;
+            w.codes = (uint2 *)(base + ((size_t)e->workspace_bytes - cb) / 256 * 256);
+            if ((char *)w.codes < w.slices + slices_need(e)) // (an odd workspace size: the rounding ate the room)
+                w.codes = nullptr, w.slice_room += cb;
+        }
     }
     return w;
 }
@@ -529,6 +585,7 @@ static void reset_workspace(const Workspace &w, long n_catch, int *flags, long n
 static void scan_forcing(const SmartEnsemble *e, KArgs a, const Workspace &w, hipStream_t s)
 {
     a.fflags = w.fflags;
+    a.codes = w.codes;
     hipLaunchKernelGGL(smart_forcing_scan, dim3(64, (unsigned)e->n_catchments), dim3(256), 0, s, a,
                        reinterpret_cast<const double2 *>(e->forcing));
 }
@@ -679,8 +736,10 @@ static int run(const SmartEnsemble *e, bool literal_recip = false)
         // every fast launch looks at its forcing (the merged kernels for what the flags say about runs of equal
         // values; all of them for the NaN that belongs to the literal kernel: status word)
         scan_forcing(e, a, w, s);
-        if (x.report >= 0 && (x.class_mask & SMART_PLAN_CLASS_REGULAR))
+        if (x.report >= 0 && (x.class_mask & SMART_PLAN_CLASS_REGULAR)) {
             a.fflags = a_sliced.fflags = w.fflags;
+            a.codes = a_sliced.codes = pair_blocks_wanted() ? w.codes : nullptr;
+        }
     }
 
     // ---- launch: one kernel on the caller's stream; several fork onto the device's auxiliary streams and join
@@ -758,15 +817,9 @@ static int64_t workspace_bytes(const SmartEnsemble *e)
 {
     if (!e || e->n_catchments < 1 || e->n_samples < 1 || e->n_steps < 0 || e->report_gap < 1)
         return 0;
-    size_t need = header_bytes(e->n_catchments) + obs_stats_bytes(e);
-    if (e->math_mode == SMART_MATH_FAST) {
-        int per_simd = 0;
-        double load = 0.0;
-        int n_dev = 0;
-        DeviceCtx *d = hipGetDeviceCount(&n_dev) == hipSuccess && n_dev > 0 ? device_ctx() : nullptr;
-        if (d && plan_time_slices(e, d->n_simd, &per_simd, &load) > 1)
-            need += slice_bytes(e->n_samples, e->n_catchments);
-    }
+    size_t need = header_bytes(e->n_catchments) + obs_stats_bytes(e) + slices_need(e);
+    if (codes_bytes(e))
+        need = (need + 255) / 256 * 256 + codes_bytes(e);
     return (int64_t)need;
 }
 

@@ -46,6 +46,8 @@ struct KArgs {
     // workspace header (null without a workspace: no status word, no time slices, every wavefront scans the forcing)
     int *hdr = nullptr;       // [kHdrInts]: status word, ticket counters of the sliced kernels
     int *fflags = nullptr;    // [C]: forcing flags of catchment c (forcing_flags_of_step below), from smart_forcing_scan
+    const uint2 *codes = nullptr; // [C][code_chunks(T)]: per chunk of four steps the two code words of the pair blocks
+                                  // (SMART_A_PAIRS_INTERVAL), from smart_forcing_scan; null: the threaded chunks
     // run lengths a catchment's forcing is tested for: the divisors of the report gap, largest first (div[0] = gap)
     int n_div = 0;
     int div[kMaxDiv] = {};
@@ -104,6 +106,9 @@ __device__ __forceinline__ void raise_status(const KArgs &a, int bit)
 #define SMART_PLACE_LOOP(phase) asm volatile(".p2align 6\n\t" SMART_NOPS(phase))
 #ifndef SMART_STEPS_PHASE
 #define SMART_STEPS_PHASE 1
+#endif
+#ifndef SMART_PAIR_BLOCKS
+#define SMART_PAIR_BLOCKS 1 // the streaming step loop as pair blocks behind computed jumps (0: the threaded chunks; A/B builds)
 #endif
 #ifndef SMART_STEP_ARMS
 #define SMART_STEP_ARMS 1 // the step loop of sub-daily forcing as three asm arms (0: the compiled step_lazy of round 2)
@@ -429,14 +434,27 @@ __device__ __forceinline__ void time_loop_arms_each(Model &m, const double2 *__r
 // intervals but -- when it ends where the catchment's forcing ends -- the last one, which the clamped loop above
 // takes (a prefetch must never read past the array).
 template <bool QUICK, bool LAST = false, class Model, class IntervalEnd>
-__device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restrict__ f, long n_iv, long gap,
-                                              bool ends_at_array_end, double &acc, IntervalEnd &&interval_end)
+__device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restrict__ f, const double2 *f_asm,
+                                              const uint2 *codes, long n_iv, long gap, bool ends_at_array_end,
+                                              double &acc, IntervalEnd &&interval_end)
 {
     const int cpi = (int)(gap / kChunk);
     long n_stream = 0;
 #if SMART_CHUNK_THREADED
     if (gap % (2 * kChunk) == 0 && n_iv > 0) // (an even number of chunks per interval: the two buffers swap roles)
         n_stream = ends_at_array_end ? n_iv - 1 : n_iv;
+#endif
+#if SMART_PAIR_BLOCKS
+    // the pair blocks (SMART_A_PAIRS_INTERVAL): the kinds of the steps come from smart_forcing_scan's code words
+    // (f itself stays what it was: a __restrict__ pointer that has been through a phi loses hipcc the scalar loads)
+    long n_paired = 0;
+    if constexpr (QUICK && !Model::kSplit) if (codes && n_stream > 0) {
+        m.template stream_pairs<LAST>(f, f_asm, codes, n_stream, cpi / 2, acc, interval_end);
+        n_paired = n_stream;
+        n_stream = 0;
+    }
+#else
+    const long n_paired = 0;
 #endif
     if (n_stream > 0) {
         double2 cur[kChunk], nxt[kChunk];
@@ -482,7 +500,7 @@ __device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restric
             interval_end();
         }
     }
-    for (long iv = n_stream; iv < n_iv; ++iv) {
+    for (long iv = n_stream + n_paired; iv < n_iv; ++iv) {
         time_loop_arms<QUICK, LAST>(m, f + iv * gap, gap, acc, [] {});
         interval_end();
     }
@@ -753,6 +771,22 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
     if constexpr (Model::kBalanceSums)
         m.balance_sums(q_out_total, num, den);
     write_results(a, x, m, rep, summary ? num / den : num_raw / den_raw, capture ? flows : nullptr);
+}
+
+// ---- code words of the pair blocks (smart_fast_arms.h: SMART_A_PAIRS_INTERVAL) ----------------------------------------
+// Per chunk of four steps two words, one per pair of steps: the byte offset of the pair's block from block 0.  Blocks
+// lie kPairStride bytes apart, ordered by (chunk parity, pair, kind of the first step, kind of the second); kinds as the
+// arms tell them apart on the bits of the forcing: rain != +0 -> rain step (2), else PE != +0 -> dry (1), else calm (0).
+// A block that starts with a rain step is entered 4 bytes in.  Meaningful for sane forcing only (the QUICK waves).
+constexpr long kPairStride = 2048;
+__host__ __device__ constexpr long code_chunks(long T) { return T / kChunk + 4; } // (+ the requests beyond a stretch)
+__device__ __forceinline__ unsigned step_kind(const double2 v)
+{
+    return __builtin_bit_cast(unsigned long long, v.x) != 0 ? 2u : (__builtin_bit_cast(unsigned long long, v.y) != 0 ? 1u : 0u);
+}
+__device__ __forceinline__ unsigned pair_code(long chunk, int pair, unsigned k0, unsigned k1)
+{
+    return (unsigned)((((chunk & 1) * 2 + pair) * 9 + k0 * 3 + k1) * kPairStride + (k0 == 2 ? 4 : 0));
 }
 
 // ---- piecewise-constant forcing ------------------------------------------------------------------------------
@@ -1075,6 +1109,11 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
     // that fetch them with scalar loads take them as __restrict__ parameters)
     [[maybe_unused]] const double *__restrict__ obs_c = obs_all ? obs_all + x.c * a.R : nullptr;
     [[maybe_unused]] const double *__restrict__ dev_c = ws_all ? ws_all + x.c * (kWsHead + a.R) + kWsHead : nullptr;
+    [[maybe_unused]] const uint2 *codes_c = a.codes ? a.codes + x.c * code_chunks(a.T) : nullptr;
+    // the same forcing for the asm that loads it itself (stream_pairs), NOT derived from the __restrict__ argument: a
+    // pointer handed to an asm has escaped, and with `f` escaped every asm of the launch might have written the forcing
+    // for all hipcc knows -- its own loads of it would no longer be scalar loads
+    [[maybe_unused]] const double2 *f_asm = reinterpret_cast<const double2 *>(a.forcing) + x.c * a.T;
     double num = 0.0, den = 0.0, q_out_total = 0.0;
     [[maybe_unused]] double num_raw = 0.0, den_raw = 0.0; // raw reports: the two sums over the reported steps (structure.py:194-195)
     double *hand = a.seg_state + (slot * kSegFields) * kWave + x.lane;
@@ -1214,7 +1253,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         long k = 0, r = ra;
         (void)k;
         double acc = 0.0;
-        auto report = [&]() { // end of report interval r (wave-uniform)
+        auto report = [&]() __attribute__((always_inline)) { // end of report interval r (wave-uniform)
             if constexpr (REPORT == kReportMean) {
                 rep.emit(a, x, r, acc * inv_gap);
                 ++r;
@@ -1260,7 +1299,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         // intervals (three inlined copies of the loop -- warm-up, run, run with a test per step -- cost 30 VGPRs at
         // their joins).
         const bool quick = m.zero_ok && !(fflags & kForcingInsane);
-        auto walk = [&](auto quick_tag) {
+        auto walk = [&](auto quick_tag) __attribute__((always_inline)) {
             constexpr bool Q = decltype(quick_tag)::value;
 #pragma nounroll
             for (int stretch = 0; stretch < 2; ++stretch) { // the warm-up intervals, then the report intervals
@@ -1301,7 +1340,10 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                             run_steps(std::false_type{}, std::false_type{});
                     }
                 } else {
-                    arm_intervals<Q, REPORT == kReportLast>(m, f + i0 * gap, i1 - i0, gap, i1 * gap == a.T, acc, [&]() {
+                    arm_intervals<Q, REPORT == kReportLast>(m, f + i0 * gap, f_asm + i0 * gap,
+                                                            codes_c ? codes_c + i0 * gap / kChunk : nullptr,
+                                                            i1 - i0, gap, i1 * gap == a.T, acc,
+                                                            [&]() __attribute__((always_inline)) {
                         if (stretch == 1)
                             report();
                     });

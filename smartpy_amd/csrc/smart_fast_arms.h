@@ -174,29 +174,30 @@
     "v_fma_f64 %[dp], %[l5], %[" SMART_S1 "], %[dp]\n\t"
 #define SMART_A_TOT_XG SMART_A_LSUM("tot") "v_add_f64 %[xg], %[ai], -%[tot]\n\t"
 
-// ---- the three arms.  route: SMART_A_ROUTE (interval sums) or SMART_A_ROUTE_LAST; pe / rn: names of the SGPR operands
-// that hold the step's forcing; casc: the hook of the deferred cascade (SMART_A_CASC_*); deep / split / zeros / drain:
+// ---- the three arms.  route: SMART_A_ROUTE (interval sums) or SMART_A_ROUTE_LAST; pe / rn: the TEXT of the SGPR pairs
+// that hold the step's forcing (an asm operand, "%[pe0]", or a physical register, "s[38:39]"); casc: the hook of the deferred cascade (SMART_A_CASC_*); deep / split / zeros / drain:
 // what the SPLIT models add ("" otherwise)
 #define SMART_A_DRY(route, pe, split)                                                                                  \
-    route "v_add_f64 %[pend], %[pend], %[" pe "]\n\t"                                                          \
+    route "v_add_f64 %[pend], %[pend], " pe "\n\t"                                                          \
                   "v_fma_f64 %[ys], %[ys], %[ds], 0\n\t"                                                               \
                   "v_fma_f64 %[yf], %[yf], %[df], 0\n\t"                                                               \
                   "v_fma_f64 %[yg], %[yg], %[dg], 0\n\t" split
 #define SMART_A_DRY_SPLIT                                                                                              \
     "v_fma_f64 %[yd], %[yd], %[ds], 0\n\t"                                                                             \
     "v_fma_f64 %[ydg], %[ydg], %[dg], 0\n\t"
-#define SMART_A_CALM(route, casc, deep, split)                                                                         \
-    "v_cmp_lt_f64 vcc, 0, %[pend]\n\t" route casc SMART_A_LEAKS(deep) "v_add_f64 %[xf], %[tot], -%[ai]\n\t"            \
+#define SMART_A_CALM_BODY(route, casc, deep, split)                                                                    \
+    route casc SMART_A_LEAKS(deep) "v_add_f64 %[xf], %[tot], -%[ai]\n\t"                                               \
         SMART_A_TOT_XG "v_fma_f64 %[ys], %[ys], %[ds], 0\n\t"                                                          \
                        "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                                      \
                        "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                                      \
                        "v_add_f64 %[xgs], %[xgs], %[xg]\n\t" split
+#define SMART_A_CALM(route, casc, deep, split) "v_cmp_lt_f64 vcc, 0, %[pend]\n\t" SMART_A_CALM_BODY(route, casc, deep, split)
 #define SMART_A_CALM_SPLIT                                                                                             \
     "v_fma_f64 %[yd], %[yd], %[ds], 0\n\t"                                                                             \
     "v_fma_f64 %[ydg], %[ydg], %[dg], %[dp]\n\t"
 #define SMART_A_RAIN(route, rn, pe, casc, zeros, fill, deep, split)                                                    \
-    "v_mov_b64 %[t1], %[" pe "]\n\t"                                                                                   \
-    "v_fma_f64 %[ex], %[" rn "], %[pt], -%[t1]\n\t"                                                                    \
+    "v_mov_b64 %[t1], " pe "\n\t"                                                                                      \
+    "v_fma_f64 %[ex], " rn ", %[pt], -%[t1]\n\t"                                                                       \
     "v_cmp_le_f64 %[wm], 0, %[ex]\n\t"                                                                                 \
     "v_cmp_lt_f64 %[tmp], 0, %[pend]\n\t" route "v_max_f64 %[t1], -%[ex], 0\n\t"                                       \
                                                         "v_add_f64 %[pend], %[pend], %[t1]\n\t"                        \
@@ -243,14 +244,14 @@
     "s_cbranch_scc0 5f\n\t"                                                                                            \
     "s_cmp_eq_u64 %[pe0], 0\n\t"                                                                                       \
     "s_cbranch_scc0 7f\n\t" SMART_A_CALM(route, SMART_A_CASC_CALM("9"), deep, calm_split) "s_branch 9f\n\t"            \
-        SMART_A_CASC_CALM_OOL("9") SMART_A_ALIGN8_ODD "5:\n\t" SMART_A_RAIN(route, "rn0", "pe0", SMART_A_CASC_RAIN("9"), \
+        SMART_A_CASC_CALM_OOL("9") SMART_A_ALIGN8_ODD "5:\n\t" SMART_A_RAIN(route, "%[rn0]", "%[pe0]", SMART_A_CASC_RAIN("9"), \
                                                                             zeros, SMART_A_FILL_QUICK(drain), deep,    \
                                                                             rain_split)                                \
             "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL("9") SMART_A_ALIGN8                                                \
-            "7:\n\t" SMART_A_DRY(route, "pe0", dry_split) "9:\n\t"
+            "7:\n\t" SMART_A_DRY(route, "%[pe0]", dry_split) "9:\n\t"
 // the rain arm alone (waves that may not take the shortcuts)
 #define SMART_A_STEP_RAIN(route, deep, zeros, drain, rain_split)                                                       \
-    SMART_A_ALIGN8 SMART_A_RAIN(route, "rn0", "pe0", SMART_A_CASC_RAIN("9"), zeros, SMART_A_FILL(drain), deep, rain_split)            \
+    SMART_A_ALIGN8 SMART_A_RAIN(route, "%[rn0]", "%[pe0]", SMART_A_CASC_RAIN("9"), zeros, SMART_A_FILL(drain), deep, rain_split)            \
     "s_branch 9f\n\t" SMART_A_CASC_RAIN_OOL("9") "9:\n\t"
 
 // ---- a chunk of four steps, threaded ---------------------------------------------------------------------------
@@ -275,9 +276,9 @@
     "s_cmp_eq_u64 %[pe" j "], 0\n\t"                                                                                   \
     "s_cbranch_scc1 10" j "b\n\t"
 #define SMART_A_CALM_J(route, j, deep, split) "10" j ":\n\t" SMART_A_CALM(route, SMART_A_CASC_CALM(j), deep, split)
-#define SMART_A_DRY_J(route, j, split) "11" j ":\n\t" SMART_A_DRY(route, "pe" j, split)
+#define SMART_A_DRY_J(route, j, split) "11" j ":\n\t" SMART_A_DRY(route, "%[pe" j "]", split)
 #define SMART_A_RAIN_J(route, j, zeros, fill, deep, split)                                                             \
-    "12" j ":\n\t" SMART_A_RAIN(route, "rn" j, "pe" j, SMART_A_CASC_RAIN(j), zeros, fill, deep, split)
+    "12" j ":\n\t" SMART_A_RAIN(route, "%[rn" j "]", "%[pe" j "]", SMART_A_CASC_RAIN(j), zeros, fill, deep, split)
 // (alignment: the chunk -- its calm lane -- and the dry lane start on an 8-byte boundary, the rain lane at 4 mod 8; the two
 // lie behind unconditional branches, their padding is never executed.  With the dispatches 16 bytes each, a dry step's
 // nine instructions, a calm step's 45 behind its hook, and a rain step's first 10 and last 59 then lie on the boundary:
@@ -306,6 +307,96 @@
     SMART_A_RAIN_J(route, "3", zeros, SMART_A_FILL(drain), deep, rain_split)                                           \
     "s_branch 130f\n\t" SMART_A_CASC_RAIN_OOL("0") SMART_A_CASC_RAIN_OOL("1") SMART_A_CASC_RAIN_OOL("2")               \
     SMART_A_CASC_RAIN_OOL("3") "130:\n\t"
+
+// ---- a report interval of the step loop as PAIRS of steps, each pair one straight-line block (round 4) ----------------
+// What a lone wavefront pays for, measured (tools/microbench/lone.hip, profiles/r04_microbench_lone.txt): a vector or a
+// scalar instruction 4 cycles, a conditional branch that is NOT taken 16, a taken one 24 to 40 -- the threaded chunk's
+// dispatch (two compares, two branches not taken) costs a step as much as a dry step's nine vector instructions.
+// Here the kind of every step is worked out ONCE per launch, by smart_forcing_scan: for each chunk of four steps two
+// code words, one per pair of steps -- the byte offset of the block that holds the two arms of that pair, one behind the
+// other with no dispatch in between.  Blocks lie 4 KB apart (36 of them: 2 buffers x 2 pairs x 9 patterns; never-executed
+// padding in between), a pair ends with  base + code word -> s_setpc_b64:  one computed jump per two steps instead of
+// four branch instructions.  The forcing is loaded by the asm itself, two chunks ahead, into two fixed register
+// buffers (the arms name their forcing by physical register; a buffer per chunk parity); the loop control (wait,
+// request, count) sits in the tail of the second pair's blocks.  What a block knows about its first step lets the
+// second drop work: a calm step behind a calm one has no demand pending (no compare, no hook), behind a dry one it
+// has (the cascade in line, unconditionally).  The arithmetic is that of the threaded chunk, operation for operation.
+//   F0 = s[36:51], F1 = s[52:67]   forcing of the chunk at hand / the next one (rain, PE of step 0, 1, 2, 3)
+//   s68, s69 / s70, s71            their code words (first pair, second pair)
+//   s72 counter (pairs of chunks, counts up to zero), s73 / s74 byte offsets of the last request into forcing / codes,
+//   s[76:77] jump target, s[78:79] address of block 0
+// F0 and s68, s69 are in/out operands pinned to those registers: they carry the first chunk of the NEXT interval out
+// (requested two chunks ahead like any other, arrived by then) and back in.
+#define SMART_P_STRIDE 2048
+#define SMART_P_ARM_C_N(route, id, deep, split) SMART_A_CALM(route, SMART_A_CASC_CALM(id), deep, split)
+#define SMART_P_ARM_C_Q(route, deep, split) SMART_A_CALM_BODY(route, "", deep, split)
+// (the cascade holds five 4-byte instructions: one s_nop puts what follows back on the 8-byte boundary)
+#define SMART_P_ARM_C_F(route, deep, split) SMART_A_CALM_BODY(route, SMART_A_CASCADE "s_nop 0\n\t", deep, split)
+#define SMART_P_ARM_R(route, rn, pe, id, zeros, drain, deep, split)                                                    \
+    SMART_A_RAIN(route, rn, pe, SMART_A_CASC_RAIN(id), zeros, SMART_A_FILL_QUICK(drain), deep, split)
+// tails: the jump to the second pair's block; the end of a chunk in buffer 0 / 1
+#define SMART_P_JUMP(code) "s_add_u32 s76, s78, " code "\n\ts_addc_u32 s77, s79, 0\n\ts_setpc_b64 s[76:77]\n\t"
+#define SMART_P_REQUEST(f, c)                                                                                          \
+    "s_add_u32 s73, s73, 64\n\t"                                                                                       \
+    "s_load_dwordx16 " f ", %[fp], s73\n\t"                                                                            \
+    "s_add_u32 s74, s74, 8\n\t"                                                                                        \
+    "s_load_dwordx2 " c ", %[cp], s74\n\t"
+#define SMART_P_TAIL_A0 SMART_P_JUMP("s69")
+#define SMART_P_TAIL_A1 SMART_P_JUMP("s71")
+#define SMART_P_TAIL_B0 "s_waitcnt lgkmcnt(0)\n\t" SMART_P_REQUEST("s[36:51]", "s[68:69]") SMART_P_JUMP("s70")
+#define SMART_P_TAIL_B1                                                                                                \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+    "s_add_u32 s72, s72, 1\n\t"                                                                                        \
+    "s_cbranch_scc1 99f\n\t" SMART_P_REQUEST("s[52:67]", "s[70:71]") SMART_P_JUMP("s68")
+// the nine blocks of one position: rx, px / ry, py = the forcing registers of its two steps.  A block whose first step is
+// a rain step is entered 4 bytes behind its boundary (the code word says so): the rain arm wants to start at 4 mod 8
+// (SMART_A_ALIGN8_ODD) -- and ends there (eleven 4-byte instructions on its way): behind a calm or a dry step it gets there
+// by an s_nop, behind a rain step it is there, and a calm or a dry step behind a rain step gets an s_nop back
+#define SMART_P_BLOCK(body) ".p2align 11\n\t" body
+#define SMART_P_OOL(x) SMART_A_ALIGN8 x
+#define SMART_P_NINE(route, rx, px, ry, py, tail, deep, calm_split, zeros, drain, rain_split, dry_split)               \
+    SMART_P_BLOCK(SMART_P_ARM_C_N(route, "0", deep, calm_split) SMART_P_ARM_C_Q(route, deep, calm_split)               \
+                      tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                                                    \
+    SMART_P_BLOCK(SMART_P_ARM_C_N(route, "0", deep, calm_split) SMART_A_DRY(route, py, dry_split)                      \
+                      tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                                                    \
+    SMART_P_BLOCK(SMART_P_ARM_C_N(route, "0", deep, calm_split) "s_nop 0\n\t" SMART_P_ARM_R(                           \
+        route, ry, py, "1", zeros, drain, deep, rain_split)                                                            \
+                      tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")) SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))            \
+    SMART_P_BLOCK(SMART_A_DRY(route, px, dry_split) SMART_P_ARM_C_F(route, deep, calm_split) tail)                     \
+    SMART_P_BLOCK(SMART_A_DRY(route, px, dry_split) SMART_A_DRY(route, py, dry_split) tail)                            \
+    SMART_P_BLOCK(SMART_A_DRY(route, px, dry_split) "s_nop 0\n\t" SMART_P_ARM_R(                                       \
+        route, ry, py, "1", zeros, drain, deep, rain_split) tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))              \
+    SMART_P_BLOCK("s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", zeros, drain, deep, rain_split) "s_nop 0\n\t"        \
+                      SMART_P_ARM_C_N(route, "1", deep, calm_split)                                                    \
+                          tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0")) SMART_P_OOL(SMART_A_CASC_CALM_OOL("1")))        \
+    SMART_P_BLOCK("s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", zeros, drain, deep, rain_split) "s_nop 0\n\t"        \
+                      SMART_A_DRY(route, py, dry_split) tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0")))                  \
+    SMART_P_BLOCK("s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", zeros, drain, deep, rain_split)                      \
+                      SMART_P_ARM_R(route, ry, py, "1", zeros, drain, deep, rain_split)                                \
+                          tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0")) SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))
+// the interval: %[half] = chunks / 2 (>= 1), %[fp] / %[cp] = the interval's first chunk in the forcing / the code words
+#define SMART_A_PAIRS_INTERVAL(route, deep, calm_split, zeros, drain, rain_split, dry_split)                           \
+    "s_getpc_b64 s[78:79]\n\t"                                                                                         \
+    "90:\n\t"                                                                                                          \
+    "s_add_u32 s78, s78, 91f-90b\n\t"                                                                                  \
+    "s_addc_u32 s79, s79, 0\n\t"                                                                                       \
+    "s_mov_b32 s73, 64\n\t"                                                                                            \
+    "s_load_dwordx16 s[52:67], %[fp], s73\n\t"                                                                         \
+    "s_mov_b32 s74, 8\n\t"                                                                                             \
+    "s_load_dwordx2 s[70:71], %[cp], s74\n\t"                                                                          \
+    "s_sub_u32 s72, 0, %[half]\n\t" SMART_P_JUMP("s68") ".p2align 11\n\t"                                              \
+    "91:\n\t" SMART_P_NINE(route, "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", SMART_P_TAIL_A0, deep, calm_split,   \
+                           zeros, drain, rain_split, dry_split)                                                        \
+        SMART_P_NINE(route, "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]", SMART_P_TAIL_B0, deep, calm_split, zeros,  \
+                     drain, rain_split, dry_split)                                                                     \
+            SMART_P_NINE(route, "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]", SMART_P_TAIL_A1, deep, calm_split,     \
+                         zeros, drain, rain_split, dry_split)                                                          \
+                SMART_P_NINE(route, "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]", SMART_P_TAIL_B1, deep,             \
+                             calm_split, zeros, drain, rain_split, dry_split) ".p2align 3\n\t"                         \
+                                                                              "99:\n\t"
+#define SMART_P_CLOBBERS                                                                                               \
+    "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",    \
+        "s70", "s71", "s72", "s73", "s74", "s76", "s77", "s78", "s79", "vcc", "scc"
 
 // ---- the wet interval of the interval engine (FastModel::wet_interval, merged regular variant, no exits) ----------
 // `n` wet steps with one excess: 73 vector instructions a step (5 routing, 22 filling, 34 for the three leak passes

@@ -933,6 +933,51 @@ struct FastModel {
         }
     }
 
+    // `n_iv` report intervals of `half` pairs of chunks each, walked pair of steps by pair of steps through the blocks of
+    // SMART_A_PAIRS_INTERVAL; interval_end() after each.  f / codes: the first interval's first chunk and its code words
+    // (smart_forcing_scan); f_asm = f through a pointer that hipcc does not take for f (smart_device.h).  QUICK waves only.  The asm requests two chunks beyond the interval it walks: the caller keeps
+    // the last interval of the forcing array away from it (arm_intervals).
+    template <bool LAST, class IntervalEnd>
+    __device__ __forceinline__ void stream_pairs(const double2 *__restrict__ f, const double2 *f_asm, const uint2 *codes,
+                                                 long n_iv, int half, double &acc, IntervalEnd &&interval_end)
+    {
+        // (the models with the final state vector keep the threaded chunks: two rain arms with their two extra
+        // reservoirs do not fit a 2 KB block, and 4 KB blocks put the asm's end beyond the reach of a branch)
+        static_assert(!SPLIT, "stream_pairs: the SPLIT models take the threaded chunks");
+        SMART_ARM_LOCALS;
+        // the chunk at hand, pinned to F0 / s68, s69 (the blocks name these registers)
+        register double r0 asm("s36") = f[0].x;
+        register double p0 asm("s38") = f[0].y;
+        register double r1 asm("s40") = f[1].x;
+        register double p1 asm("s42") = f[1].y;
+        register double r2 asm("s44") = f[2].x;
+        register double p2 asm("s46") = f[2].y;
+        register double r3 asm("s48") = f[3].x;
+        register double p3 asm("s50") = f[3].y;
+        register unsigned ca asm("s68") = codes[0].x;
+        register unsigned cb asm("s69") = codes[0].y;
+        const long f_step = 8L * half, c_step = 2L * half; // chunks per interval = 2 half; 4 steps, one code pair a chunk
+#define SMART_PAIRS_IO                                                                                                 \
+    "+s"(r0), "+s"(p0), "+s"(r1), "+s"(p1), "+s"(r2), "+s"(p2), "+s"(r3), "+s"(p3), "+s"(ca), "+s"(cb)
+#define SMART_PAIRS_IN [fp] "s"(f_asm), [cp] "s"(codes), [half] "s"(half)
+        for (long iv = 0; iv < n_iv; ++iv) {
+            if constexpr (LAST) {
+                asm volatile(SMART_A_PAIRS_INTERVAL(SMART_A_ROUTE_LAST, "", "", "", "", "", "")
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_LAST, SMART_PAIRS_IO
+                             : SMART_ARM_CONSTS, SMART_PAIRS_IN
+                             : SMART_P_CLOBBERS);
+            } else {
+                asm volatile(SMART_A_PAIRS_INTERVAL(SMART_A_ROUTE, "", "", "", "", "", "")
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_PAIRS_IO
+                             : SMART_ARM_CONSTS, SMART_PAIRS_IN
+                             : SMART_P_CLOBBERS);
+            }
+            f_asm += f_step;
+            codes += c_step;
+            interval_end();
+        }
+    }
+
     // ---- a whole report interval without rain excess (run_ensemble_merged) ------------------------------------
     // While no lane gets inflow the routing half of the model is linear with constant coefficients:
     //   U_j' = dec_j U_j  (j = quick, inter, groundwater),   U_riv' = (1 - a_r) U_riv + a_r (U_q + U_i + U_g)
