@@ -110,6 +110,9 @@ __device__ __forceinline__ void raise_status(const KArgs &a, int bit)
 #ifndef SMART_PAIR_BLOCKS
 #define SMART_PAIR_BLOCKS 1 // the streaming step loop as pair blocks behind computed jumps (0: the threaded chunks; A/B builds)
 #endif
+#ifndef SMART_P_STRIDE
+#define SMART_P_STRIDE 2112 // bytes from one pair block to the next (smart_fast_arms.h; a multiple of 64, not a power of two)
+#endif
 #ifndef SMART_STEP_ARMS
 #define SMART_STEP_ARMS 1 // the step loop of sub-daily forcing as three asm arms (0: the compiled step_lazy of round 2)
 #endif
@@ -435,8 +438,8 @@ __device__ __forceinline__ void time_loop_arms_each(Model &m, const double2 *__r
 // takes (a prefetch must never read past the array).
 template <bool QUICK, bool LAST = false, class Model, class IntervalEnd>
 __device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restrict__ f, const double2 *f_asm,
-                                              const uint2 *codes, long n_iv, long gap, bool ends_at_array_end,
-                                              double &acc, IntervalEnd &&interval_end)
+                                              const uint2 *codes, const double *obs_p, const double *dev_p, long n_iv,
+                                              long gap, bool ends_at_array_end, double &acc, IntervalEnd &&interval_end)
 {
     const int cpi = (int)(gap / kChunk);
     long n_stream = 0;
@@ -449,7 +452,7 @@ __device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restric
     // (f itself stays what it was: a __restrict__ pointer that has been through a phi loses hipcc the scalar loads)
     long n_paired = 0;
     if constexpr (QUICK && !Model::kSplit) if (codes && n_stream > 0) {
-        m.template stream_pairs<LAST>(f, f_asm, codes, n_stream, cpi / 2, acc, interval_end);
+        m.template stream_pairs<LAST>(f, f_asm, codes, obs_p, dev_p, n_stream, cpi / 2, acc, interval_end);
         n_paired = n_stream;
         n_stream = 0;
     }
@@ -778,7 +781,7 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
 // lie kPairStride bytes apart, ordered by (chunk parity, pair, kind of the first step, kind of the second); kinds as the
 // arms tell them apart on the bits of the forcing: rain != +0 -> rain step (2), else PE != +0 -> dry (1), else calm (0).
 // A block that starts with a rain step is entered 4 bytes in.  Meaningful for sane forcing only (the QUICK waves).
-constexpr long kPairStride = 2048;
+constexpr long kPairStride = SMART_P_STRIDE; // (smart_fast_arms.h)
 __host__ __device__ constexpr long code_chunks(long T) { return T / kChunk + 4; } // (+ the requests beyond a stretch)
 __device__ __forceinline__ unsigned step_kind(const double2 v)
 {
@@ -1253,9 +1256,17 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         long k = 0, r = ra;
         (void)k;
         double acc = 0.0;
-        auto report = [&]() __attribute__((always_inline)) { // end of report interval r (wave-uniform)
+        // end of report interval r (wave-uniform); ew: the observation of this report and its deviation from the mean
+        // when the caller has fetched them ahead (stream_pairs), nothing otherwise
+        auto report = [&](auto... ew) __attribute__((always_inline)) {
+            auto emit = [&](const double val) __attribute__((always_inline)) {
+                if constexpr (sizeof...(ew) == 2)
+                    rep.emit_prefetched(a, x, r, val, ew...);
+                else
+                    rep.emit(a, x, r, val);
+            };
             if constexpr (REPORT == kReportMean) {
-                rep.emit(a, x, r, acc * inv_gap);
+                emit(acc * inv_gap);
                 ++r;
                 k = 0;
                 q_out_total += acc;
@@ -1263,7 +1274,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                 if (Model::kSplit && r == a.R - 1)
                     park_state();
             } else if constexpr (REPORT == kReportLast) { // acc, q_gw, q_in: what SMART_A_ROUTE_LAST left of the last step
-                rep.emit(a, x, r, acc);
+                emit(acc);
                 ++r;
                 num_raw += m.q_gw;
                 den_raw += m.q_in;
@@ -1340,13 +1351,16 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                             run_steps(std::false_type{}, std::false_type{});
                     }
                 } else {
-                    arm_intervals<Q, REPORT == kReportLast>(m, f + i0 * gap, f_asm + i0 * gap,
-                                                            codes_c ? codes_c + i0 * gap / kChunk : nullptr,
-                                                            i1 - i0, gap, i1 * gap == a.T, acc,
-                                                            [&]() __attribute__((always_inline)) {
-                        if (stretch == 1)
-                            report();
-                    });
+                    // (the report entries through a.obs / a.ws, not through the __restrict__ arguments: see f_asm)
+                    const bool fetch = stretch == 1 && rep.want_obj;
+                    arm_intervals<Q, REPORT == kReportLast>(
+                        m, f + i0 * gap, f_asm + i0 * gap, codes_c ? codes_c + i0 * gap / kChunk : nullptr,
+                        fetch ? a.obs + x.c * a.R + i0 : nullptr,
+                        fetch ? a.ws + x.c * (kWsHead + a.R) + kWsHead + i0 : nullptr, i1 - i0, gap, i1 * gap == a.T, acc,
+                        [&](auto... ew) __attribute__((always_inline)) {
+                            if (stretch == 1)
+                                report(ew...);
+                        });
                 }
             }
         };

@@ -327,7 +327,9 @@
 //   s[76:77] jump target, s[78:79] address of block 0
 // F0 and s68, s69 are in/out operands pinned to those registers: they carry the first chunk of the NEXT interval out
 // (requested two chunks ahead like any other, arrived by then) and back in.
-#define SMART_P_STRIDE 2048
+#ifndef SMART_P_STRIDE
+#error "SMART_P_STRIDE comes from smart_device.h"
+#endif
 #define SMART_P_ARM_C_N(route, id, deep, split) SMART_A_CALM(route, SMART_A_CASC_CALM(id), deep, split)
 #define SMART_P_ARM_C_Q(route, deep, split) SMART_A_CALM_BODY(route, "", deep, split)
 // (the cascade holds five 4-byte instructions: one s_nop puts what follows back on the 8-byte boundary)
@@ -352,29 +354,39 @@
 // a rain step is entered 4 bytes behind its boundary (the code word says so): the rain arm wants to start at 4 mod 8
 // (SMART_A_ALIGN8_ODD) -- and ends there (eleven 4-byte instructions on its way): behind a calm or a dry step it gets there
 // by an s_nop, behind a rain step it is there, and a calm or a dry step behind a rain step gets an s_nop back
-#define SMART_P_BLOCK(body) ".p2align 11\n\t" body
+// block number n (position x 9 + pattern) starts SMART_P_STRIDE x n bytes behind block 0 (label 91): .org puts it there and
+// refuses a predecessor that has outgrown its room.  The stride is NOT a power of two: with blocks 2 KB apart the k-th
+// line of every block falls into one of 8 sets of the instruction cache
+#define SMART_P_STR_(x) #x
+#define SMART_P_STR(x) SMART_P_STR_(x)
+#define SMART_P_BLOCK(pos, k, body) ".org 91b+(" pos "*9+" k ")*" SMART_P_STR(SMART_P_STRIDE) "\n\t" body
 #define SMART_P_OOL(x) SMART_A_ALIGN8 x
-#define SMART_P_NINE(route, rx, px, ry, py, tail, deep, calm_split, zeros, drain, rain_split, dry_split)               \
-    SMART_P_BLOCK(SMART_P_ARM_C_N(route, "0", deep, calm_split) SMART_P_ARM_C_Q(route, deep, calm_split)               \
-                      tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                                                    \
-    SMART_P_BLOCK(SMART_P_ARM_C_N(route, "0", deep, calm_split) SMART_A_DRY(route, py, dry_split)                      \
-                      tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                                                    \
-    SMART_P_BLOCK(SMART_P_ARM_C_N(route, "0", deep, calm_split) "s_nop 0\n\t" SMART_P_ARM_R(                           \
+#define SMART_P_NINE(pos, route, rx, px, ry, py, tail, deep, calm_split, zeros, drain, rain_split, dry_split)          \
+    SMART_P_BLOCK(pos, "0", SMART_P_ARM_C_N(route, "0", deep, calm_split) SMART_P_ARM_C_Q(route, deep, calm_split)     \
+                                tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                                          \
+    SMART_P_BLOCK(pos, "1", SMART_P_ARM_C_N(route, "0", deep, calm_split) SMART_A_DRY(route, py, dry_split)            \
+                                tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                                          \
+    SMART_P_BLOCK(pos, "2", SMART_P_ARM_C_N(route, "0", deep, calm_split) "s_nop 0\n\t" SMART_P_ARM_R(                 \
         route, ry, py, "1", zeros, drain, deep, rain_split)                                                            \
-                      tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")) SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))            \
-    SMART_P_BLOCK(SMART_A_DRY(route, px, dry_split) SMART_P_ARM_C_F(route, deep, calm_split) tail)                     \
-    SMART_P_BLOCK(SMART_A_DRY(route, px, dry_split) SMART_A_DRY(route, py, dry_split) tail)                            \
-    SMART_P_BLOCK(SMART_A_DRY(route, px, dry_split) "s_nop 0\n\t" SMART_P_ARM_R(                                       \
+                                tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")) SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))  \
+    SMART_P_BLOCK(pos, "3", SMART_A_DRY(route, px, dry_split) SMART_P_ARM_C_F(route, deep, calm_split) tail)           \
+    SMART_P_BLOCK(pos, "4", SMART_A_DRY(route, px, dry_split) SMART_A_DRY(route, py, dry_split) tail)                  \
+    SMART_P_BLOCK(pos, "5", SMART_A_DRY(route, px, dry_split) "s_nop 0\n\t" SMART_P_ARM_R(                             \
         route, ry, py, "1", zeros, drain, deep, rain_split) tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))              \
-    SMART_P_BLOCK("s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", zeros, drain, deep, rain_split) "s_nop 0\n\t"        \
-                      SMART_P_ARM_C_N(route, "1", deep, calm_split)                                                    \
-                          tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0")) SMART_P_OOL(SMART_A_CASC_CALM_OOL("1")))        \
-    SMART_P_BLOCK("s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", zeros, drain, deep, rain_split) "s_nop 0\n\t"        \
-                      SMART_A_DRY(route, py, dry_split) tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0")))                  \
-    SMART_P_BLOCK("s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", zeros, drain, deep, rain_split)                      \
-                      SMART_P_ARM_R(route, ry, py, "1", zeros, drain, deep, rain_split)                                \
-                          tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0")) SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))
-// the interval: %[half] = chunks / 2 (>= 1), %[fp] / %[cp] = the interval's first chunk in the forcing / the code words
+    SMART_P_BLOCK(pos, "6", "s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", zeros, drain, deep, rain_split)            \
+                                "s_nop 0\n\t" SMART_P_ARM_C_N(route, "1", deep, calm_split)                            \
+                                    tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0"))                                       \
+                                        SMART_P_OOL(SMART_A_CASC_CALM_OOL("1")))                                       \
+    SMART_P_BLOCK(pos, "7", "s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", zeros, drain, deep, rain_split)            \
+                                "s_nop 0\n\t" SMART_A_DRY(route, py, dry_split)                                        \
+                                    tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0")))                                      \
+    SMART_P_BLOCK(pos, "8", "s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", zeros, drain, deep, rain_split)            \
+                                SMART_P_ARM_R(route, ry, py, "1", zeros, drain, deep, rain_split)                      \
+                                    tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0"))                                       \
+                                        SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))
+// the interval: %[half] = chunks / 2 (>= 1), %[fp] / %[cp] = the interval's first chunk in the forcing / the code words;
+// %[op] / %[wp] -> %[eo] / %[wo]: the observation of the interval's report and its deviation, requested here and in by
+// the first wait of the loop control
 #define SMART_A_PAIRS_INTERVAL(route, deep, calm_split, zeros, drain, rain_split, dry_split)                           \
     "s_getpc_b64 s[78:79]\n\t"                                                                                         \
     "90:\n\t"                                                                                                          \
@@ -384,14 +396,16 @@
     "s_load_dwordx16 s[52:67], %[fp], s73\n\t"                                                                         \
     "s_mov_b32 s74, 8\n\t"                                                                                             \
     "s_load_dwordx2 s[70:71], %[cp], s74\n\t"                                                                          \
-    "s_sub_u32 s72, 0, %[half]\n\t" SMART_P_JUMP("s68") ".p2align 11\n\t"                                              \
-    "91:\n\t" SMART_P_NINE(route, "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", SMART_P_TAIL_A0, deep, calm_split,   \
+    "s_load_dwordx2 %[eo], %[op], 0x0\n\t"                                                                             \
+    "s_load_dwordx2 %[wo], %[wp], 0x0\n\t"                                                                             \
+    "s_sub_u32 s72, 0, %[half]\n\t" SMART_P_JUMP("s68") ".p2align 6\n\t"                                              \
+    "91:\n\t" SMART_P_NINE("0", route, "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", SMART_P_TAIL_A0, deep, calm_split,   \
                            zeros, drain, rain_split, dry_split)                                                        \
-        SMART_P_NINE(route, "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]", SMART_P_TAIL_B0, deep, calm_split, zeros,  \
+        SMART_P_NINE("1", route, "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]", SMART_P_TAIL_B0, deep, calm_split, zeros,  \
                      drain, rain_split, dry_split)                                                                     \
-            SMART_P_NINE(route, "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]", SMART_P_TAIL_A1, deep, calm_split,     \
+            SMART_P_NINE("2", route, "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]", SMART_P_TAIL_A1, deep, calm_split,     \
                          zeros, drain, rain_split, dry_split)                                                          \
-                SMART_P_NINE(route, "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]", SMART_P_TAIL_B1, deep,             \
+                SMART_P_NINE("3", route, "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]", SMART_P_TAIL_B1, deep,             \
                              calm_split, zeros, drain, rain_split, dry_split) ".p2align 3\n\t"                         \
                                                                               "99:\n\t"
 #define SMART_P_CLOBBERS                                                                                               \

@@ -939,27 +939,45 @@ struct FastModel {
     // the last interval of the forcing array away from it (arm_intervals).
     template <bool LAST, class IntervalEnd>
     __device__ __forceinline__ void stream_pairs(const double2 *__restrict__ f, const double2 *f_asm, const uint2 *codes,
-                                                 long n_iv, int half, double &acc, IntervalEnd &&interval_end)
+                                                 const double *obs_p, const double *dev_p, long n_iv, int half,
+                                                 double &acc, IntervalEnd &&interval_end)
     {
         // (the models with the final state vector keep the threaded chunks: two rain arms with their two extra
         // reservoirs do not fit a 2 KB block, and 4 KB blocks put the asm's end beyond the reach of a branch)
         static_assert(!SPLIT, "stream_pairs: the SPLIT models take the threaded chunks");
         SMART_ARM_LOCALS;
-        // the chunk at hand, pinned to F0 / s68, s69 (the blocks name these registers)
-        register double r0 asm("s36") = f[0].x;
-        register double p0 asm("s38") = f[0].y;
-        register double r1 asm("s40") = f[1].x;
-        register double p1 asm("s42") = f[1].y;
-        register double r2 asm("s44") = f[2].x;
-        register double p2 asm("s46") = f[2].y;
-        register double r3 asm("s48") = f[3].x;
-        register double p3 asm("s50") = f[3].y;
-        register unsigned ca asm("s68") = codes[0].x;
-        register unsigned cb asm("s69") = codes[0].y;
+        // the chunk at hand: in and out of the asm in F0 / s68, s69 (the blocks name these registers)
+        // (constraints that name the register pair: a `register double x asm("s36")` variable pins 32 bits of it)
+        double r0 = f[0].x, p0 = f[0].y, r1 = f[1].x, p1 = f[1].y, r2 = f[2].x, p2 = f[2].y, r3 = f[3].x, p3 = f[3].y;
+        // (the code words through the constant address space: a scalar load, values that stay in SGPRs)
+        typedef const unsigned __attribute__((address_space(4))) *const_u32;
+        unsigned ca = ((const_u32)(unsigned long long)codes)[0], cb = ((const_u32)(unsigned long long)codes)[1];
+        // the observation of each interval's report and its deviation from the mean (obs_p / dev_p: the first interval's,
+        // null: no objective functions, or the warm-up) are requested by the asm as it enters the interval and handed to
+        // interval_end(e, w): left to the report itself they are two memory latencies, one behind the other, that a lone
+        // wavefront sits out at the end of every interval
+        const long o_step = obs_p ? 1 : 0;
+        if (!obs_p) {
+            obs_p = reinterpret_cast<const double *>(f_asm); // (somewhere to load from; interval_end ignores the values)
+            dev_p = obs_p;
+        }
+        // (wave-uniform, but hipcc does not see it through the report's closure: a vector register is no base of a load)
+        auto uniform = [](const double *p) {
+            const unsigned long long u = (unsigned long long)p;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            return (const double *)(((unsigned long long)hi << 32) | lo);
+        };
+        obs_p = uniform(obs_p);
+        dev_p = uniform(dev_p);
+        double e_obs, w_obs;
         const long f_step = 8L * half, c_step = 2L * half; // chunks per interval = 2 half; 4 steps, one code pair a chunk
 #define SMART_PAIRS_IO                                                                                                 \
-    "+s"(r0), "+s"(p0), "+s"(r1), "+s"(p1), "+s"(r2), "+s"(p2), "+s"(r3), "+s"(p3), "+s"(ca), "+s"(cb)
-#define SMART_PAIRS_IN [fp] "s"(f_asm), [cp] "s"(codes), [half] "s"(half)
+    "={s[36:37]}"(r0), "={s[38:39]}"(p0), "={s[40:41]}"(r1), "={s[42:43]}"(p1), "={s[44:45]}"(r2), "={s[46:47]}"(p2),     \
+        "={s[48:49]}"(r3), "={s[50:51]}"(p3), "={s68}"(ca), "={s69}"(cb), [eo] "=&s"(e_obs), [wo] "=&s"(w_obs)
+#define SMART_PAIRS_IN                                                                                                 \
+    [fp] "s"(f_asm), [cp] "s"(codes), [half] "s"(half), [op] "s"(obs_p), [wp] "s"(dev_p), "{s[36:37]}"(r0),            \
+        "{s[38:39]}"(p0), "{s[40:41]}"(r1), "{s[42:43]}"(p1), "{s[44:45]}"(r2), "{s[46:47]}"(p2), "{s[48:49]}"(r3),    \
+        "{s[50:51]}"(p3), "{s68}"(ca), "{s69}"(cb)
         for (long iv = 0; iv < n_iv; ++iv) {
             if constexpr (LAST) {
                 asm volatile(SMART_A_PAIRS_INTERVAL(SMART_A_ROUTE_LAST, "", "", "", "", "", "")
@@ -974,7 +992,9 @@ struct FastModel {
             }
             f_asm += f_step;
             codes += c_step;
-            interval_end();
+            obs_p += o_step;
+            dev_p += o_step;
+            interval_end(e_obs, w_obs);
         }
     }
 
