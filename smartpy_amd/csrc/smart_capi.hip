@@ -208,8 +208,7 @@ __global__ void smart_forcing_scan(KArgs a, const double2 *__restrict__ forcing)
             uint2 w = make_uint2(0u, 0u);
             if ((ch + 1) * kChunk <= a.T) {
                 const double2 *__restrict__ v = f + ch * kChunk;
-                w.x = pair_code(ch, 0, step_kind(v[0]), step_kind(v[1]));
-                w.y = pair_code(ch, 1, step_kind(v[2]), step_kind(v[3]));
+                w = chunk_codes(ch, step_kind(v[0]), step_kind(v[1]), step_kind(v[2]), step_kind(v[3]));
             }
             codes[ch] = w;
         }

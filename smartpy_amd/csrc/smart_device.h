@@ -653,6 +653,40 @@ struct Reporter {
         }
     }
 
+    // The report of the streamed step loop (FastModel::stream_pairs), where everything around the arithmetic costs a lone
+    // wavefront an issue turn: e, w fetched ahead by the caller; the report's place in the discharge matrix a per-lane
+    // pointer that moves on by ld (begin_rows / next_row) instead of a 64-bit product per report; a missing observation
+    // told by the mark smart_obs_prepare left in its deviation (one scalar compare); and no test for the lanes beyond
+    // the batch -- they carry the batch's last sample (lane_ctx), so they store what its own lane stores, where it does.
+    double *row = nullptr;
+    __device__ __forceinline__ void begin_rows(const KArgs &a, const LaneCtx &x, long r)
+    {
+        row = a.discharge ? a.discharge + (x.c * a.R + r) * a.ld + x.n : nullptr;
+    }
+    __device__ __forceinline__ void next_row(const KArgs &a)
+    {
+        if (a.discharge)
+            row += a.ld;
+    }
+    __device__ __forceinline__ void emit_marked(const KArgs &a, long r, double val, double e, double w)
+    {
+        if (a.discharge)
+            *row = val;
+        if (want_obj) {
+            if (r == 0)
+                shift = val;
+            if (!is_missing_mark(w)) { // montecarlo.py:195-196
+                const double d = val - e;
+                const double u = val - shift;
+                A += d;
+                B += d * d;
+                C1 += u;
+                C2 += u * u;
+                C3 += w * u;
+            }
+        }
+    }
+
     // The same with the observation e = obs[r] and w = e - mean(e) requested ahead of time by the caller
     // (interval_loop_obs): no scalar-load latency between the last step of the interval and the moments.
     __device__ __forceinline__ void emit_prefetched(const KArgs &a, const LaneCtx &x, long r, double val, double e,
@@ -790,6 +824,13 @@ __device__ __forceinline__ unsigned step_kind(const double2 v)
 __device__ __forceinline__ unsigned pair_code(long chunk, int pair, unsigned k0, unsigned k1)
 {
     return (unsigned)((((chunk & 1) * 2 + pair) * 9 + k0 * 3 + k1) * kPairStride + (k0 == 2 ? 4 : 0));
+}
+// the two code words of a chunk; four calm or four dry steps: one block for the chunk (36 + 2 x chunk parity + kind)
+__device__ __forceinline__ uint2 chunk_codes(long chunk, unsigned k0, unsigned k1, unsigned k2, unsigned k3)
+{
+    if (k0 != 2 && k0 == k1 && k0 == k2 && k0 == k3)
+        return make_uint2((unsigned)((36 + (chunk & 1) * 2 + k0) * kPairStride), 0u);
+    return make_uint2(pair_code(chunk, 0, k0, k1), pair_code(chunk, 1, k2, k3));
 }
 
 // ---- piecewise-constant forcing ------------------------------------------------------------------------------
@@ -1261,9 +1302,10 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         auto report = [&](auto... ew) __attribute__((always_inline)) {
             auto emit = [&](const double val) __attribute__((always_inline)) {
                 if constexpr (sizeof...(ew) == 2)
-                    rep.emit_prefetched(a, x, r, val, ew...);
+                    rep.emit_marked(a, r, val, ew...);
                 else
                     rep.emit(a, x, r, val);
+                rep.next_row(a);
             };
             if constexpr (REPORT == kReportMean) {
                 emit(acc * inv_gap);
@@ -1316,6 +1358,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
             for (int stretch = 0; stretch < 2; ++stretch) { // the warm-up intervals, then the report intervals
                 const long i0 = stretch ? ra : wa, i1 = stretch ? rb : wb;
                 if (stretch == 1) {
+                    rep.begin_rows(a, x, ra);
                     acc = 0.0; // (the warm-up's sum)
                     if (starts_run)
                         m.begin_run();

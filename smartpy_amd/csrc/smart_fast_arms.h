@@ -195,18 +195,18 @@
 #define SMART_A_CALM_SPLIT                                                                                             \
     "v_fma_f64 %[yd], %[yd], %[ds], 0\n\t"                                                                             \
     "v_fma_f64 %[ydg], %[ydg], %[dg], %[dp]\n\t"
-#define SMART_A_RAIN(route, rn, pe, casc, zeros, fill, deep, split)                                                    \
+// (pendcmp: the test for a pending demand, casc: what acts on it -- the hook of the cascade behind  tmp &= wet lanes;
+// the pair blocks, which know the step before, leave both out or put the cascade itself there)
+#define SMART_A_RAIN_X(route, rn, pe, pendcmp, casc, zeros, fill, deep, split)                                         \
     "v_mov_b64 %[t1], " pe "\n\t"                                                                                      \
     "v_fma_f64 %[ex], " rn ", %[pt], -%[t1]\n\t"                                                                       \
-    "v_cmp_le_f64 %[wm], 0, %[ex]\n\t"                                                                                 \
-    "v_cmp_lt_f64 %[tmp], 0, %[pend]\n\t" route "v_max_f64 %[t1], -%[ex], 0\n\t"                                       \
-                                                        "v_add_f64 %[pend], %[pend], %[t1]\n\t"                        \
-                                                        "v_mov_b64 %[xs], 0\n\t"                                       \
-                                                        "v_mov_b64 %[xf], 0\n\t"                                       \
-                                                        "v_mov_b64 %[xg], 0\n\t" zeros                                 \
-                                                        "s_and_saveexec_b64 %[sv], %[wm]\n\t"                          \
-                                                        "s_cbranch_execz 8f\n\t"                                       \
-                                                        "s_and_b64 %[tmp], %[tmp], %[wm]\n\t" casc fill                \
+    "v_cmp_le_f64 %[wm], 0, %[ex]\n\t" pendcmp route "v_max_f64 %[t1], -%[ex], 0\n\t"                                  \
+                                                     "v_add_f64 %[pend], %[pend], %[t1]\n\t"                           \
+                                                     "v_mov_b64 %[xs], 0\n\t"                                          \
+                                                     "v_mov_b64 %[xf], 0\n\t"                                          \
+                                                     "v_mov_b64 %[xg], 0\n\t" zeros                                    \
+                                                     "s_and_saveexec_b64 %[sv], %[wm]\n\t"                             \
+                                                     "s_cbranch_execz 8f\n\t" casc fill                                \
         SMART_A_LEAKS(deep) "v_add_f64 %[t1], %[tot], -%[ai]\n\t"                                                      \
                             "v_add_f64 %[xf], %[xf], %[t1]\n\t" SMART_A_TOT_XG "8:\n\t"                                \
                             "s_or_b64 exec, exec, %[sv]\n\t"                                                           \
@@ -214,6 +214,9 @@
                             "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                                 \
                             "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                                 \
                             "v_add_f64 %[xgs], %[xgs], %[xg]\n\t" split
+#define SMART_A_RAIN(route, rn, pe, casc, zeros, fill, deep, split)                                                    \
+    SMART_A_RAIN_X(route, rn, pe, "v_cmp_lt_f64 %[tmp], 0, %[pend]\n\t", "s_and_b64 %[tmp], %[tmp], %[wm]\n\t" casc,    \
+                   zeros, fill, deep, split)
 #define SMART_A_RAIN_ZEROS_SPLIT "v_mov_b64 %[xd], 0\n\tv_mov_b64 %[dp], 0\n\t"
 #define SMART_A_RAIN_DRAIN_SPLIT "v_mul_f64 %[xd], %[pd], %[t1]\n\t"
 #define SMART_A_RAIN_SPLIT                                                                                             \
@@ -314,8 +317,8 @@
 // dispatch (two compares, two branches not taken) costs a step as much as a dry step's nine vector instructions.
 // Here the kind of every step is worked out ONCE per launch, by smart_forcing_scan: for each chunk of four steps two
 // code words, one per pair of steps -- the byte offset of the block that holds the two arms of that pair, one behind the
-// other with no dispatch in between.  Blocks lie 4 KB apart (36 of them: 2 buffers x 2 pairs x 9 patterns; never-executed
-// padding in between), a pair ends with  base + code word -> s_setpc_b64:  one computed jump per two steps instead of
+// other with no dispatch in between.  Blocks lie SMART_P_STRIDE bytes apart (2 buffers x 2 pairs x 9 patterns + 2 x 2 for
+// whole chunks of one kind; never-executed padding in between), a pair ends with  base + code word -> s_setpc_b64:  one computed jump per two steps instead of
 // four branch instructions.  The forcing is loaded by the asm itself, two chunks ahead, into two fixed register
 // buffers (the arms name their forcing by physical register; a buffer per chunk parity); the loop control (wait,
 // request, count) sits in the tail of the second pair's blocks.  What a block knows about its first step lets the
@@ -336,6 +339,13 @@
 #define SMART_P_ARM_C_F(route, deep, split) SMART_A_CALM_BODY(route, SMART_A_CASCADE "s_nop 0\n\t", deep, split)
 #define SMART_P_ARM_R(route, rn, pe, id, zeros, drain, deep, split)                                                    \
     SMART_A_RAIN(route, rn, pe, SMART_A_CASC_RAIN(id), zeros, SMART_A_FILL_QUICK(drain), deep, split)
+// ... behind a calm step nothing is pending (no test, no hook: 16 bytes less, the parity stays); behind a dry step every
+// lane has a demand pending, and the wet ones -- there is one, past s_cbranch_execz -- take it now: the cascade in line
+// (an s_nop ahead of it: the cascade's long runs on the 8-byte boundary, the filling's head behind it where it was)
+#define SMART_P_ARM_R_Q(route, rn, pe, zeros, drain, deep, split)                                                      \
+    SMART_A_RAIN_X(route, rn, pe, "", "", zeros, SMART_A_FILL_QUICK(drain), deep, split)
+#define SMART_P_ARM_R_F(route, rn, pe, zeros, drain, deep, split)                                                      \
+    SMART_A_RAIN_X(route, rn, pe, "", "s_nop 0\n\t" SMART_A_CASCADE, zeros, SMART_A_FILL_QUICK(drain), deep, split)
 // tails: the jump to the second pair's block; the end of a chunk in buffer 0 / 1
 #define SMART_P_JUMP(code) "s_add_u32 s76, s78, " code "\n\ts_addc_u32 s77, s79, 0\n\ts_setpc_b64 s[76:77]\n\t"
 #define SMART_P_REQUEST(f, c)                                                                                          \
@@ -366,13 +376,12 @@
                                 tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                                          \
     SMART_P_BLOCK(pos, "1", SMART_P_ARM_C_N(route, "0", deep, calm_split) SMART_A_DRY(route, py, dry_split)            \
                                 tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                                          \
-    SMART_P_BLOCK(pos, "2", SMART_P_ARM_C_N(route, "0", deep, calm_split) "s_nop 0\n\t" SMART_P_ARM_R(                 \
-        route, ry, py, "1", zeros, drain, deep, rain_split)                                                            \
-                                tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")) SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))  \
+    SMART_P_BLOCK(pos, "2", SMART_P_ARM_C_N(route, "0", deep, calm_split) "s_nop 0\n\t" SMART_P_ARM_R_Q(               \
+        route, ry, py, zeros, drain, deep, rain_split) tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                   \
     SMART_P_BLOCK(pos, "3", SMART_A_DRY(route, px, dry_split) SMART_P_ARM_C_F(route, deep, calm_split) tail)           \
     SMART_P_BLOCK(pos, "4", SMART_A_DRY(route, px, dry_split) SMART_A_DRY(route, py, dry_split) tail)                  \
-    SMART_P_BLOCK(pos, "5", SMART_A_DRY(route, px, dry_split) "s_nop 0\n\t" SMART_P_ARM_R(                             \
-        route, ry, py, "1", zeros, drain, deep, rain_split) tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))              \
+    SMART_P_BLOCK(pos, "5", SMART_A_DRY(route, px, dry_split) "s_nop 0\n\t" SMART_P_ARM_R_F(                           \
+        route, ry, py, zeros, drain, deep, rain_split) tail)                                                           \
     SMART_P_BLOCK(pos, "6", "s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", zeros, drain, deep, rain_split)            \
                                 "s_nop 0\n\t" SMART_P_ARM_C_N(route, "1", deep, calm_split)                            \
                                     tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0"))                                       \
@@ -384,6 +393,14 @@
                                 SMART_P_ARM_R(route, ry, py, "1", zeros, drain, deep, rain_split)                      \
                                     tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0"))                                       \
                                         SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))
+// ... and two blocks per buffer for the chunks whose four steps are all calm or all dry (a night, a dry spell: 38 % of
+// the chunks of the flat-forcing workload): the first code word leads there, the chunk's tail follows the fourth arm
+#define SMART_P_QUADS(pos, kc, kd, route, p0, p1, p2, p3, tail, deep, calm_split, dry_split)                           \
+    SMART_P_BLOCK(pos, kc, SMART_P_ARM_C_N(route, "0", deep, calm_split) SMART_P_ARM_C_Q(route, deep, calm_split)      \
+                               SMART_P_ARM_C_Q(route, deep, calm_split) SMART_P_ARM_C_Q(route, deep, calm_split)       \
+                                   tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                                       \
+    SMART_P_BLOCK(pos, kd, SMART_A_DRY(route, p0, dry_split) SMART_A_DRY(route, p1, dry_split)                         \
+                               SMART_A_DRY(route, p2, dry_split) SMART_A_DRY(route, p3, dry_split) tail)
 // the interval: %[half] = chunks / 2 (>= 1), %[fp] / %[cp] = the interval's first chunk in the forcing / the code words;
 // %[op] / %[wp] -> %[eo] / %[wo]: the observation of the interval's report and its deviation, requested here and in by
 // the first wait of the loop control
@@ -406,8 +423,12 @@
             SMART_P_NINE("2", route, "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]", SMART_P_TAIL_A1, deep, calm_split,     \
                          zeros, drain, rain_split, dry_split)                                                          \
                 SMART_P_NINE("3", route, "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]", SMART_P_TAIL_B1, deep,             \
-                             calm_split, zeros, drain, rain_split, dry_split) ".p2align 3\n\t"                         \
-                                                                              "99:\n\t"
+                             calm_split, zeros, drain, rain_split, dry_split)                                          \
+                    SMART_P_QUADS("4", "0", "1", route, "s[38:39]", "s[42:43]", "s[46:47]", "s[50:51]",                \
+                                  SMART_P_TAIL_B0, deep, calm_split, dry_split)                                        \
+                        SMART_P_QUADS("4", "2", "3", route, "s[54:55]", "s[58:59]", "s[62:63]", "s[66:67]",            \
+                                      SMART_P_TAIL_B1, deep, calm_split, dry_split) ".p2align 3\n\t"                   \
+                                                                                    "99:\n\t"
 #define SMART_P_CLOBBERS                                                                                               \
     "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",    \
         "s70", "s71", "s72", "s73", "s74", "s76", "s77", "s78", "s79", "vcc", "scc"
