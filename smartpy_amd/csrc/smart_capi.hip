@@ -500,7 +500,7 @@ struct Workspace {
     double *stats = nullptr;
     char *slices = nullptr;
     size_t slice_room = 0;
-    uint2 *codes = nullptr; // at the end of the workspace, when it has the room smart_workspace_bytes() asks for
+    uint2 *codes = nullptr; // behind the hand-over, when the workspace has the room smart_workspace_bytes() asks for
 };
 
 static Workspace carve(const SmartEnsemble *e)
@@ -516,12 +516,10 @@ static Workspace carve(const SmartEnsemble *e)
         w.stats = sb ? (double *)(base + hb) : nullptr;
         w.slices = base + hb + sb;
         w.slice_room = (size_t)e->workspace_bytes - hb - sb;
-        const size_t cb = codes_bytes(e);
-        if (cb && w.slice_room >= slices_need(e) + cb) {
-            w.slice_room -= cb;
-            w.codes = (uint2 *)(base + ((size_t)e->workspace_bytes - cb) / 256 * 256);
-            if ((char *)w.codes < w.slices + slices_need(e)) // (an odd workspace size: the rounding ate the room)
-                w.codes = nullptr, w.slice_room += cb;
+        const size_t cb = codes_bytes(e), sl = slices_need(e);
+        if (cb && w.slice_room >= sl + cb) { // (behind the hand-over of a sliced launch; 8-byte aligned like it)
+            w.codes = (uint2 *)(w.slices + sl);
+            w.slice_room = sl;
         }
     }
     return w;
@@ -816,10 +814,7 @@ static int64_t workspace_bytes(const SmartEnsemble *e)
 {
     if (!e || e->n_catchments < 1 || e->n_samples < 1 || e->n_steps < 0 || e->report_gap < 1)
         return 0;
-    size_t need = header_bytes(e->n_catchments) + obs_stats_bytes(e) + slices_need(e);
-    if (codes_bytes(e))
-        need = (need + 255) / 256 * 256 + codes_bytes(e);
-    return (int64_t)need;
+    return (int64_t)(header_bytes(e->n_catchments) + obs_stats_bytes(e) + slices_need(e) + codes_bytes(e));
 }
 
 static int make_plan(const SmartEnsemble *e, int32_t *plan)

@@ -451,7 +451,11 @@ __device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restric
     // the pair blocks (SMART_A_PAIRS_INTERVAL): the kinds of the steps come from smart_forcing_scan's code words
     // (f itself stays what it was: a __restrict__ pointer that has been through a phi loses hipcc the scalar loads)
     long n_paired = 0;
-    if constexpr (QUICK && !Model::kSplit) if (codes && n_stream > 0) {
+    // (its jumps add a 32-bit offset to the address of block 0 without a carry: not for a code object that straddles a
+    // 4 GB line -- one launch in a few thousand at worst; that one walks the threaded chunks)
+    const unsigned pc_lo = (unsigned)__builtin_amdgcn_s_getpc();
+    const bool clear_of_4g = pc_lo > 0x00400000u && pc_lo < 0xffc00000u;
+    if constexpr (QUICK && !Model::kSplit) if (codes && n_stream > 0 && clear_of_4g) {
         m.template stream_pairs<LAST>(f, f_asm, codes, obs_p, dev_p, n_stream, cpi / 2, acc, interval_end);
         n_paired = n_stream;
         n_stream = 0;
@@ -658,6 +662,7 @@ struct Reporter {
     // pointer that moves on by ld (begin_rows / next_row) instead of a 64-bit product per report; a missing observation
     // told by the mark smart_obs_prepare left in its deviation (one scalar compare); and no test for the lanes beyond
     // the batch -- they carry the batch's last sample (lane_ctx), so they store what its own lane stores, where it does.
+    // (The interval engine, 3,900 cycles an interval, gains nothing from it: same-box A/B, headline level.)
     double *row = nullptr;
     __device__ __forceinline__ void begin_rows(const KArgs &a, const LaneCtx &x, long r)
     {

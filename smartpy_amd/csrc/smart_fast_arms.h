@@ -347,7 +347,8 @@
 #define SMART_P_ARM_R_F(route, rn, pe, zeros, drain, deep, split)                                                      \
     SMART_A_RAIN_X(route, rn, pe, "", "s_nop 0\n\t" SMART_A_CASCADE, zeros, SMART_A_FILL_QUICK(drain), deep, split)
 // tails: the jump to the second pair's block; the end of a chunk in buffer 0 / 1
-#define SMART_P_JUMP(code) "s_add_u32 s76, s78, " code "\n\ts_addc_u32 s77, s79, 0\n\ts_setpc_b64 s[76:77]\n\t"
+// (no carry into the address's upper half: arm_intervals takes this path only when the code lies clear of a 4 GB line)
+#define SMART_P_JUMP(code) "s_add_u32 s76, s78, " code "\n\ts_setpc_b64 s[76:77]\n\t"
 #define SMART_P_REQUEST(f, c)                                                                                          \
     "s_add_u32 s73, s73, 64\n\t"                                                                                       \
     "s_load_dwordx16 " f ", %[fp], s73\n\t"                                                                            \
@@ -409,6 +410,7 @@
     "90:\n\t"                                                                                                          \
     "s_add_u32 s78, s78, 91f-90b\n\t"                                                                                  \
     "s_addc_u32 s79, s79, 0\n\t"                                                                                       \
+    "s_mov_b32 s77, s79\n\t"                                                                                           \
     "s_mov_b32 s73, 64\n\t"                                                                                            \
     "s_load_dwordx16 s[52:67], %[fp], s73\n\t"                                                                         \
     "s_mov_b32 s74, 8\n\t"                                                                                             \
