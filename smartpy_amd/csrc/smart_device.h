@@ -110,6 +110,9 @@ __device__ __forceinline__ void raise_status(const KArgs &a, int bit)
 #ifndef SMART_PAIR_BLOCKS
 #define SMART_PAIR_BLOCKS 1 // the streaming step loop as pair blocks behind computed jumps (0: the threaded chunks; A/B builds)
 #endif
+#ifndef SMART_EVERY_PHASE
+#define SMART_EVERY_PHASE 2 // dwords between a 64-byte line and the loop of time_loop_arms_each
+#endif
 #ifndef SMART_P_STRIDE
 #define SMART_P_STRIDE 2112 // bytes from one pair block to the next (smart_fast_arms.h; a multiple of 64, not a power of two)
 #endif
@@ -397,6 +400,9 @@ __device__ __forceinline__ void time_loop_arms_each(Model &m, const double2 *__r
         for (int j = 0; j < kChunk; ++j)
             asm volatile("" ::"s"(cur[j].x), "s"(cur[j].y));
     }
+    // (where the loop lies counts: SMART_PLACE_LOOP; the phase by measurement, tools/gpu_round.sh phases)
+    if (n_chunks > 0)
+        SMART_PLACE_LOOP(SMART_EVERY_PHASE);
     for (int ch = 0; ch < n_chunks; ++ch) {
         const int pre = (ch + 1 < n_chunks ? ch + 1 : ch) * kChunk; // last chunk: harmless re-load of itself
 #pragma unroll
