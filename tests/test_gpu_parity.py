@@ -451,7 +451,7 @@ def test_headline_size_properties(eng):
     dev_p = torch.from_numpy(params).cuda()
     kw = dict(extra=bench.EXTRA, obs=obs, gw_obs=0.12667)
     out = eng.run_ensemble(dev_p, f, bench.AREA, 3600.0, W, 24, **kw)
-    assert 'smart_fast_intervals[16 slices' in out._prepared.describe()     # the kernel the bench line names
+    assert 'smart_fast_intervals[24 slices' in out._prepared.describe()     # the kernel the bench line names
     perm = torch.randperm(N, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
     out_p = eng.run_ensemble(dev_p[perm], f, bench.AREA, 3600.0, W, 24, want_discharge=False, **kw)
     assert torch.equal(out.objfn[perm], out_p.objfn) and torch.equal(out.gw[perm], out_p.gw)
@@ -470,11 +470,11 @@ def test_headline_size_properties(eng):
     assert rel(gw[rows], gwo) < 1e-10
 
 
-@pytest.mark.parametrize('leg, kernel', [('runs_of_6', 'smart_fast_runs[16 slices'),
-                                         ('flat_forcing', 'smart_fast_steps[16 slices'),
-                                         ('raw_gap24', 'smart_fast_intervals_raw[16 slices'),
-                                         ('raw_gap24_flat', 'smart_fast_steps_raw[16 slices'),
-                                         ('gap1', 'smart_fast_steps_every[16 slices')])
+@pytest.mark.parametrize('leg, kernel', [('runs_of_6', 'smart_fast_runs[24 slices'),
+                                         ('flat_forcing', 'smart_fast_steps[24 slices'),
+                                         ('raw_gap24', 'smart_fast_intervals_raw[24 slices'),
+                                         ('raw_gap24_flat', 'smart_fast_steps_raw[24 slices'),
+                                         ('gap1', 'smart_fast_steps_every[24 slices')])
 def test_bench_legs_at_full_size(eng, leg, kernel):
     """The other legs of the bench line at their full size: the headline's 1e5 LHS rows x hourly 10 years on
     6-hourly values (the run engine, two-mode wet intervals over runs of six steps), on forcing that varies inside
