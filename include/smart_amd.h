@@ -138,7 +138,9 @@ typedef struct SmartEnsemble {
     void *workspace;       /* device scratch of workspace_bytes bytes: observation statistics when    */
                            /* objfn != NULL ([C][8 + R] doubles, required), and the hand-over buffer   */
                            /* of a time-sliced launch (optional: without room for it the launch is     */
-                           /* not sliced).  smart_workspace_bytes() tells how much both need.          */
+                           /* not sliced), and the code words of the step loop's pair blocks (optional:  */
+                           /* without them it dispatches step by step).  smart_workspace_bytes() tells   */
+                           /* how much all of them need.                                               */
     int64_t workspace_bytes;
 
     void *stream;          /* hipStream_t; NULL = the default stream                                 */
@@ -163,7 +165,8 @@ int smart_check_ensemble(const SmartEnsemble *e);
 /* Bytes of device scratch the call wants in e->workspace for these sizes and outputs (pointers are not read):
  * a header (status word, counters, per-catchment forcing flags), the observation statistics if e->objfn is set,
  * plus -- on a machine with a HIP device -- the hand-over buffer of the time-sliced launch the library would
- * choose.  The library allocates nothing itself: the caller owns every buffer, which also lets the call be captured
+ * choose, plus 8 bytes per four time steps and catchment for fast summary / raw runs whose report gap is a multiple
+ * of eight steps (the kinds of the steps, worked out once per launch).  The library allocates nothing itself: the caller owns every buffer, which also lets the call be captured
  * into a HIP graph.  A launch without a workspace runs unsliced and reports no status. */
 int64_t smart_workspace_bytes(const SmartEnsemble *e);
 
