@@ -466,7 +466,7 @@
 // an exit inside every step (the kernels with exits, FastModel::kExits) costs a lone wavefront one per step.
 // Bit-identical to mode 0 (tools/debug/steps_bits.py).  2: both loops unrolled twice.
 #ifndef SMART_WET_MODES
-#define SMART_WET_MODES 1
+#define SMART_WET_MODES 3
 #endif
 #define SMART_A_WET_ABSORBED(fix)                                                                                      \
     SMART_A_WET_HEAD "v_cmp_nle_f64 vcc, %[t1], 0\n\t"                                                                 \
@@ -504,6 +504,59 @@
     "s_nop 0\n\t"                                                                                                      \
     "6:\n\t" SMART_A_WET_FULL("7") "s_add_u32 %[cnt], %[cnt], 1\n\t"                                                   \
     "s_cbranch_scc0 6b\n\t"                                                                                            \
+    "9:\n\t"
+#elif SMART_WET_MODES == 3
+// FOUR steps per turn of either loop (round 4).  What a lone wavefront pays at the end of every step of mode 1 is a taken
+// branch: 24 cycles and more (tools/microbench/lone.hip) on a step of 57 to 73 vector instructions; a branch that is not
+// taken costs it 16, so unrolling with a test between the copies (mode 2) gains next to nothing.  Here the n mod 4
+// steps that do not fill a turn come first, in mode 1's loops; the rest runs four to a turn with one counter and one
+// back-edge per turn.  The absorbed loops leave for the full ones as in mode 1: from copy k into the middle of copy k.
+// Same instructions per step, same bits.  Parities as in mode 1: an absorbed step starts at 4 mod 8 and ends on the
+// boundary -- an s_nop between the copies of a turn (4 cycles against eleven straddling instructions); the full steps
+// are 64-bit encodings throughout and start on the boundary.
+#ifndef SMART_WET_TURN
+#define SMART_WET_TURN 4 // steps per turn: 4 or 8
+#endif
+#if SMART_WET_TURN == 8
+#define SMART_A_WET_SHIFT "3"
+#define SMART_A_WET_MASK "7"
+#define SMART_A_WET_ABS_MORE                                                                                           \
+    "s_nop 0\n\t" SMART_A_WET_ABSORBED("75") "s_nop 0\n\t" SMART_A_WET_ABSORBED("76") "s_nop 0\n\t" SMART_A_WET_ABSORBED("77") \
+    "s_nop 0\n\t" SMART_A_WET_ABSORBED("78")
+#define SMART_A_WET_FULL_MORE SMART_A_WET_FULL("75") SMART_A_WET_FULL("76") SMART_A_WET_FULL("77") SMART_A_WET_FULL("78")
+#else
+#define SMART_A_WET_SHIFT "2"
+#define SMART_A_WET_MASK "3"
+#define SMART_A_WET_ABS_MORE ""
+#define SMART_A_WET_FULL_MORE ""
+#endif
+#define SMART_A_WET_GROUPS                                                                                             \
+    "s_lshr_b32 %[cnt], %[n], " SMART_A_WET_SHIFT "\n\t"                                                               \
+    "s_sub_u32 %[cnt], 0, %[cnt]\n\t"                                                                                  \
+    "s_cbranch_scc0 9f\n\t"
+#define SMART_A_WET_INTERVAL                                                                                           \
+    SMART_A_ALIGN8 "s_cmp_eq_u32 %[ok], 0\n\t"                                                                         \
+    "s_cbranch_scc1 40f\n\t"                                                                                           \
+    "s_and_b32 %[cnt], %[n], " SMART_A_WET_MASK "\n\t"                                                                 \
+    "s_cbranch_scc0 20f\n\t"                                                                                           \
+    "s_sub_u32 %[cnt], 0, %[cnt]\n\t"                                                                                  \
+    "5:\n\t" SMART_A_WET_ABSORBED("7") "s_add_u32 %[cnt], %[cnt], 1\n\t"                                               \
+    "s_cbranch_scc0 5b\n\t"                                                                                            \
+    "20:\n\t" SMART_A_WET_GROUPS "25:\n\t" SMART_A_WET_ABSORBED("71") "s_nop 0\n\t" SMART_A_WET_ABSORBED("72")         \
+    "s_nop 0\n\t" SMART_A_WET_ABSORBED("73") "s_nop 0\n\t" SMART_A_WET_ABSORBED("74") SMART_A_WET_ABS_MORE                   \
+    "s_add_u32 %[cnt], %[cnt], 1\n\t"                                                                                  \
+    "s_cbranch_scc0 25b\n\t"                                                                                           \
+    "s_branch 9f\n\t"                                                                                                  \
+    "40:\n\t"                                                                                                          \
+    "s_and_b32 %[cnt], %[n], " SMART_A_WET_MASK "\n\t"                                                                 \
+    "s_cbranch_scc0 30f\n\t"                                                                                           \
+    "s_sub_u32 %[cnt], 0, %[cnt]\n\t"                                                                                  \
+    "6:\n\t" SMART_A_WET_FULL("7") "s_add_u32 %[cnt], %[cnt], 1\n\t"                                                   \
+    "s_cbranch_scc0 6b\n\t"                                                                                            \
+    "30:\n\t" SMART_A_WET_GROUPS "s_nop 0\n\t"                                                                         \
+    "31:\n\t" SMART_A_WET_FULL("71") SMART_A_WET_FULL("72") SMART_A_WET_FULL("73") SMART_A_WET_FULL("74")              \
+    SMART_A_WET_FULL_MORE "s_add_u32 %[cnt], %[cnt], 1\n\t"                                                                                  \
+    "s_cbranch_scc0 31b\n\t"                                                                                           \
     "9:\n\t"
 #else
 #define SMART_A_WET_INTERVAL                                                                                           \

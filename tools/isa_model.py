@@ -184,7 +184,7 @@ def fill_paths(workload):
 
 
 def fmt(c):
-    return 'VALU %3d (fp64 %3d, vcmp %d, vmov %d) scalar %2d (branch %d) smem %d' % (
+    return 'VALU %3d (fp64 %3d, vcmp %d, vmov %d) scalar %4.4g (branch %.4g) smem %d' % (
         c['VALU'], c.get('fp64', 0), c.get('vcmp', 0), c.get('vmov', 0), c['scalar'], c.get('branch', 0), c.get('smem', 0))
 
 
@@ -345,22 +345,37 @@ def intervals_model(out):
     wet = [blk for blk in blocks if {'5', '6', '7', '9'} <= {lab for lab, _ in blk[2]}]
     assert wet, 'no wet-interval asm found'
     seg = segments(wet[0][2])
-    # 5: the loop of steps whose excess the top layer takes in every lane (ends with its counter, its back-edge and the
-    # jump over the other loop); 6: head of a full step, 7: where the first step that leaves something over joins
-    # it; 9: end
-    if seg['5'][-1] == 's_nop':         # (the padding behind `s_branch 9f` that puts the loop of full steps on an 8-byte
-        seg['5'].pop()                  # boundary: never executed)
-    assert seg['5'][-3:] == ['s_add_u32', 's_cbranch_scc0', 's_branch'] and seg['7'][-2:] == ['s_add_u32', 's_cbranch_scc0']
-    absorbed = hist(seg['5'][:-3])
+    # 5: the loop of steps whose excess the top layer takes in every lane, 6: head of a full step, 7: where the first step
+    # that leaves something over joins it; 9: end.  SMART_WET_MODES 3 (round 4): these two loops take the n mod 4 steps
+    # that do not fill a turn; 25 / 31 = the same steps four to a turn (71 ... 74 the joins), one counter and one back-edge
+    # per turn, an s_nop between the absorbed copies; 20 / 30 / 40: the group counts
+    four = '25' in seg and '31' in seg
+    if four:
+        assert seg['5'][-2:] == ['s_add_u32', 's_cbranch_scc0'] and seg['7'][-2:] == ['s_add_u32', 's_cbranch_scc0']
+        absorbed = hist(seg['5'][:-2])
+        turn_abs = seg['25']
+        assert turn_abs[-3:] == ['s_add_u32', 's_cbranch_scc0', 's_branch'] and turn_abs.count('s_nop') == 3
+        assert hist([o for o in turn_abs[:-3] if o != 's_nop'])['VALU'] == 4 * absorbed['VALU']
+        turn_full = seg['31'] + seg['71'] + seg['72'] + seg['73'] + seg['74']
+        assert turn_full[-2:] == ['s_add_u32', 's_cbranch_scc0']
+        assert hist(turn_full[:-2])['VALU'] == 4 * hist(seg['6'] + seg['7'][:-2])['VALU']
+    else:
+        if seg['5'][-1] == 's_nop':         # (the padding behind `s_branch 9f` that puts the loop of full steps on an
+            seg['5'].pop()                  # 8-byte boundary: never executed)
+        assert seg['5'][-3:] == ['s_add_u32', 's_cbranch_scc0', 's_branch']
+        assert seg['7'][-2:] == ['s_add_u32', 's_cbranch_scc0']
+        absorbed = hist(seg['5'][:-3])
     step = hist(seg['6'] + seg['7'][:-2])
     loop_tail = hist(seg['7'][-2:])
-    entry = hist(seg[''])
+    if four:    # per step of a 24-step interval: a quarter of a turn's counter and back-edge
+        loop_tail = Counter({k: v / 4.0 for k, v in loop_tail.items()})
+    entry = hist(seg[''] + (seg['20'] if four else []))       # (+ the group count of the loop the interval starts in)
     paths = fill_paths('headline')
     share = paths['absorbed_prefix_of_the_run']
     report = ['# smart_fast_intervals: the wet interval (smart_fast_arms.h: SMART_A_WET_INTERVAL)', '',
               '- a full wet step: %s' % fmt(step),
               '- a step whose excess the top layer takes in every lane: %s' % fmt(absorbed),
-              '- loop tail, once per step: %s' % fmt(loop_tail),
+              '- loop tail, per step%s: %s' % (' (four steps to a turn: a quarter of its counter and back-edge)' if four else '', fmt(loop_tail)),
               '- entry, once per wet interval: %s' % fmt(entry),
               '- steps in the absorbed prefix of their interval: %.3f of the wet wave-steps; intervals that change '
               'mode: %.2f of the wet ones (tools/fill_paths.py, %d rows)' % (share, paths['mode_switches_per_wet_run'],
