@@ -1,5 +1,5 @@
 """Replays the seeds of tests/test_gpu_parity.py::run_interval_cases (or, with --wide / --batch, ::run_wide_cases /
-::run_batch_cases) given on the command line and prints, for every comparison that is off by more than its tolerance
+::run_batch_cases; --raw / --every: run_interval_cases under those reports) given on the command line and prints, for every comparison that is off by more than its tolerance
 (or 1e-9 for the purely relative ones), where the largest difference sits and how large the values are there.
 --plain leaves SMART_TIME_SLICES / SMART_EXITS alone."""
 import os
@@ -61,6 +61,10 @@ for seed in [int(x) for x in sys.argv[1:] if not x.startswith('--')]:
             t.run_wide_cases(engine, seed, 10)
         elif '--batch' in sys.argv:
             t.run_batch_cases(engine, seed, 10)
+        elif '--every' in sys.argv:
+            t.run_interval_cases(engine, setenv, seed, 5, mode='every')      # (fuzz_wide.py runs cases // 2 of these)
+        elif '--raw' in sys.argv:
+            t.run_interval_cases(engine, setenv, seed, 10, mode='raw')
         else:
             t.run_interval_cases(engine, setenv, seed, 10)
         print('seed', seed, 'passed')
