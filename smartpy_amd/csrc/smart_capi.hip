@@ -213,6 +213,30 @@ __global__ void smart_forcing_scan(KArgs a, const double2 *__restrict__ forcing)
             codes[ch] = w;
         }
     }
+    // a report every step: the run as records of (rain, PE, observation, deviation) and a code word per pair of steps
+    if (a.estream) {
+        double *rec = const_cast<double *>(a.estream) + (long)blockIdx.y * every_pairs(a.T) * 8;
+        unsigned *codes = const_cast<unsigned *>(a.ecodes) + (long)blockIdx.y * every_pairs(a.T);
+        const double *obs = a.obs ? a.obs + (long)blockIdx.y * a.R : nullptr;
+        const double *dev = a.ws ? a.ws + (long)blockIdx.y * (kWsHead + a.R) + kWsHead : nullptr;
+        for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < every_pairs(a.T); p += (long)gridDim.x * blockDim.x) {
+            double r[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            unsigned code = 0;
+            if (2 * p + 1 < a.T) {
+                for (int j = 0; j < 2; ++j) {
+                    const long t = 2 * p + j;
+                    r[4 * j] = f[t].x;
+                    r[4 * j + 1] = f[t].y;
+                    r[4 * j + 2] = obs && dev && t < a.R ? obs[t] : 0.0;
+                    r[4 * j + 3] = obs && dev && t < a.R ? dev[t] : 0.0;
+                }
+                code = every_code(p, step_kind(f[2 * p]), step_kind(f[2 * p + 1]));
+            }
+            for (int j = 0; j < 8; ++j)
+                rec[p * 8 + j] = r[j];
+            codes[p] = code;
+        }
+    }
     if (bad)
         __hip_atomic_fetch_or(a.fflags + blockIdx.y, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // a NaN or an infinity in the forcing: the fast kernels are not made for it (what the reference's branches do with
@@ -374,9 +398,13 @@ static size_t slices_need(const SmartEnsemble *e)
     return d && plan_time_slices(e, d->n_simd, &per_simd, &load) > 1 ? slice_bytes(e->n_samples, e->n_catchments) : 0;
 }
 
-// the code words of the pair blocks: for the calls whose regular rows may take the streaming step loop
+// the code words of the pair blocks: for the calls whose regular rows may take the streaming step loop; for a report every
+// step (gap 1, where there are no pair blocks of that kind) the stream of records and its code words instead
 static size_t codes_bytes(const SmartEnsemble *e)
 {
+    if (e->math_mode == SMART_MATH_FAST && merged_report(e) == kReportEvery)
+        return ((size_t)e->n_catchments * (size_t)every_pairs(e->n_steps) * (8 * sizeof(double) + sizeof(unsigned)) + 255) /
+               256 * 256;
     if (e->math_mode != SMART_MATH_FAST || e->report_gap % (2 * kChunk) != 0)
         return 0;
     const int merged = merged_report(e);
@@ -581,10 +609,24 @@ static void reset_workspace(const Workspace &w, long n_catch, int *flags, long n
                        n_flags);
 }
 
+// which of the two uses of Workspace::codes this call makes (codes_bytes)
+static void set_codes(const SmartEnsemble *e, KArgs *a, const Workspace &w)
+{
+    a->codes = nullptr, a->estream = nullptr, a->ecodes = nullptr;
+    if (!w.codes || !pair_blocks_wanted())
+        return;
+    if (merged_report(e) == kReportEvery) {
+        a->estream = (const double *)w.codes;
+        a->ecodes = (const unsigned *)(a->estream + (size_t)e->n_catchments * (size_t)every_pairs(e->n_steps) * 8);
+    } else {
+        a->codes = w.codes;
+    }
+}
+
 static void scan_forcing(const SmartEnsemble *e, KArgs a, const Workspace &w, hipStream_t s)
 {
     a.fflags = w.fflags;
-    a.codes = w.codes;
+    set_codes(e, &a, w);
     hipLaunchKernelGGL(smart_forcing_scan, dim3(64, (unsigned)e->n_catchments), dim3(256), 0, s, a,
                        reinterpret_cast<const double2 *>(e->forcing));
 }
@@ -737,7 +779,8 @@ static int run(const SmartEnsemble *e, bool literal_recip = false)
         scan_forcing(e, a, w, s);
         if (x.report >= 0 && (x.class_mask & SMART_PLAN_CLASS_REGULAR)) {
             a.fflags = a_sliced.fflags = w.fflags;
-            a.codes = a_sliced.codes = pair_blocks_wanted() ? w.codes : nullptr;
+            set_codes(e, &a, w);
+            a_sliced.codes = a.codes, a_sliced.estream = a.estream, a_sliced.ecodes = a.ecodes;
         }
     }
 

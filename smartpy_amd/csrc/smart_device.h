@@ -46,6 +46,10 @@ struct KArgs {
     // workspace header (null without a workspace: no status word, no time slices, every wavefront scans the forcing)
     int *hdr = nullptr;       // [kHdrInts]: status word, ticket counters of the sliced kernels
     int *fflags = nullptr;    // [C]: forcing flags of catchment c (forcing_flags_of_step below), from smart_forcing_scan
+    // a report every step (gap 1): the run as one stream of records (rain, PE, observation, deviation per step) and a
+    // code word per pair of steps (SMART_A_EVERY_STREAM), from smart_forcing_scan; null: time_loop_arms_each
+    const double *estream = nullptr;  // [C][every_pairs(T)][8]
+    const unsigned *ecodes = nullptr; // [C][every_pairs(T)]
     const uint2 *codes = nullptr; // [C][code_chunks(T)]: per chunk of four steps the two code words of the pair blocks
                                   // (SMART_A_PAIRS_INTERVAL), from smart_forcing_scan; null: the threaded chunks
     // run lengths a catchment's forcing is tested for: the divisors of the report gap, largest first (div[0] = gap)
@@ -109,6 +113,9 @@ __device__ __forceinline__ void raise_status(const KArgs &a, int bit)
 #endif
 #ifndef SMART_PAIR_BLOCKS
 #define SMART_PAIR_BLOCKS 1 // the streaming step loop as pair blocks behind computed jumps (0: the threaded chunks; A/B builds)
+#endif
+#ifndef SMART_E_STRIDE
+#define SMART_E_STRIDE 2240 // bytes from one block of the every-step stream to the next (smart_fast_arms.h)
 #endif
 #ifndef SMART_EVERY_PHASE
 #define SMART_EVERY_PHASE 2 // dwords between a 64-byte line and the loop of time_loop_arms_each
@@ -836,6 +843,13 @@ __device__ __forceinline__ unsigned pair_code(long chunk, int pair, unsigned k0,
 {
     return (unsigned)((((chunk & 1) * 2 + pair) * 9 + k0 * 3 + k1) * kPairStride + (k0 == 2 ? 4 : 0));
 }
+// the every-step stream: pairs of steps, two register buffers by the pair's parity
+constexpr long kEveryStride = SMART_E_STRIDE;
+__host__ __device__ constexpr long every_pairs(long T) { return T / 2 + 4; } // (+ the requests beyond a stretch)
+__device__ __forceinline__ unsigned every_code(long pair, unsigned k0, unsigned k1)
+{
+    return (unsigned)(((pair & 1) * 9 + k0 * 3 + k1) * kEveryStride + (k0 == 2 ? 4 : 0));
+}
 // the two code words of a chunk; four calm or four dry steps: one block for the chunk (36 + 2 x chunk parity + kind)
 __device__ __forceinline__ uint2 chunk_codes(long chunk, unsigned k0, unsigned k1, unsigned k2, unsigned k3)
 {
@@ -1389,11 +1403,37 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                                 report_every(store_tag, obs_tag, OBS ? obs_c[0] : 0.0, OBS ? dev_c[0] : 0.0);
                                 first = 1;
                             }
-                            time_loop_arms_each<Q, OBS>(m, f + first, OBS ? obs_c + first : nullptr,
-                                                        OBS ? dev_c + first : nullptr, i1 - first, acc,
-                                                        [&](long, const double e, const double w) {
-                                                            report_every(store_tag, obs_tag, e, w);
-                                                        });
+                            auto each = [&](long from, long n) __attribute__((always_inline)) {
+                                time_loop_arms_each<Q, OBS>(m, f + from, OBS ? obs_c + from : nullptr,
+                                                            OBS ? dev_c + from : nullptr, n, acc,
+                                                            [&](long, const double e, const double w) {
+                                                                report_every(store_tag, obs_tag, e, w);
+                                                            });
+                            };
+#if SMART_PAIR_BLOCKS
+                            // whole groups of four steps, from a multiple of four on: the stream of SMART_A_EVERY_STREAM
+                            if constexpr (Q && !Model::kSplit) {
+                                const unsigned pc_lo = (unsigned)__builtin_amdgcn_s_getpc(); // (see arm_intervals)
+                                if (a.estream && pc_lo > 0x00400000u && pc_lo < 0xffc00000u) {
+                                    constexpr bool STORE = decltype(store_tag)::value;
+                                    const long lead = (4 - first % 4) % 4 < i1 - first ? (4 - first % 4) % 4 : i1 - first;
+                                    each(first, lead);
+                                    first += lead;
+                                    const long quads = (i1 - first) / 4;
+                                    if (quads > 0) {
+                                        double *lane_row = STORE ? row + x.n : nullptr;
+                                        m.template stream_every<STORE, OBS>(
+                                            a.estream + (x.c * every_pairs(a.T) + first / 2) * 8,
+                                            a.ecodes + x.c * every_pairs(a.T) + first / 2, (int)quads, acc, rep.A, rep.B,
+                                            rep.C1, rep.C2, rep.C3, rep.shift, q_out_total, lane_row, a.ld);
+                                        if constexpr (STORE)
+                                            row += quads * 4 * a.ld;
+                                        first += quads * 4;
+                                    }
+                                }
+                            }
+#endif
+                            each(first, i1 - first);
                         };
                         if (row && rep.want_obj)
                             run_steps(std::true_type{}, std::true_type{});

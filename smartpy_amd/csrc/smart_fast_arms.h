@@ -57,12 +57,13 @@
 // ends up holding the outflow of the step just taken (the river's state ahead of its update) and the routing temporary
 // is kept in registers of its own: qi = dt/rk * (the step's inflow to the river, sum of the five catchment outflows),
 // qg = dt/rk * (its groundwater part) -- the two sums behind the groundwater ratio of raw reports (:194-195; the
-// common factor dt/rk cancels in the ratio).  The river update rounds exactly as in SMART_A_ROUTE.
+// common factor dt/rk cancels in the ratio).  The river update rounds exactly as in SMART_A_ROUTE.  (The move in its
+// 64-bit encoding, _e64: five 8-byte instructions like SMART_A_ROUTE's, the parity of what follows is the same.)
 #define SMART_A_ROUTE_LAST                                                                                             \
     "v_mul_f64 %[qg], %[cg], %[yg]\n\t"                                                                                \
     "v_fma_f64 %[qi], %[cf], %[yf], %[qg]\n\t"                                                                         \
     "v_fma_f64 %[qi], %[cs], %[ys], %[qi]\n\t"                                                                         \
-    "v_mov_b64 %[acc], %[riv]\n\t"                                                                                     \
+    "v_mov_b64_e64 %[acc], %[riv]\n\t"                                                                                 \
     "v_fma_f64 %[riv], %[riv], %[oma], %[qi]\n\t"
 // deferred evaporation cascade over the active lanes (flush_pending): t = d - l; l = max(-t, 0); d = max(C t, 0)
 #define SMART_A_CASCADE                                                                                                \
@@ -434,6 +435,92 @@
 #define SMART_P_CLOBBERS                                                                                               \
     "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",    \
         "s70", "s71", "s72", "s73", "s74", "s76", "s77", "s78", "s79", "vcc", "scc"
+
+// ---- a report every step (gap 1) as pair blocks with the report in the asm (round 4) ---------------------------------
+// The every-step loop (time_loop_arms_each) dispatches step by step (SMART_A_STEP: one to two taken branches a step)
+// and reports through compiled code between the asms.  Here smart_forcing_scan lays the run out as ONE stream of
+// 32-byte records -- rain, PE, the observation of the step's report, its deviation from the mean -- and a code word per
+// PAIR of steps; a pair is one s_load_dwordx16, two register buffers swap roles (P0 = s[36:51], P1 = s[52:67]; code
+// words s68 / s70), and a block holds arm, report, arm, report and the loop control: one computed jump per two steps,
+// no compiled code in between, for a whole stretch of steps (a multiple of four: the exit test sits in P1's tails).
+// The report is Reporter's (smart_device.h: report_every), operation for operation: the discharge through a per-lane
+// row pointer (lanes beyond the batch carry its last sample and store what its lane stores), the moments unless the
+// deviation carries the missing-observation mark (its upper word: one scalar compare), the sum of the outflows.
+// 18 blocks, SMART_E_STRIDE bytes apart.  After a rain arm -- which ends at 4 mod 8 -- and ahead of one an s_nop: the
+// reports and the other arms on the 8-byte boundary.
+#define SMART_E_STORE "global_store_dwordx2 %[row], %[acc], off\n\tv_lshl_add_u64 %[row], %[ld], 3, %[row]\n\t"
+#define SMART_E_MOMENTS(e, w, whi)                                                                                     \
+    "s_cmp_eq_u32 " whi ", 0x7ff8dead\n\t"                                                                             \
+    "s_cbranch_scc1 50f\n\t"                                                                                           \
+    "s_nop 0\n\t"                                                                                                      \
+    "v_add_f64 %[rd], %[acc], -" e "\n\t"                                                                              \
+    "v_add_f64 %[ru], %[acc], -%[shift]\n\t"                                                                           \
+    "v_add_f64 %[mA], %[mA], %[rd]\n\t"                                                                                \
+    "v_fma_f64 %[mB], %[rd], %[rd], %[mB]\n\t"                                                                         \
+    "v_add_f64 %[mC1], %[mC1], %[ru]\n\t"                                                                              \
+    "v_fma_f64 %[mC2], %[ru], %[ru], %[mC2]\n\t"                                                                       \
+    "v_fma_f64 %[mC3], " w ", %[ru], %[mC3]\n\t"                                                                       \
+    "50:\n\t"
+#define SMART_E_SUM "v_add_f64 %[qtot], %[qtot], %[acc]\n\t"
+// rep(e, w, whi): the report text of a step (the caller composes it from the three pieces above)
+#define SMART_E_C_N(rep, id) SMART_P_ARM_C_N(SMART_A_ROUTE_LAST, id, "", "") rep
+#define SMART_E_C_Q(rep) SMART_P_ARM_C_Q(SMART_A_ROUTE_LAST, "", "") rep
+#define SMART_E_C_F(rep) SMART_P_ARM_C_F(SMART_A_ROUTE_LAST, "", "") rep
+#define SMART_E_D(pe, rep) SMART_A_DRY(SMART_A_ROUTE_LAST, pe, "") rep
+#define SMART_E_R(rn, pe, id, rep) "s_nop 0\n\t" SMART_P_ARM_R(SMART_A_ROUTE_LAST, rn, pe, id, "", "", "", "") "s_nop 0\n\t" rep
+#define SMART_E_R_Q(rn, pe, rep) "s_nop 0\n\t" SMART_P_ARM_R_Q(SMART_A_ROUTE_LAST, rn, pe, "", "", "", "") "s_nop 0\n\t" rep
+#define SMART_E_R_F(rn, pe, rep) "s_nop 0\n\t" SMART_P_ARM_R_F(SMART_A_ROUTE_LAST, rn, pe, "", "", "", "") "s_nop 0\n\t" rep
+#define SMART_E_BLOCK(pos, k, body) ".org 91b+(" pos "*9+" k ")*" SMART_P_STR(SMART_E_STRIDE) "\n\t" body
+#define SMART_E_NINE(pos, rx, px, r0, ry, py, r1, tail)                                                                \
+    SMART_E_BLOCK(pos, "0", SMART_E_C_N(r0, "0") SMART_E_C_Q(r1) tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))         \
+    SMART_E_BLOCK(pos, "1", SMART_E_C_N(r0, "0") SMART_E_D(py, r1) tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))       \
+    SMART_E_BLOCK(pos, "2", SMART_E_C_N(r0, "0") SMART_E_R_Q(ry, py, r1) tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0"))) \
+    SMART_E_BLOCK(pos, "3", SMART_E_D(px, r0) SMART_E_C_F(r1) tail)                                                    \
+    SMART_E_BLOCK(pos, "4", SMART_E_D(px, r0) SMART_E_D(py, r1) tail)                                                  \
+    SMART_E_BLOCK(pos, "5", SMART_E_D(px, r0) SMART_E_R_F(ry, py, r1) tail)                                            \
+    SMART_E_BLOCK(pos, "6", SMART_E_R(rx, px, "0", r0) SMART_E_C_N(r1, "1")                                            \
+                                tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0")) SMART_P_OOL(SMART_A_CASC_CALM_OOL("1")))  \
+    SMART_E_BLOCK(pos, "7", SMART_E_R(rx, px, "0", r0) SMART_E_D(py, r1) tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0"))) \
+    SMART_E_BLOCK(pos, "8", SMART_E_R(rx, px, "0", r0) SMART_E_R(ry, py, "1", r1)                                      \
+                                tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0")) SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))
+#define SMART_E_REQUEST(p, c)                                                                                          \
+    "s_add_u32 s73, s73, 64\n\t"                                                                                       \
+    "s_load_dwordx16 " p ", %[sp], s73\n\t"                                                                            \
+    "s_add_u32 s74, s74, 4\n\t"                                                                                        \
+    "s_load_dword " c ", %[cp], s74\n\t"
+#define SMART_E_TAIL_P0 "s_waitcnt lgkmcnt(0)\n\t" SMART_E_REQUEST("s[36:51]", "s68") SMART_P_JUMP("s70")
+#define SMART_E_TAIL_P1                                                                                                \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+    "s_add_u32 s72, s72, 1\n\t"                                                                                        \
+    "s_cbranch_scc1 99f\n\t" SMART_E_REQUEST("s[52:67]", "s70") SMART_P_JUMP("s68")
+// %[quads] = steps / 4 (>= 1); %[sp] / %[cp]: the first pair's record and code word; store / mom: SMART_E_STORE or "",
+// SMART_E_MOMENTS or nothing
+#define SMART_E_REP(store, mom, e, w, whi) store mom(e, w, whi) SMART_E_SUM
+#define SMART_E_NOMOM(e, w, whi) ""
+#define SMART_A_EVERY_STREAM(store, mom)                                                                               \
+    "s_getpc_b64 s[78:79]\n\t"                                                                                         \
+    "90:\n\t"                                                                                                          \
+    "s_add_u32 s78, s78, 91f-90b\n\t"                                                                                  \
+    "s_addc_u32 s79, s79, 0\n\t"                                                                                       \
+    "s_mov_b32 s77, s79\n\t"                                                                                           \
+    "s_load_dwordx16 s[36:51], %[sp], 0x0\n\t"                                                                         \
+    "s_load_dword s68, %[cp], 0x0\n\t"                                                                                 \
+    "s_mov_b32 s73, 64\n\t"                                                                                            \
+    "s_load_dwordx16 s[52:67], %[sp], s73\n\t"                                                                         \
+    "s_mov_b32 s74, 4\n\t"                                                                                             \
+    "s_load_dword s70, %[cp], s74\n\t"                                                                                 \
+    "s_sub_u32 s72, 0, %[quads]\n\t"                                                                                   \
+    "s_waitcnt lgkmcnt(0)\n\t" SMART_P_JUMP("s68") ".p2align 6\n\t"                                                    \
+    "91:\n\t" SMART_E_NINE("0", "s[36:37]", "s[38:39]", SMART_E_REP(store, mom, "s[40:41]", "s[42:43]", "s43"),        \
+                           "s[44:45]", "s[46:47]", SMART_E_REP(store, mom, "s[48:49]", "s[50:51]", "s51"),             \
+                           SMART_E_TAIL_P0)                                                                            \
+        SMART_E_NINE("1", "s[52:53]", "s[54:55]", SMART_E_REP(store, mom, "s[56:57]", "s[58:59]", "s59"), "s[60:61]",  \
+                     "s[62:63]", SMART_E_REP(store, mom, "s[64:65]", "s[66:67]", "s67"), SMART_E_TAIL_P1)              \
+            ".p2align 3\n\t"                                                                                           \
+            "99:\n\t"
+#define SMART_E_CLOBBERS                                                                                               \
+    "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",    \
+        "s68", SMART_P_CLOBBERS
 
 // ---- the wet interval of the interval engine (FastModel::wet_interval, merged regular variant, no exits) ----------
 // `n` wet steps with one excess: 73 vector instructions a step (5 routing, 22 filling, 34 for the three leak passes

@@ -998,6 +998,35 @@ struct FastModel {
         }
     }
 
+    // `quads` x 4 steps with a report after every step, walked through the blocks of SMART_A_EVERY_STREAM: records = the
+    // stretch's first pair in smart_forcing_scan's stream (rain, PE, observation, deviation per step), codes = its code
+    // word.  The report's variables are Reporter's (smart_device.h: report_every); row = this lane's place in the first
+    // report's row of the discharge matrix, moved on by ld per report.  QUICK waves, models without the final row.
+    template <bool STORE, bool OBS>
+    __device__ __forceinline__ void stream_every(const double *records, const unsigned *codes, int quads, double &acc,
+                                                 double &mA, double &mB, double &mC1, double &mC2, double &mC3,
+                                                 const double shift, double &qtot, double *&row, const long ld)
+    {
+        static_assert(!SPLIT, "stream_every: the SPLIT models take time_loop_arms_each");
+        SMART_ARM_LOCALS;
+        double rd, ru;
+        unsigned long long row_bits = (unsigned long long)row;
+#define SMART_EVERY_OUT                                                                                                \
+    SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_LAST, [mA] "+v"(mA), [mB] "+v"(mB), [mC1] "+v"(mC1), [mC2] "+v"(mC2),   \
+        [mC3] "+v"(mC3), [qtot] "+v"(qtot), [row] "+v"(row_bits), [rd] "=&v"(rd), [ru] "=&v"(ru)
+#define SMART_EVERY_IN                                                                                                 \
+    SMART_ARM_CONSTS, [sp] "s"(records), [cp] "s"(codes), [quads] "s"(quads), [shift] "v"(shift), [ld] "s"(ld)
+        if constexpr (STORE && OBS)
+            asm volatile(SMART_A_EVERY_STREAM(SMART_E_STORE, SMART_E_MOMENTS) : SMART_EVERY_OUT : SMART_EVERY_IN : SMART_E_CLOBBERS);
+        else if constexpr (STORE)
+            asm volatile(SMART_A_EVERY_STREAM(SMART_E_STORE, SMART_E_NOMOM) : SMART_EVERY_OUT : SMART_EVERY_IN : SMART_E_CLOBBERS);
+        else if constexpr (OBS)
+            asm volatile(SMART_A_EVERY_STREAM("", SMART_E_MOMENTS) : SMART_EVERY_OUT : SMART_EVERY_IN : SMART_E_CLOBBERS);
+        else
+            asm volatile(SMART_A_EVERY_STREAM("", SMART_E_NOMOM) : SMART_EVERY_OUT : SMART_EVERY_IN : SMART_E_CLOBBERS);
+        row = (double *)row_bits;
+    }
+
     // ---- a whole report interval without rain excess (run_ensemble_merged) ------------------------------------
     // While no lane gets inflow the routing half of the model is linear with constant coefficients:
     //   U_j' = dec_j U_j  (j = quick, inter, groundwater),   U_riv' = (1 - a_r) U_riv + a_r (U_q + U_i + U_g)

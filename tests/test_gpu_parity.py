@@ -1197,20 +1197,23 @@ def test_randomized_raw_and_every_step_reports(eng, monkeypatch):
     assert run_interval_cases(eng, setenv, 20261005, 15, mode='every') < 1e-10
 
 
-@pytest.mark.parametrize('report, gap', [('summary', 24), ('summary', 8), ('raw', 16), ('summary', 48)])
+@pytest.mark.parametrize('report, gap', [('summary', 24), ('summary', 8), ('raw', 16), ('summary', 48), ('summary', 1),
+                                         ('raw', 1)])
 def test_pair_blocks_are_bit_identical_to_the_threaded_chunks(eng, monkeypatch, report, gap):
     """The streaming step loop as pair blocks behind computed jumps (smart_fast_arms.h: SMART_A_PAIRS_INTERVAL; the kinds
     of the steps from smart_forcing_scan's code words) against the threaded chunks of the same library
     (SMART_PAIR_BLOCKS=0 at run time): a forcing that holds every one of the 81 kinds of chunk -- calm, dry and rain
     steps in every order -- on both chunk parities, each followed by every other at least once in a shuffled order;
-    missing observations; a warm-up; sliced and not.  Every output bit for bit, and the oracle within tolerance."""
+    missing observations; a warm-up; sliced and not.  Every output bit for bit, and the oracle within tolerance.
+    gap 1: a report every step -- the stream of records with the report in the asm (SMART_A_EVERY_STREAM) against the
+    step-by-step loop with its compiled report; with and without the discharge matrix, with and without observations."""
     rng = np.random.default_rng(gap * 7 + len(report))
     kinds = [(a, b, c, d) for a in range(3) for b in range(3) for c in range(3) for d in range(3)]
     chunks = []
     for rep in range(6):                                   # six shuffles: both parities, many successions
         order = rng.permutation(len(kinds))
         chunks += [kinds[i] for i in order] + ([kinds[order[0]]] if rep % 2 else [])
-    n_chunks = len(chunks) // (gap // 4) * (gap // 4)
+    n_chunks = len(chunks) // max(gap // 4, 1) * max(gap // 4, 1)
     kind = np.array(chunks[:n_chunks]).ravel()             # 0 calm, 1 dry, 2 rain
     T = kind.size
     rain = np.where(kind == 2, rng.gamma(0.5, 1.5, T) + 1e-3, 0.0)
@@ -1224,13 +1227,24 @@ def test_pair_blocks_are_bit_identical_to_the_threaded_chunks(eng, monkeypatch, 
     obs[rng.random(n_out) < 0.2] = np.nan
     rtype = so.REPORT_SUMMARY if report == 'summary' else so.REPORT_RAW
     outs = {}
+    kernel = 'smart_fast_steps_every' if gap == 1 else ('smart_fast_steps_raw' if report == 'raw' else 'smart_fast_steps[')
     for slices in ('1', '5'):
         monkeypatch.setenv('SMART_TIME_SLICES', slices)
         for pairs in ('1', '0'):
             monkeypatch.setenv('SMART_PAIR_BLOCKS', pairs)
             r = eng.run_ensemble(params, forcing_of(rain, peva), 2.1e8, 3600.0, W, gap, obs=obs, gw_obs=0.2, report=report)
-            assert ('smart_fast_steps_raw' if report == 'raw' else 'smart_fast_steps[') in r._prepared.describe() + '['
+            assert kernel in r._prepared.describe() + '['
             outs[slices, pairs] = [x.cpu().numpy().copy() for x in (r.discharge, r.gw, r.objfn)]
+            if gap == 1:        # the other three instances of the report: no matrix, no observations, neither
+                q = eng.run_ensemble(params, forcing_of(rain, peva), 2.1e8, 3600.0, W, gap, obs=obs, gw_obs=0.2,
+                                     report=report, want_discharge=False)
+                assert bits_equal(q.objfn.cpu().numpy(), outs[slices, pairs][2]) and bits_equal(q.gw.cpu().numpy(),
+                                                                                               outs[slices, pairs][1])
+                q = eng.run_ensemble(params, forcing_of(rain, peva), 2.1e8, 3600.0, W, gap, report=report)
+                assert bits_equal(q.discharge.cpu().numpy(), outs[slices, pairs][0])
+                q = eng.run_ensemble(params, forcing_of(rain, peva), 2.1e8, 3600.0, W, gap, report=report,
+                                     want_discharge=False)
+                assert bits_equal(q.gw.cpu().numpy(), outs[slices, pairs][1])
     for key, got in outs.items():
         for a, b in zip(got, outs['1', '0']):
             assert bits_equal(a, b), key

@@ -18,9 +18,9 @@ KINDS = 'CDR'          # smart_device.h: step_kind -- 0 calm, 1 dry, 2 rain
 FIRST = {'C': 'v_cmp_lt_f64', 'D': 'v_mul_f64', 'R': 'v_mov_b64'}      # how the three arms begin
 
 
-def _stride():
+def _stride(name='SMART_P_STRIDE'):
     text = open(os.path.join(ROOT, 'smartpy_amd', 'csrc', 'smart_device.h')).read()
-    return int(re.search(r'#define SMART_P_STRIDE (\d+)', text).group(1))
+    return int(re.search(r'#define %s (\d+)' % name, text).group(1))
 
 
 def _kernel(name):
@@ -105,3 +105,38 @@ def test_a_dry_pair_is_eighteen_instructions_on_the_boundary():
     assert [x['size'] for x in body[:18]] == [8] * 18 and all(x['addr'] % 8 == 0 for x in body[:18])
     assert all(x['op'].startswith(('v_mul_f64', 'v_fma_f64', 'v_add_f64')) for x in body[:18])
     assert [x['op'] for x in body[18:20]] == ['s_add_u32', 's_setpc_b64']
+
+
+def test_every_block_of_the_every_step_stream_lies_where_its_code_word_points():
+    """SMART_A_EVERY_STREAM (a report every step): four instances in smart_fast_steps_every (matrix stored or not,
+    observations or not), each 2 x 9 blocks SMART_E_STRIDE bytes apart; every block's main path -- arm, report, arm,
+    report, loop control -- ends with the computed jump inside the block's room and requests exactly one pair of steps"""
+    stride = _stride('SMART_E_STRIDE')
+    assert stride % 64 == 0
+    insts = _kernel('smart_fast_steps_every')
+    at = {x['addr']: i for i, x in enumerate(insts)}
+    entries = [i for i, x in enumerate(insts) if x['op'] == 's_getpc_b64' and 's[78:79]' in x['args']]
+    assert len(entries) == 4
+    stores = []
+    for i in entries:
+        base = insts[i]['addr'] + 4 + int(insts[i + 1]['args'].split(',')[-1], 0)
+        assert base % 64 == 0
+        n_store = 0
+        for n in range(18):
+            names = KINDS[(n % 9) // 3] + KINDS[n % 3]
+            b = base + n * stride
+            assert b in at, 'block %d does not start on an instruction' % n
+            k = at[b]
+            if names[0] == 'R':
+                assert insts[k]['op'] == 's_nop' and insts[k]['size'] == 4
+                k += 1
+            assert insts[k]['op'].startswith(FIRST[names[0]]), (n, names, insts[k]['op'])
+            loads = sums = 0
+            while insts[k]['op'] != 's_setpc_b64':
+                assert insts[k]['addr'] < b + stride, 'block %d (%s) outgrew its %d bytes' % (n, names, stride)
+                loads += insts[k]['op'].startswith('s_load_dwordx16')
+                n_store += insts[k]['op'] == 'global_store_dwordx2'
+                k += 1
+            assert loads == 1, (n, names)
+        stores.append(n_store)
+    assert sorted(stores) == [0, 0, 36, 36]         # two of the four instances store, one value per step
