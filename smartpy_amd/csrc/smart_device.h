@@ -450,31 +450,14 @@ __device__ __forceinline__ void time_loop_arms_each(Model &m, const double2 *__r
 // intervals but -- when it ends where the catchment's forcing ends -- the last one, which the clamped loop above
 // takes (a prefetch must never read past the array).
 template <bool QUICK, bool LAST = false, class Model, class IntervalEnd>
-__device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restrict__ f, const double2 *f_asm,
-                                              const uint2 *codes, const double *obs_p, const double *dev_p, long n_iv,
-                                              long gap, bool ends_at_array_end, double &acc, IntervalEnd &&interval_end)
+__device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restrict__ f, long n_iv, long gap,
+                                              bool ends_at_array_end, double &acc, IntervalEnd &&interval_end)
 {
     const int cpi = (int)(gap / kChunk);
     long n_stream = 0;
 #if SMART_CHUNK_THREADED
     if (gap % (2 * kChunk) == 0 && n_iv > 0) // (an even number of chunks per interval: the two buffers swap roles)
         n_stream = ends_at_array_end ? n_iv - 1 : n_iv;
-#endif
-#if SMART_PAIR_BLOCKS
-    // the pair blocks (SMART_A_PAIRS_INTERVAL): the kinds of the steps come from smart_forcing_scan's code words
-    // (f itself stays what it was: a __restrict__ pointer that has been through a phi loses hipcc the scalar loads)
-    long n_paired = 0;
-    // (its jumps add a 32-bit offset to the address of block 0 without a carry: not for a code object that straddles a
-    // 4 GB line -- one launch in a few thousand at worst; that one walks the threaded chunks)
-    const unsigned pc_lo = (unsigned)__builtin_amdgcn_s_getpc();
-    const bool clear_of_4g = pc_lo > 0x00400000u && pc_lo < 0xffc00000u;
-    if constexpr (QUICK && !Model::kSplit) if (codes && n_stream > 0 && clear_of_4g) {
-        m.template stream_pairs<LAST>(f, f_asm, codes, obs_p, dev_p, n_stream, cpi / 2, acc, interval_end);
-        n_paired = n_stream;
-        n_stream = 0;
-    }
-#else
-    const long n_paired = 0;
 #endif
     if (n_stream > 0) {
         double2 cur[kChunk], nxt[kChunk];
@@ -520,7 +503,7 @@ __device__ __forceinline__ void arm_intervals(Model &m, const double2 *__restric
             interval_end();
         }
     }
-    for (long iv = n_stream + n_paired; iv < n_iv; ++iv) {
+    for (long iv = n_stream; iv < n_iv; ++iv) {
         time_loop_arms<QUICK, LAST>(m, f + iv * gap, gap, acc, [] {});
         interval_end();
     }
@@ -670,12 +653,11 @@ struct Reporter {
         }
     }
 
-    // The report of the streamed step loop (FastModel::stream_pairs), where everything around the arithmetic costs a lone
-    // wavefront an issue turn: e, w fetched ahead by the caller; the report's place in the discharge matrix a per-lane
-    // pointer that moves on by ld (begin_rows / next_row) instead of a 64-bit product per report; a missing observation
-    // told by the mark smart_obs_prepare left in its deviation (one scalar compare); and no test for the lanes beyond
-    // the batch -- they carry the batch's last sample (lane_ctx), so they store what its own lane stores, where it does.
-    // (The interval engine, 3,900 cycles an interval, gains nothing from it: same-box A/B, headline level.)
+    // The streamed step loop (FastModel::stream_stretch) reports inside its asm (smart_fast_arms.h: SMART_P_REPORT) -- what
+    // emit() does, operation for operation, with three differences of form: the report's place in the discharge matrix is
+    // this per-lane pointer, moved on by ld per report (begin_rows / next_row keep it in step when emit() reports); a
+    // missing observation is told by the mark smart_obs_prepare left in its deviation; and there is no test for the lanes
+    // beyond the batch -- they carry the batch's last sample (lane_ctx) and store what its own lane stores, where it does.
     double *row = nullptr;
     __device__ __forceinline__ void begin_rows(const KArgs &a, const LaneCtx &x, long r)
     {
@@ -685,24 +667,6 @@ struct Reporter {
     {
         if (a.discharge)
             row += a.ld;
-    }
-    __device__ __forceinline__ void emit_marked(const KArgs &a, long r, double val, double e, double w)
-    {
-        if (a.discharge)
-            *row = val;
-        if (want_obj) {
-            if (r == 0)
-                shift = val;
-            if (!is_missing_mark(w)) { // montecarlo.py:195-196
-                const double d = val - e;
-                const double u = val - shift;
-                A += d;
-                B += d * d;
-                C1 += u;
-                C2 += u * u;
-                C3 += w * u;
-            }
-        }
     }
 
     // The same with the observation e = obs[r] and w = e - mean(e) requested ahead of time by the caller
@@ -1322,14 +1286,9 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
         long k = 0, r = ra;
         (void)k;
         double acc = 0.0;
-        // end of report interval r (wave-uniform); ew: the observation of this report and its deviation from the mean
-        // when the caller has fetched them ahead (stream_pairs), nothing otherwise
-        auto report = [&](auto... ew) __attribute__((always_inline)) {
+        auto report = [&]() __attribute__((always_inline)) { // end of report interval r (wave-uniform)
             auto emit = [&](const double val) __attribute__((always_inline)) {
-                if constexpr (sizeof...(ew) == 2)
-                    rep.emit_marked(a, r, val, ew...);
-                else
-                    rep.emit(a, x, r, val);
+                rep.emit(a, x, r, val);
                 rep.next_row(a);
             };
             if constexpr (REPORT == kReportMean) {
@@ -1445,16 +1404,40 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                             run_steps(std::false_type{}, std::false_type{});
                     }
                 } else {
-                    // (the report entries through a.obs / a.ws, not through the __restrict__ arguments: see f_asm)
-                    const bool fetch = stretch == 1 && rep.want_obj;
-                    arm_intervals<Q, REPORT == kReportLast>(
-                        m, f + i0 * gap, f_asm + i0 * gap, codes_c ? codes_c + i0 * gap / kChunk : nullptr,
-                        fetch ? a.obs + x.c * a.R + i0 : nullptr,
-                        fetch ? a.ws + x.c * (kWsHead + a.R) + kWsHead + i0 : nullptr, i1 - i0, gap, i1 * gap == a.T, acc,
-                        [&](auto... ew) __attribute__((always_inline)) {
-                            if (stretch == 1)
-                                report(ew...);
-                        });
+                    long done = 0;
+#if SMART_PAIR_BLOCKS
+                    // The pair blocks (FastModel::stream_stretch: the whole stretch, reports included, in one asm): report
+                    // gaps of whole pairs of chunks, the kinds of the steps from smart_forcing_scan's code words.  The last
+                    // interval of the forcing array stays with the loop below (the asm requests two chunks ahead).  Its
+                    // jumps add a 32-bit offset to the address of block 0 without a carry: not for a code object that
+                    // straddles a 4 GB line -- that launch walks the threaded chunks.  (Observations and deviations
+                    // through a.obs / a.ws, not through the __restrict__ arguments: see f_asm.)
+                    if constexpr (Q && !Model::kSplit) {
+                        const unsigned pc_lo = (unsigned)__builtin_amdgcn_s_getpc();
+                        const long n_stream = i1 * gap == a.T ? i1 - i0 - 1 : i1 - i0;
+                        if (codes_c && gap % (2 * kChunk) == 0 && n_stream > 0 && pc_lo > 0x00400000u && pc_lo < 0xffc00000u) {
+                            const bool reporting = stretch == 1, fetch = reporting && rep.want_obj;
+                            double unused = 0.0;
+                            m.template stream_stretch<REPORT == kReportLast>(
+                                f_asm + i0 * gap, codes_c + i0 * gap / kChunk, fetch ? a.obs + x.c * a.R + i0 : nullptr,
+                                fetch ? a.ws + x.c * (kWsHead + a.R) + kWsHead + i0 : nullptr, n_stream,
+                                (int)(gap / (2 * kChunk)), reporting, a.discharge != nullptr, r == 0, inv_gap, acc, rep.A,
+                                rep.B, rep.C1, rep.C2, rep.C3, rep.shift, REPORT == kReportLast ? num_raw : q_out_total,
+                                REPORT == kReportLast ? den_raw : unused, rep.row, a.ld);
+                            if (reporting) {
+                                r += n_stream;
+                                if (Model::kSplit && r == a.R - 1)
+                                    park_state();
+                            }
+                            done = n_stream;
+                        }
+                    }
+#endif
+                    arm_intervals<Q, REPORT == kReportLast>(m, f + (i0 + done) * gap, i1 - i0 - done, gap, i1 * gap == a.T,
+                                                            acc, [&]() __attribute__((always_inline)) {
+                                                                if (stretch == 1)
+                                                                    report();
+                                                            });
                 }
             }
         };

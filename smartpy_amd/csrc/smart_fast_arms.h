@@ -361,7 +361,7 @@
 #define SMART_P_TAIL_B1                                                                                                \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
     "s_add_u32 s72, s72, 1\n\t"                                                                                        \
-    "s_cbranch_scc1 99f\n\t" SMART_P_REQUEST("s[52:67]", "s[70:71]") SMART_P_JUMP("s68")
+    "s_cbranch_scc1 95f\n\t" SMART_P_REQUEST("s[52:67]", "s[70:71]") SMART_P_JUMP("s68")
 // the nine blocks of one position: rx, px / ry, py = the forcing registers of its two steps.  A block whose first step is
 // a rain step is entered 4 bytes behind its boundary (the code word says so): the rain arm wants to start at 4 mod 8
 // (SMART_A_ALIGN8_ODD) -- and ends there (eleven 4-byte instructions on its way): behind a calm or a dry step it gets there
@@ -403,38 +403,89 @@
                                    tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                                       \
     SMART_P_BLOCK(pos, kd, SMART_A_DRY(route, p0, dry_split) SMART_A_DRY(route, p1, dry_split)                         \
                                SMART_A_DRY(route, p2, dry_split) SMART_A_DRY(route, p3, dry_split) tail)
-// the interval: %[half] = chunks / 2 (>= 1), %[fp] / %[cp] = the interval's first chunk in the forcing / the code words;
-// %[op] / %[wp] -> %[eo] / %[wo]: the observation of the interval's report and its deviation, requested here and in by
-// the first wait of the loop control
-#define SMART_A_PAIRS_INTERVAL(route, deep, calm_split, zeros, drain, rain_split, dry_split)                           \
+// The moments of a report about value `val` with observation e, deviation w (upper word whi: the missing mark): Reporter's
+// (smart_device.h: emit_marked / report_every), operation for operation
+#define SMART_R_MOMENTS(val, e, w, whi)                                                                                \
+    "s_cmp_eq_u32 " whi ", 0x7ff8dead\n\t"                                                                             \
+    "s_cbranch_scc1 50f\n\t"                                                                                           \
+    "s_nop 0\n\t"                                                                                                      \
+    "v_add_f64 %[rd], " val ", -" e "\n\t"                                                                             \
+    "v_add_f64 %[ru], " val ", -%[shift]\n\t"                                                                          \
+    "v_add_f64 %[mA], %[mA], %[rd]\n\t"                                                                                \
+    "v_fma_f64 %[mB], %[rd], %[rd], %[mB]\n\t"                                                                         \
+    "v_add_f64 %[mC1], %[mC1], %[ru]\n\t"                                                                              \
+    "v_fma_f64 %[mC2], %[ru], %[ru], %[mC2]\n\t"                                                                       \
+    "v_fma_f64 %[mC3], " w ", %[ru], %[mC3]\n\t"                                                                       \
+    "50:\n\t"
+// The report at the end of an interval, in the asm (one copy per asm, reached from the tails of the last pair's blocks):
+// nothing during the warm-up (%[rep] = 0); the value (value: the instruction that puts it into %[rv]); report 0 sets the
+// constant the moments are taken about (s85: is the next report number 0?); the discharge through the lane's row pointer;
+// the moments (e, w in s[80:83], requested when the interval began); `after`: what the run keeps of the interval.
+#define SMART_P_REPORT(value, after)                                                                                   \
+    "s_cmp_eq_u32 %[rep], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 96f\n\t" value "s_cmp_eq_u32 s85, 0\n\t"                                                           \
+    "s_cbranch_scc1 93f\n\t"                                                                                           \
+    "v_mov_b64_e64 %[shift], %[rv]\n\t"                                                                                \
+    "s_mov_b32 s85, 0\n\t"                                                                                             \
+    "93:\n\t"                                                                                                          \
+    "s_cmp_eq_u32 %[sto], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 97f\n\t"                                                                                           \
+    "global_store_dwordx2 %[row], %[rv], off\n\t"                                                                      \
+    "v_lshl_add_u64 %[row], %[ld], 3, %[row]\n\t"                                                                      \
+    "97:\n\t"                                                                                                          \
+    "s_cmp_eq_u32 %[hob], 0\n\t"                                                                                       \
+    "s_cbranch_scc1 98f\n\t" SMART_R_MOMENTS("%[rv]", "s[80:81]", "s[82:83]", "s83") "98:\n\t" after "96:\n\t"
+#define SMART_P_REPORT_MEAN                                                                                            \
+    SMART_P_REPORT("v_mul_f64 %[rv], %[acc], %[ig]\n\t", "v_add_f64 %[qtot], %[qtot], %[acc]\n\tv_mov_b64_e64 %[acc], 0\n\t")
+#define SMART_P_REPORT_LAST                                                                                            \
+    SMART_P_REPORT("v_mov_b64_e64 %[rv], %[acc]\n\t",                                                                  \
+                   "v_add_f64 %[numr], %[numr], %[qg]\n\tv_add_f64 %[denr], %[denr], %[qi]\n\t")
+// a STRETCH of %[niv] report intervals of %[half] pairs of chunks each: %[fp] / %[cp] = the first chunk in the forcing /
+// the code words, %[op] / %[wp] = the first interval's observation / deviation (anything readable without objective
+// functions).  s75 counts the intervals, s84 is the byte offset of the observation at hand.
+#define SMART_A_PAIRS_STRETCH(route, report, deep, calm_split, zeros, drain, rain_split, dry_split)                    \
     "s_getpc_b64 s[78:79]\n\t"                                                                                         \
     "90:\n\t"                                                                                                          \
     "s_add_u32 s78, s78, 91f-90b\n\t"                                                                                  \
     "s_addc_u32 s79, s79, 0\n\t"                                                                                       \
     "s_mov_b32 s77, s79\n\t"                                                                                           \
+    "s_load_dwordx16 s[36:51], %[fp], 0x0\n\t"                                                                         \
+    "s_load_dwordx2 s[68:69], %[cp], 0x0\n\t"                                                                          \
     "s_mov_b32 s73, 64\n\t"                                                                                            \
     "s_load_dwordx16 s[52:67], %[fp], s73\n\t"                                                                         \
     "s_mov_b32 s74, 8\n\t"                                                                                             \
     "s_load_dwordx2 s[70:71], %[cp], s74\n\t"                                                                          \
-    "s_load_dwordx2 %[eo], %[op], 0x0\n\t"                                                                             \
-    "s_load_dwordx2 %[wo], %[wp], 0x0\n\t"                                                                             \
-    "s_sub_u32 s72, 0, %[half]\n\t" SMART_P_JUMP("s68") ".p2align 6\n\t"                                              \
-    "91:\n\t" SMART_P_NINE("0", route, "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", SMART_P_TAIL_A0, deep, calm_split,   \
-                           zeros, drain, rain_split, dry_split)                                                        \
-        SMART_P_NINE("1", route, "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]", SMART_P_TAIL_B0, deep, calm_split, zeros,  \
-                     drain, rain_split, dry_split)                                                                     \
-            SMART_P_NINE("2", route, "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]", SMART_P_TAIL_A1, deep, calm_split,     \
-                         zeros, drain, rain_split, dry_split)                                                          \
-                SMART_P_NINE("3", route, "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]", SMART_P_TAIL_B1, deep,             \
+    "s_mov_b32 s84, 0\n\t"                                                                                             \
+    "s_load_dwordx2 s[80:81], %[op], 0x0\n\t"                                                                          \
+    "s_load_dwordx2 s[82:83], %[wp], 0x0\n\t"                                                                          \
+    "s_sub_u32 s72, 0, %[half]\n\t"                                                                                    \
+    "s_sub_u32 s75, 0, %[niv]\n\t"                                                                                     \
+    "s_mov_b32 s85, %[r0]\n\t"                                                                                         \
+    "s_waitcnt lgkmcnt(0)\n\t" SMART_P_JUMP("s68") ".p2align 6\n\t"                                                    \
+    "91:\n\t" SMART_P_NINE("0", route, "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", SMART_P_TAIL_A0, deep,          \
+                           calm_split, zeros, drain, rain_split, dry_split)                                            \
+        SMART_P_NINE("1", route, "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]", SMART_P_TAIL_B0, deep, calm_split,    \
+                     zeros, drain, rain_split, dry_split)                                                              \
+            SMART_P_NINE("2", route, "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]", SMART_P_TAIL_A1, deep,            \
+                         calm_split, zeros, drain, rain_split, dry_split)                                              \
+                SMART_P_NINE("3", route, "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]", SMART_P_TAIL_B1, deep,        \
                              calm_split, zeros, drain, rain_split, dry_split)                                          \
                     SMART_P_QUADS("4", "0", "1", route, "s[38:39]", "s[42:43]", "s[46:47]", "s[50:51]",                \
                                   SMART_P_TAIL_B0, deep, calm_split, dry_split)                                        \
                         SMART_P_QUADS("4", "2", "3", route, "s[54:55]", "s[58:59]", "s[62:63]", "s[66:67]",            \
                                       SMART_P_TAIL_B1, deep, calm_split, dry_split) ".p2align 3\n\t"                   \
-                                                                                    "99:\n\t"
+    "95:\n\t" report "s_add_u32 s75, s75, 1\n\t"                                                                       \
+    "s_cbranch_scc1 99f\n\t"                                                                                           \
+    "s_sub_u32 s72, 0, %[half]\n\t"                                                                                    \
+    "s_add_u32 s84, s84, 8\n\t"                                                                                        \
+    "s_load_dwordx2 s[80:81], %[op], s84\n\t"                                                                          \
+    "s_load_dwordx2 s[82:83], %[wp], s84\n\t" SMART_P_REQUEST("s[52:67]", "s[70:71]") SMART_P_JUMP("s68") "99:\n\t"
 #define SMART_P_CLOBBERS                                                                                               \
     "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",    \
         "s70", "s71", "s72", "s73", "s74", "s76", "s77", "s78", "s79", "vcc", "scc"
+#define SMART_S_CLOBBERS                                                                                               \
+    "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",    \
+        "s68", "s69", "s75", "s80", "s81", "s82", "s83", "s84", "s85", SMART_P_CLOBBERS
 
 // ---- a report every step (gap 1) as pair blocks with the report in the asm (round 4) ---------------------------------
 // The every-step loop (time_loop_arms_each) dispatches step by step (SMART_A_STEP: one to two taken branches a step)
@@ -449,18 +500,7 @@
 // 18 blocks, SMART_E_STRIDE bytes apart.  After a rain arm -- which ends at 4 mod 8 -- and ahead of one an s_nop: the
 // reports and the other arms on the 8-byte boundary.
 #define SMART_E_STORE "global_store_dwordx2 %[row], %[acc], off\n\tv_lshl_add_u64 %[row], %[ld], 3, %[row]\n\t"
-#define SMART_E_MOMENTS(e, w, whi)                                                                                     \
-    "s_cmp_eq_u32 " whi ", 0x7ff8dead\n\t"                                                                             \
-    "s_cbranch_scc1 50f\n\t"                                                                                           \
-    "s_nop 0\n\t"                                                                                                      \
-    "v_add_f64 %[rd], %[acc], -" e "\n\t"                                                                              \
-    "v_add_f64 %[ru], %[acc], -%[shift]\n\t"                                                                           \
-    "v_add_f64 %[mA], %[mA], %[rd]\n\t"                                                                                \
-    "v_fma_f64 %[mB], %[rd], %[rd], %[mB]\n\t"                                                                         \
-    "v_add_f64 %[mC1], %[mC1], %[ru]\n\t"                                                                              \
-    "v_fma_f64 %[mC2], %[ru], %[ru], %[mC2]\n\t"                                                                       \
-    "v_fma_f64 %[mC3], " w ", %[ru], %[mC3]\n\t"                                                                       \
-    "50:\n\t"
+#define SMART_E_MOMENTS(e, w, whi) SMART_R_MOMENTS("%[acc]", e, w, whi)
 #define SMART_E_SUM "v_add_f64 %[qtot], %[qtot], %[acc]\n\t"
 // rep(e, w, whi): the report text of a step (the caller composes it from the three pieces above)
 #define SMART_E_C_N(rep, id) SMART_P_ARM_C_N(SMART_A_ROUTE_LAST, id, "", "") rep

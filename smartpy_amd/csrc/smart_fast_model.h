@@ -933,35 +933,32 @@ struct FastModel {
         }
     }
 
-    // `n_iv` report intervals of `half` pairs of chunks each, walked pair of steps by pair of steps through the blocks of
-    // SMART_A_PAIRS_INTERVAL; interval_end() after each.  f / codes: the first interval's first chunk and its code words
-    // (smart_forcing_scan); f_asm = f through a pointer that hipcc does not take for f (smart_device.h).  QUICK waves only.  The asm requests two chunks beyond the interval it walks: the caller keeps
-    // the last interval of the forcing array away from it (arm_intervals).
-    template <bool LAST, class IntervalEnd>
-    __device__ __forceinline__ void stream_pairs(const double2 *__restrict__ f, const double2 *f_asm, const uint2 *codes,
-                                                 const double *obs_p, const double *dev_p, long n_iv, int half,
-                                                 double &acc, IntervalEnd &&interval_end)
+    // A stretch of `n_iv` report intervals of `half` pairs of chunks each, walked pair of steps by pair of steps through the
+    // blocks of SMART_A_PAIRS_STRETCH, the report at the end of every interval included (Reporter::emit_marked and what
+    // run_ensemble_merged's report() keeps, operation for operation): ONE asm, no compiled code until the stretch is over.
+    // f_asm / codes: the first interval's first chunk in the forcing (through a pointer that hipcc does not take for the
+    // __restrict__ one: smart_device.h) and its code words (smart_forcing_scan); obs_p / dev_p: the first interval's
+    // observation and deviation (null: none, or the warm-up -- reporting: false).  first_is_0: the stretch's first report
+    // is report 0, which sets the constant the moments are taken about.  sum_a / sum_b: the sum of the outflows (means;
+    // sum_b unused) or the two sums of the raw groundwater ratio (LAST).  QUICK waves only; the asm requests two chunks
+    // beyond the stretch: the caller keeps the last interval of the forcing array away from it.
+    template <bool LAST>
+    __device__ __forceinline__ void stream_stretch(const double2 *f_asm, const uint2 *codes, const double *obs_p,
+                                                   const double *dev_p, long n_iv, int half, bool reporting, bool storing,
+                                                   bool first_is_0, double inv_gap, double &acc, double &mA, double &mB,
+                                                   double &mC1, double &mC2, double &mC3, double &shift, double &sum_a,
+                                                   double &sum_b, double *&row, long ld)
     {
         // (the models with the final state vector keep the threaded chunks: two rain arms with their two extra
-        // reservoirs do not fit a 2 KB block, and 4 KB blocks put the asm's end beyond the reach of a branch)
-        static_assert(!SPLIT, "stream_pairs: the SPLIT models take the threaded chunks");
+        // reservoirs do not fit a block)
+        static_assert(!SPLIT, "stream_stretch: the SPLIT models take the threaded chunks");
         SMART_ARM_LOCALS;
-        // the chunk at hand: in and out of the asm in F0 / s68, s69 (the blocks name these registers)
-        // (constraints that name the register pair: a `register double x asm("s36")` variable pins 32 bits of it)
-        double r0 = f[0].x, p0 = f[0].y, r1 = f[1].x, p1 = f[1].y, r2 = f[2].x, p2 = f[2].y, r3 = f[3].x, p3 = f[3].y;
-        // (the code words through the constant address space: a scalar load, values that stay in SGPRs)
-        typedef const unsigned __attribute__((address_space(4))) *const_u32;
-        unsigned ca = ((const_u32)(unsigned long long)codes)[0], cb = ((const_u32)(unsigned long long)codes)[1];
-        // the observation of each interval's report and its deviation from the mean (obs_p / dev_p: the first interval's,
-        // null: no objective functions, or the warm-up) are requested by the asm as it enters the interval and handed to
-        // interval_end(e, w): left to the report itself they are two memory latencies, one behind the other, that a lone
-        // wavefront sits out at the end of every interval
-        const long o_step = obs_p ? 1 : 0;
+        const int has_obs = obs_p != nullptr;
         if (!obs_p) {
-            obs_p = reinterpret_cast<const double *>(f_asm); // (somewhere to load from; interval_end ignores the values)
+            obs_p = reinterpret_cast<const double *>(f_asm); // (somewhere to load from: n_iv doubles of the forcing)
             dev_p = obs_p;
         }
-        // (wave-uniform, but hipcc does not see it through the report's closure: a vector register is no base of a load)
+        // (wave-uniform, but hipcc does not see it through the caller's closures: a vector register is no base of a load)
         auto uniform = [](const double *p) {
             const unsigned long long u = (unsigned long long)p;
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -969,33 +966,31 @@ struct FastModel {
         };
         obs_p = uniform(obs_p);
         dev_p = uniform(dev_p);
-        double e_obs, w_obs;
-        const long f_step = 8L * half, c_step = 2L * half; // chunks per interval = 2 half; 4 steps, one code pair a chunk
-#define SMART_PAIRS_IO                                                                                                 \
-    "={s[36:37]}"(r0), "={s[38:39]}"(p0), "={s[40:41]}"(r1), "={s[42:43]}"(p1), "={s[44:45]}"(r2), "={s[46:47]}"(p2),     \
-        "={s[48:49]}"(r3), "={s[50:51]}"(p3), "={s68}"(ca), "={s69}"(cb), [eo] "=&s"(e_obs), [wo] "=&s"(w_obs)
-#define SMART_PAIRS_IN                                                                                                 \
-    [fp] "s"(f_asm), [cp] "s"(codes), [half] "s"(half), [op] "s"(obs_p), [wp] "s"(dev_p), "{s[36:37]}"(r0),            \
-        "{s[38:39]}"(p0), "{s[40:41]}"(r1), "{s[42:43]}"(p1), "{s[44:45]}"(r2), "{s[46:47]}"(p2), "{s[48:49]}"(r3),    \
-        "{s[50:51]}"(p3), "{s68}"(ca), "{s69}"(cb)
-        for (long iv = 0; iv < n_iv; ++iv) {
-            if constexpr (LAST) {
-                asm volatile(SMART_A_PAIRS_INTERVAL(SMART_A_ROUTE_LAST, "", "", "", "", "", "")
-                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_LAST, SMART_PAIRS_IO
-                             : SMART_ARM_CONSTS, SMART_PAIRS_IN
-                             : SMART_P_CLOBBERS);
-            } else {
-                asm volatile(SMART_A_PAIRS_INTERVAL(SMART_A_ROUTE, "", "", "", "", "", "")
-                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_PAIRS_IO
-                             : SMART_ARM_CONSTS, SMART_PAIRS_IN
-                             : SMART_P_CLOBBERS);
-            }
-            f_asm += f_step;
-            codes += c_step;
-            obs_p += o_step;
-            dev_p += o_step;
-            interval_end(e_obs, w_obs);
-        }
+        double rv, rd, ru;
+        unsigned long long row_bits = (unsigned long long)row;
+        // (wave-uniform all of them; readfirstlane tells hipcc)
+        const int n = __builtin_amdgcn_readfirstlane((int)n_iv), rep_i = __builtin_amdgcn_readfirstlane((int)reporting),
+                  sto_i = __builtin_amdgcn_readfirstlane((int)(storing && reporting)),
+                  hob_i = __builtin_amdgcn_readfirstlane((int)(has_obs && reporting)),
+                  r0_i = __builtin_amdgcn_readfirstlane((int)(first_is_0 && reporting));
+#define SMART_STRETCH_OUT                                                                                              \
+    [mA] "+v"(mA), [mB] "+v"(mB), [mC1] "+v"(mC1), [mC2] "+v"(mC2), [mC3] "+v"(mC3), [shift] "+v"(shift),              \
+        [row] "+v"(row_bits), [rv] "=&v"(rv), [rd] "=&v"(rd), [ru] "=&v"(ru)
+#define SMART_STRETCH_IN                                                                                               \
+    [fp] "s"(f_asm), [cp] "s"(codes), [half] "s"(half), [niv] "s"(n), [op] "s"(obs_p), [wp] "s"(dev_p),                \
+        [rep] "s"(rep_i), [sto] "s"(sto_i), [hob] "s"(hob_i), [r0] "s"(r0_i), [ig] "v"(inv_gap), [ld] "s"(ld)
+        if constexpr (LAST)
+            asm volatile(SMART_A_PAIRS_STRETCH(SMART_A_ROUTE_LAST, SMART_P_REPORT_LAST, "", "", "", "", "", "")
+                         : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_LAST, SMART_STRETCH_OUT, [numr] "+v"(sum_a),
+                           [denr] "+v"(sum_b)
+                         : SMART_ARM_CONSTS, SMART_STRETCH_IN
+                         : SMART_S_CLOBBERS);
+        else
+            asm volatile(SMART_A_PAIRS_STRETCH(SMART_A_ROUTE, SMART_P_REPORT_MEAN, "", "", "", "", "", "")
+                         : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_STRETCH_OUT, [qtot] "+v"(sum_a)
+                         : SMART_ARM_CONSTS, SMART_STRETCH_IN
+                         : SMART_S_CLOBBERS);
+        row = (double *)row_bits;
     }
 
     // `quads` x 4 steps with a report after every step, walked through the blocks of SMART_A_EVERY_STREAM: records = the
