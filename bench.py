@@ -105,14 +105,38 @@ def wet_fraction(forcing, n_warm, t_lo=0.9, t_hi=1.1):
     return float(np.mean(np.clip((t_hi - thr) / (t_hi - t_lo), 0.0, 1.0)))
 
 
+def _code_only(text):
+    """C / C++ source without its comments, runs of white space collapsed (string literals left alone)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == '\\' else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith('//', i):
+            i = text.find('\n', i)
+            i = n if i < 0 else i
+        elif text.startswith('/*', i):
+            i = text.find('*/', i + 2)
+            i = n if i < 0 else i + 2
+        else:
+            out.append(c)
+            i += 1
+    return ' '.join(''.join(out).split())
+
+
 def kernel_source_hash():
-    """sha256 over the kernel sources: a PMC summary is only quoted for the code it was measured on."""
+    """sha256 over the kernel sources, comments and white space aside: a PMC summary is only quoted for the code it was
+    measured on -- and an edit of a comment is not an edit of the code."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, 'smartpy_amd', 'csrc')
     for name in sorted(os.listdir(csrc)):
         if name.endswith(('.hip', '.h', '.cpp')):
-            with open(os.path.join(csrc, name), 'rb') as fh:
-                h.update(name.encode() + b'\0' + fh.read())
+            with open(os.path.join(csrc, name), 'r', encoding='utf-8', errors='replace') as fh:
+                h.update(name.encode() + b'\0' + _code_only(fh.read()).encode())
     return h.hexdigest()[:16]
 
 

@@ -51,7 +51,7 @@ struct KArgs {
     const double *estream = nullptr;  // [C][every_pairs(T)][8]
     const unsigned *ecodes = nullptr; // [C][every_pairs(T)]
     const uint2 *codes = nullptr; // [C][code_chunks(T)]: per chunk of four steps the two code words of the pair blocks
-                                  // (SMART_A_PAIRS_INTERVAL), from smart_forcing_scan; null: the threaded chunks
+                                  // (SMART_A_PAIRS_STRETCH), from smart_forcing_scan; null: the threaded chunks
     // run lengths a catchment's forcing is tested for: the divisors of the report gap, largest first (div[0] = gap)
     int n_div = 0;
     int div[kMaxDiv] = {};
@@ -792,7 +792,7 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
     write_results(a, x, m, rep, summary ? num / den : num_raw / den_raw, capture ? flows : nullptr);
 }
 
-// ---- code words of the pair blocks (smart_fast_arms.h: SMART_A_PAIRS_INTERVAL) ----------------------------------------
+// ---- code words of the pair blocks (smart_fast_arms.h: SMART_A_PAIRS_STRETCH) -----------------------------------------
 // Per chunk of four steps two words, one per pair of steps: the byte offset of the pair's block from block 0.  Blocks
 // lie kPairStride bytes apart, ordered by (chunk parity, pair, kind of the first step, kind of the second); kinds as the
 // arms tell them apart on the bits of the forcing: rain != +0 -> rain step (2), else PE != +0 -> dry (1), else calm (0).
@@ -1143,7 +1143,7 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
     [[maybe_unused]] const double *__restrict__ obs_c = obs_all ? obs_all + x.c * a.R : nullptr;
     [[maybe_unused]] const double *__restrict__ dev_c = ws_all ? ws_all + x.c * (kWsHead + a.R) + kWsHead : nullptr;
     [[maybe_unused]] const uint2 *codes_c = a.codes ? a.codes + x.c * code_chunks(a.T) : nullptr;
-    // the same forcing for the asm that loads it itself (stream_pairs), NOT derived from the __restrict__ argument: a
+    // the same forcing for the asm that loads it itself (stream_stretch), NOT derived from the __restrict__ argument: a
     // pointer handed to an asm has escaped, and with `f` escaped every asm of the launch might have written the forcing
     // for all hipcc knows -- its own loads of it would no longer be scalar loads
     [[maybe_unused]] const double2 *f_asm = reinterpret_cast<const double2 *>(a.forcing) + x.c * a.T;

@@ -312,25 +312,26 @@
     "s_branch 130f\n\t" SMART_A_CASC_RAIN_OOL("0") SMART_A_CASC_RAIN_OOL("1") SMART_A_CASC_RAIN_OOL("2")               \
     SMART_A_CASC_RAIN_OOL("3") "130:\n\t"
 
-// ---- a report interval of the step loop as PAIRS of steps, each pair one straight-line block (round 4) ----------------
+// ---- a stretch of report intervals of the step loop as PAIRS of steps, each pair one straight-line block (round 4) -----
 // What a lone wavefront pays for, measured (tools/microbench/lone.hip, profiles/r04_microbench_lone.txt): a vector or a
 // scalar instruction 4 cycles, a conditional branch that is NOT taken 16, a taken one 24 to 40 -- the threaded chunk's
 // dispatch (two compares, two branches not taken) costs a step as much as a dry step's nine vector instructions.
 // Here the kind of every step is worked out ONCE per launch, by smart_forcing_scan: for each chunk of four steps two
 // code words, one per pair of steps -- the byte offset of the block that holds the two arms of that pair, one behind the
 // other with no dispatch in between.  Blocks lie SMART_P_STRIDE bytes apart (2 buffers x 2 pairs x 9 patterns + 2 x 2 for
-// whole chunks of one kind; never-executed padding in between), a pair ends with  base + code word -> s_setpc_b64:  one computed jump per two steps instead of
-// four branch instructions.  The forcing is loaded by the asm itself, two chunks ahead, into two fixed register
-// buffers (the arms name their forcing by physical register; a buffer per chunk parity); the loop control (wait,
-// request, count) sits in the tail of the second pair's blocks.  What a block knows about its first step lets the
-// second drop work: a calm step behind a calm one has no demand pending (no compare, no hook), behind a dry one it
-// has (the cascade in line, unconditionally).  The arithmetic is that of the threaded chunk, operation for operation.
+// whole chunks of one kind; never-executed padding in between), a pair ends with  base + code word -> s_setpc_b64:  one
+// computed jump per two steps instead of four branch instructions.  The forcing is loaded by the asm itself, two chunks
+// ahead, into two fixed register buffers (the arms name their forcing by physical register; a buffer per chunk parity);
+// the loop control (wait, request, count) sits in the tail of the second pair's blocks, and the report at the end of an
+// interval in one block behind them all (SMART_P_REPORT): a whole stretch of intervals is ONE asm.  What a block knows
+// about its first step lets the second drop work: a calm step behind a calm one has no demand pending (no compare, no
+// hook), behind a dry one it has (the cascade in line, unconditionally).  The arithmetic is that of the threaded chunk
+// and of Reporter::emit, operation for operation.
 //   F0 = s[36:51], F1 = s[52:67]   forcing of the chunk at hand / the next one (rain, PE of step 0, 1, 2, 3)
 //   s68, s69 / s70, s71            their code words (first pair, second pair)
-//   s72 counter (pairs of chunks, counts up to zero), s73 / s74 byte offsets of the last request into forcing / codes,
-//   s[76:77] jump target, s[78:79] address of block 0
-// F0 and s68, s69 are in/out operands pinned to those registers: they carry the first chunk of the NEXT interval out
-// (requested two chunks ahead like any other, arrived by then) and back in.
+//   s72 counter (pairs of chunks of the interval, counts up to zero), s75 the same for the intervals of the stretch,
+//   s73 / s74 byte offsets of the last request into forcing / codes, s84 of the observation at hand (s[80:83]: it and
+//   its deviation), s85: is the next report number 0?, s[76:77] jump target, s[78:79] address of block 0
 #ifndef SMART_P_STRIDE
 #error "SMART_P_STRIDE comes from smart_device.h"
 #endif
@@ -404,7 +405,7 @@
     SMART_P_BLOCK(pos, kd, SMART_A_DRY(route, p0, dry_split) SMART_A_DRY(route, p1, dry_split)                         \
                                SMART_A_DRY(route, p2, dry_split) SMART_A_DRY(route, p3, dry_split) tail)
 // The moments of a report about value `val` with observation e, deviation w (upper word whi: the missing mark): Reporter's
-// (smart_device.h: emit_marked / report_every), operation for operation
+// (smart_device.h: emit / report_every), operation for operation
 #define SMART_R_MOMENTS(val, e, w, whi)                                                                                \
     "s_cmp_eq_u32 " whi ", 0x7ff8dead\n\t"                                                                             \
     "s_cbranch_scc1 50f\n\t"                                                                                           \

@@ -934,7 +934,7 @@ struct FastModel {
     }
 
     // A stretch of `n_iv` report intervals of `half` pairs of chunks each, walked pair of steps by pair of steps through the
-    // blocks of SMART_A_PAIRS_STRETCH, the report at the end of every interval included (Reporter::emit_marked and what
+    // blocks of SMART_A_PAIRS_STRETCH, the report at the end of every interval included (Reporter::emit and what
     // run_ensemble_merged's report() keeps, operation for operation): ONE asm, no compiled code until the stretch is over.
     // f_asm / codes: the first interval's first chunk in the forcing (through a pointer that hipcc does not take for the
     // __restrict__ one: smart_device.h) and its code words (smart_forcing_scan); obs_p / dev_p: the first interval's

@@ -1200,7 +1200,7 @@ def test_randomized_raw_and_every_step_reports(eng, monkeypatch):
 @pytest.mark.parametrize('report, gap', [('summary', 24), ('summary', 8), ('raw', 16), ('summary', 48), ('summary', 1),
                                          ('raw', 1)])
 def test_pair_blocks_are_bit_identical_to_the_threaded_chunks(eng, monkeypatch, report, gap):
-    """The streaming step loop as pair blocks behind computed jumps (smart_fast_arms.h: SMART_A_PAIRS_INTERVAL; the kinds
+    """The streaming step loop as pair blocks behind computed jumps (smart_fast_arms.h: SMART_A_PAIRS_STRETCH; the kinds
     of the steps from smart_forcing_scan's code words) against the threaded chunks of the same library
     (SMART_PAIR_BLOCKS=0 at run time): a forcing that holds every one of the 81 kinds of chunk -- calm, dry and rain
     steps in every order -- on both chunk parities, each followed by every other at least once in a shuffled order;

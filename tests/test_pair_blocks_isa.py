@@ -1,4 +1,4 @@
-"""The pair blocks of the streaming step loop (smart_fast_arms.h: SMART_A_PAIRS_INTERVAL), checked in the code the GPU
+"""The pair blocks of the streaming step loop (smart_fast_arms.h: SMART_A_PAIRS_STRETCH), checked in the code the GPU
 will run: smart_forcing_scan's code words are byte offsets into that code, computed from a stride and a block order
 that the asm has to honour -- a block that outgrew its room or changed its place would send a jump into the middle of
 another.  The built library is disassembled (hipcc cross-compiles here, no GPU needed) and every block looked at."""

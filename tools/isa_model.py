@@ -220,7 +220,7 @@ def steps_model(out):
             continue
         (ool_ops if isinstance(owner, str) else per_ops).setdefault(owner, []).extend(ops)
     report = ['# smart_fast_steps: the threaded chunk (smart_fast_arms.h: SMART_A_CHUNK), per arm', '',
-              '(Since the pair blocks -- SMART_A_PAIRS_INTERVAL, round 4 -- this is the path of launches without a '
+              '(Since the pair blocks -- SMART_A_PAIRS_STRETCH, round 4 -- this is the path of launches without a '
               'workspace, of report gaps that are not a multiple of eight steps and of the models with the final state '
               'vector; the flat_forcing leg walks the pair blocks: the same arms, two to a block, one computed jump per '
               'block instead of two compares and two branches per step.  Its counts are measured: '
