@@ -328,7 +328,67 @@ def steps_model(out):
                                                                                      hi['fp64']),
                '  - scalar ALU + branches %.2f .. %.2f (branches %.2f .. %.2f), scalar loads %.2f' % (
                    lo['scalar'], hi['scalar'], lo['branch'], hi['branch'], lo['smem']), '']
+    # ---- the same workload through the PAIR BLOCKS (SMART_A_PAIRS_STRETCH): the arms without their dispatch, two to a block
+    # (four for a chunk of one calm or dry kind), what a block's second arm drops because it knows the first, the tails,
+    # the report block once per interval.  Counted from the threaded chunk's pieces and the text of the macros.
+    disp = Counter({'scalar': 4, 'branch': 2, 'salu': 2})
+    core = {k: Counter(per[k, 0]) for k in ('calm', 'dry', 'rain')}
+    for k in core:
+        core[k].subtract(disp)
+    pt = Counter()
+    k_of = ('calm', 'dry', 'rain')
+    for t in range(n_steps):
+        for c in ('VALU', 'fp64', 'scalar', 'branch'):
+            pt[c] += core[k_of[kind[t]]][c] * n_waves
+    for c in ('VALU', 'fp64', 'scalar', 'branch'):
+        pt[c] -= rain_soil[c] * dry_rain
+    for c in ('VALU', 'fp64'):
+        pt[c] -= fill_tail[c] * n_absorbed
+    n_quads = n_second_c = n_second_r = n_cr_after_d = 0
+    for ch in range(n_chunks):
+        k4 = kind[4 * ch:4 * ch + 4]
+        quad = k4[0] != 2 and (k4 == k4[0]).all()
+        n_quads += quad
+        firsts = (0,) if quad else (0, 2)
+        for j in range(1, 4):
+            if j in firsts:
+                continue
+            prev, cur = k4[j - 1], k4[j]
+            if cur == 0 and prev != 2:
+                n_second_c += 1          # no pending test, no hook: - v_cmp, - s_cbranch
+            if cur == 2 and prev != 2:
+                n_second_r += 1          # - v_cmp, - s_and, - s_cbranch
+            if cur != 1 and prev == 1:
+                n_cr_after_d += 1        # the cascade in line: no way out and back (2 branches), + 1 s_nop
+    pt['VALU'] -= (n_second_c + n_second_r) * n_waves
+    pt['scalar'] -= (n_second_c + 2 * n_second_r + 2 * n_cr_after_d) * n_waves
+    pt['branch'] -= (n_second_c + n_second_r + 2 * n_cr_after_d) * n_waves
+    # tails: first pair 2 (add, jump); second pair 6 + the interval test of every other chunk (2 / 2); 2 scalar loads a chunk
+    pt['scalar'] += ((n_chunks - n_quads) * 2 + n_chunks * 6 + n_chunks) * n_waves
+    pt['branch'] += ((n_chunks - n_quads) + n_chunks + n_chunks // 2) * n_waves
+    pt['smem'] = 2 * n_chunks * n_waves
+    # the report block: 4 tests, value, store + row, moments (test, 7), sum, reset; then interval counter, 2 requests, jump
+    n_iv = n_steps // 24
+    pt['VALU'] += 12 * n_iv * n_waves
+    pt['fp64'] += 9 * n_iv * n_waves
+    pt['scalar'] += 24 * n_iv * n_waves
+    pt['branch'] += 8 * n_iv * n_waves
+    plo = {c: (pt[c] + first[c] * n_casc) / ws for c in pt}
+    phi = {c: (pt[c] + cascade[c] * n_casc) / ws for c in pt}
+    report += ['## the same leg through the pair blocks (SMART_A_PAIRS_STRETCH)', '',
+               '- chunks of four calm or four dry steps (one block, one jump): %.3f; second arms that know a calm or dry '
+               'first arm: calm %.3f, rain %.3f per chunk; cascades taken in line behind a dry arm: %.3f per chunk' % (
+                   n_quads / n_chunks, n_second_c / n_chunks, n_second_r / n_chunks, n_cr_after_d / n_chunks),
+               '- expected per wave-step, cascades ending behind the top layer .. walking all six layers:',
+               '  - vector instructions %.2f .. %.2f (fp64 arithmetic %.2f .. %.2f)' % (plo['VALU'], phi['VALU'], plo['fp64'],
+                                                                                     phi['fp64']),
+               '  - scalar ALU + branches %.2f .. %.2f (branches %.2f .. %.2f), scalar loads %.2f' % (
+                   plo['scalar'], phi['scalar'], plo['branch'], phi['branch'], plo['smem']),
+               '  (an estimate from the macros\' text, not a census of the binary: hand-over, slice entry and the launch\'s '
+               'prologue are not in it, and s_setpc_b64 -- 0.57 per wave-step -- is counted with the branches here, which '
+               'SQ_INSTS_BRANCH may not do; measured: profiles/r04_flat_forcing.md)', '']
     result = {'kernel': 'smart_fast_steps', 'wave_steps': ws, 'per_wave_step_low': lo, 'per_wave_step_high': hi,
+              'pair_blocks_per_wave_step_low': plo, 'pair_blocks_per_wave_step_high': phi,
               'fp64_share_of_valu': [lo['fp64'] / lo['VALU'], hi['fp64'] / hi['VALU']],
               'arms': {'%s%d' % k: dict(v) for k, v in per.items()}, 'cascade': dict(cascade), 'glue_two_chunks': dict(glue),
               'fill_below_the_top_layer': dict(fill_tail), 'fill_absorbed_share': paths['absorbed_by_the_top_layer']}
