@@ -519,7 +519,7 @@ static int plan_time_slices(const SmartEnsemble *e, int n_simd, int *per_simd, d
     // samples, 64 x 1e4) and halve the hand-over traffic, which is all the HBM traffic of a launch that stores no
     // discharge matrix (6.2 GB -> 3 GB per launch at 1e6 samples)
     // (below that, 24: level with 16 on the interval engine, 1 % ahead on the run engine and on the step loop since
-    // its pair blocks made a slice cheaper -- tools/gpu_slices_flat.sh, gpu_slices_headline.sh)
+    // its pair blocks made a slice cheaper -- tools/gpu_round.sh slices-flat, gpu_round.sh slices-headline)
     const long want = blocks >= 10L * n_simd ? 8 : 24;
     return (int)(n_all / 64 < want ? n_all / 64 : want);
 }
