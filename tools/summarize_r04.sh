@@ -20,6 +20,9 @@ cp gpurun_out/r04_recip_bits.txt profiles/
 for c in "" _c2 _c4 _c5 _c4shard; do grep '^{' gpurun_out/bench_r04$c.log > profiles/r04_bench_${c#_}.jsonl; done
 mv profiles/r04_bench_.jsonl profiles/r04_bench_config3.jsonl
 for k in steps intervals steps_every intervals_raw; do python tools/isa_report.py smart_fast_$k profiles/r04_isa_$k --hot > /dev/null; done
+# (the listings of the two kernels with four instances of their loop each run to 1.5 MB of text: their block tables stay,
+# the text is one command away -- python tools/isa_report.py smart_fast_steps_every /tmp/every --hot)
+rm -f profiles/r04_isa_steps_every.s profiles/r04_isa_intervals_raw.s
 python tools/kernel_resources.py > profiles/r04_kernel_resources.txt 2>/dev/null
 for t in config3 flat_forcing flat_forcing_1e6 runs_of_6 raw_gap24 raw_gap24_flat gap1 config2 config4_1gpu config4_shard config5_1gpu; do
   echo "== $t"; grep -A4 "clock held and issue" profiles/r04_$t.md | tail -2; grep "timed steps\|traffic (corrected)" profiles/r04_$t.md; done
