@@ -405,7 +405,7 @@ static size_t codes_bytes(const SmartEnsemble *e)
     if (e->math_mode == SMART_MATH_FAST && merged_report(e) == kReportEvery)
         return ((size_t)e->n_catchments * (size_t)every_pairs(e->n_steps) * (8 * sizeof(double) + sizeof(unsigned)) + 255) /
                256 * 256;
-    if (e->math_mode != SMART_MATH_FAST || e->report_gap % (2 * kChunk) != 0)
+    if (e->math_mode != SMART_MATH_FAST || e->report_gap % kChunk != 0)
         return 0;
     const int merged = merged_report(e);
     if (merged != kReportMean && merged != kReportLast)

@@ -1414,16 +1414,26 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                     // through a.obs / a.ws, not through the __restrict__ arguments: see f_asm.)
                     if constexpr (Q && !Model::kSplit) {
                         const unsigned pc_lo = (unsigned)__builtin_amdgcn_s_getpc();
-                        const long n_stream = i1 * gap == a.T ? i1 - i0 - 1 : i1 - i0;
-                        if (codes_c && gap % (2 * kChunk) == 0 && n_stream > 0 && pc_lo > 0x00400000u && pc_lo < 0xffc00000u) {
+                        // whole intervals whose last chunk has two chunks of the array behind it (the asm's requests)
+                        const long cpi = gap / kChunk, room = gap % kChunk == 0 ? (a.T / kChunk - 2) / cpi - i0 : 0;
+                        const long n_stream = room < i1 - i0 ? room : i1 - i0;
+                        if (codes_c && n_stream > 0 && pc_lo > 0x00400000u && pc_lo < 0xffc00000u) {
                             const bool reporting = stretch == 1, fetch = reporting && rep.want_obj;
                             double unused = 0.0;
-                            m.template stream_stretch<REPORT == kReportLast>(
-                                f_asm + i0 * gap, codes_c + i0 * gap / kChunk, fetch ? a.obs + x.c * a.R + i0 : nullptr,
-                                fetch ? a.ws + x.c * (kWsHead + a.R) + kWsHead + i0 : nullptr, n_stream,
-                                (int)(gap / (2 * kChunk)), reporting, a.discharge != nullptr, r == 0, inv_gap, acc, rep.A,
-                                rep.B, rep.C1, rep.C2, rep.C3, rep.shift, REPORT == kReportLast ? num_raw : q_out_total,
-                                REPORT == kReportLast ? den_raw : unused, rep.row, a.ld);
+                            auto go = [&](auto odd_tag) __attribute__((always_inline)) {
+                                constexpr bool ODD = decltype(odd_tag)::value;
+                                m.template stream_stretch<REPORT == kReportLast, ODD>(
+                                    f_asm + i0 * gap, codes_c + i0 * cpi, fetch ? a.obs + x.c * a.R + i0 : nullptr,
+                                    fetch ? a.ws + x.c * (kWsHead + a.R) + kWsHead + i0 : nullptr, n_stream,
+                                    (int)(ODD ? cpi : cpi / 2), ((i0 * cpi) & 1) != 0, reporting, a.discharge != nullptr,
+                                    r == 0, inv_gap, acc, rep.A, rep.B, rep.C1, rep.C2, rep.C3, rep.shift,
+                                    REPORT == kReportLast ? num_raw : q_out_total,
+                                    REPORT == kReportLast ? den_raw : unused, rep.row, a.ld);
+                            };
+                            if (cpi & 1) // (gaps of an odd number of chunks -- 4, 12, 20 steps ...: the form that counts
+                                go(std::true_type{}); // chunks in both buffers' tails)
+                            else
+                                go(std::false_type{});
                             if (reporting) {
                                 r += n_stream;
                                 if (Model::kSplit && r == a.R - 1)

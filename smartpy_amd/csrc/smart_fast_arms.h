@@ -441,46 +441,71 @@
 #define SMART_P_REPORT_LAST                                                                                            \
     SMART_P_REPORT("v_mov_b64_e64 %[rv], %[acc]\n\t",                                                                  \
                    "v_add_f64 %[numr], %[numr], %[qg]\n\tv_add_f64 %[denr], %[denr], %[qi]\n\t")
-// a STRETCH of %[niv] report intervals of %[half] pairs of chunks each: %[fp] / %[cp] = the first chunk in the forcing /
+// a STRETCH of %[niv] report intervals of %[half] pairs of chunks (EVEN) / chunks (ODD) each: %[fp] / %[cp] = the first chunk in the forcing /
 // the code words, %[op] / %[wp] = the first interval's observation / deviation (anything readable without objective
 // functions).  s75 counts the intervals, s84 is the byte offset of the observation at hand.
-#define SMART_A_PAIRS_STRETCH(route, report, deep, calm_split, zeros, drain, rain_split, dry_split)                    \
-    "s_getpc_b64 s[78:79]\n\t"                                                                                         \
-    "90:\n\t"                                                                                                          \
-    "s_add_u32 s78, s78, 91f-90b\n\t"                                                                                  \
-    "s_addc_u32 s79, s79, 0\n\t"                                                                                       \
-    "s_mov_b32 s77, s79\n\t"                                                                                           \
-    "s_load_dwordx16 s[36:51], %[fp], 0x0\n\t"                                                                         \
-    "s_load_dwordx2 s[68:69], %[cp], 0x0\n\t"                                                                          \
+// (Two forms.  EVEN: intervals of an even number of chunks -- gaps that are multiples of eight steps: the interval ends in
+// buffer 1, only its tails count, in pairs of chunks.  ODD: any whole number of chunks -- multiples of four: both
+// buffers' tails count chunks, there is a report block behind each, and a stretch may start in either buffer: %[par].)
+#define SMART_P_LOADS(fa, ca, fb, cb)                                                                                  \
+    "s_load_dwordx16 " fa ", %[fp], 0x0\n\t"                                                                           \
+    "s_load_dwordx2 " ca ", %[cp], 0x0\n\t"                                                                            \
     "s_mov_b32 s73, 64\n\t"                                                                                            \
-    "s_load_dwordx16 s[52:67], %[fp], s73\n\t"                                                                         \
+    "s_load_dwordx16 " fb ", %[fp], s73\n\t"                                                                           \
     "s_mov_b32 s74, 8\n\t"                                                                                             \
-    "s_load_dwordx2 s[70:71], %[cp], s74\n\t"                                                                          \
+    "s_load_dwordx2 " cb ", %[cp], s74\n\t"                                                                            \
     "s_mov_b32 s84, 0\n\t"                                                                                             \
     "s_load_dwordx2 s[80:81], %[op], 0x0\n\t"                                                                          \
     "s_load_dwordx2 s[82:83], %[wp], 0x0\n\t"                                                                          \
     "s_sub_u32 s72, 0, %[half]\n\t"                                                                                    \
     "s_sub_u32 s75, 0, %[niv]\n\t"                                                                                     \
     "s_mov_b32 s85, %[r0]\n\t"                                                                                         \
-    "s_waitcnt lgkmcnt(0)\n\t" SMART_P_JUMP("s68") ".p2align 6\n\t"                                                    \
-    "91:\n\t" SMART_P_NINE("0", route, "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", SMART_P_TAIL_A0, deep,          \
-                           calm_split, zeros, drain, rain_split, dry_split)                                            \
-        SMART_P_NINE("1", route, "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]", SMART_P_TAIL_B0, deep, calm_split,    \
-                     zeros, drain, rain_split, dry_split)                                                              \
-            SMART_P_NINE("2", route, "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]", SMART_P_TAIL_A1, deep,            \
-                         calm_split, zeros, drain, rain_split, dry_split)                                              \
-                SMART_P_NINE("3", route, "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]", SMART_P_TAIL_B1, deep,        \
-                             calm_split, zeros, drain, rain_split, dry_split)                                          \
-                    SMART_P_QUADS("4", "0", "1", route, "s[38:39]", "s[42:43]", "s[46:47]", "s[50:51]",                \
-                                  SMART_P_TAIL_B0, deep, calm_split, dry_split)                                        \
-                        SMART_P_QUADS("4", "2", "3", route, "s[54:55]", "s[58:59]", "s[62:63]", "s[66:67]",            \
-                                      SMART_P_TAIL_B1, deep, calm_split, dry_split) ".p2align 3\n\t"                   \
-    "95:\n\t" report "s_add_u32 s75, s75, 1\n\t"                                                                       \
+    "s_waitcnt lgkmcnt(0)\n\t"
+#define SMART_P_ENTRY_EVEN SMART_P_LOADS("s[36:51]", "s[68:69]", "s[52:67]", "s[70:71]") SMART_P_JUMP("s68")
+#define SMART_P_ENTRY_ODD                                                                                              \
+    "s_cmp_eq_u32 %[par], 0\n\t"                                                                                       \
+    "s_cbranch_scc0 88f\n\t" SMART_P_ENTRY_EVEN                                                                        \
+    "88:\n\t" SMART_P_LOADS("s[52:67]", "s[70:71]", "s[36:51]", "s[68:69]") SMART_P_JUMP("s70")
+#define SMART_P_TAIL_B0_ODD                                                                                            \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                         \
+    "s_add_u32 s72, s72, 1\n\t"                                                                                        \
+    "s_cbranch_scc1 94f\n\t" SMART_P_REQUEST("s[36:51]", "s[68:69]") SMART_P_JUMP("s70")
+// what follows the report: the stretch over -> out; else the next interval's count, its observation, the request the
+// tail did not make, on
+#define SMART_P_NEXT_INTERVAL(f, c, code)                                                                              \
+    "s_add_u32 s75, s75, 1\n\t"                                                                                        \
     "s_cbranch_scc1 99f\n\t"                                                                                           \
     "s_sub_u32 s72, 0, %[half]\n\t"                                                                                    \
     "s_add_u32 s84, s84, 8\n\t"                                                                                        \
     "s_load_dwordx2 s[80:81], %[op], s84\n\t"                                                                          \
-    "s_load_dwordx2 s[82:83], %[wp], s84\n\t" SMART_P_REQUEST("s[52:67]", "s[70:71]") SMART_P_JUMP("s68") "99:\n\t"
+    "s_load_dwordx2 s[82:83], %[wp], s84\n\t" SMART_P_REQUEST(f, c) SMART_P_JUMP(code)
+#define SMART_P_REPORT94(report) "94:\n\t" report SMART_P_NEXT_INTERVAL("s[36:51]", "s[68:69]", "s70")
+#define SMART_A_PAIRS_STRETCH_X(route, report, entry, tail_b0, block94, deep, calm_split, zeros, drain, rain_split,    \
+                                dry_split)                                                                             \
+    "s_getpc_b64 s[78:79]\n\t"                                                                                         \
+    "90:\n\t"                                                                                                          \
+    "s_add_u32 s78, s78, 91f-90b\n\t"                                                                                  \
+    "s_addc_u32 s79, s79, 0\n\t"                                                                                       \
+    "s_mov_b32 s77, s79\n\t" entry ".p2align 6\n\t"                                                                    \
+    "91:\n\t" SMART_P_NINE("0", route, "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", SMART_P_TAIL_A0, deep,          \
+                           calm_split, zeros, drain, rain_split, dry_split)                                            \
+        SMART_P_NINE("1", route, "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]", tail_b0, deep, calm_split, zeros,     \
+                     drain, rain_split, dry_split)                                                                     \
+            SMART_P_NINE("2", route, "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]", SMART_P_TAIL_A1, deep,            \
+                         calm_split, zeros, drain, rain_split, dry_split)                                              \
+                SMART_P_NINE("3", route, "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]", SMART_P_TAIL_B1, deep,        \
+                             calm_split, zeros, drain, rain_split, dry_split)                                          \
+                    SMART_P_QUADS("4", "0", "1", route, "s[38:39]", "s[42:43]", "s[46:47]", "s[50:51]", tail_b0, deep, \
+                                  calm_split, dry_split)                                                               \
+                        SMART_P_QUADS("4", "2", "3", route, "s[54:55]", "s[58:59]", "s[62:63]", "s[66:67]",            \
+                                      SMART_P_TAIL_B1, deep, calm_split, dry_split) ".p2align 3\n\t" block94             \
+    "95:\n\t" report SMART_P_NEXT_INTERVAL("s[52:67]", "s[70:71]", "s68") "99:\n\t"
+#define SMART_A_PAIRS_STRETCH(route, report, deep, calm_split, zeros, drain, rain_split, dry_split)                    \
+    SMART_A_PAIRS_STRETCH_X(route, report, SMART_P_ENTRY_EVEN, SMART_P_TAIL_B0, "", deep, calm_split, zeros, drain,    \
+                            rain_split, dry_split)
+#define SMART_A_PAIRS_STRETCH_ODD(route, report, deep, calm_split, zeros, drain, rain_split, dry_split)                \
+    SMART_A_PAIRS_STRETCH_X(route, report, SMART_P_ENTRY_ODD, SMART_P_TAIL_B0_ODD, SMART_P_REPORT94(report), deep,     \
+                            calm_split, zeros, drain, rain_split, dry_split)
 #define SMART_P_CLOBBERS                                                                                               \
     "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67",    \
         "s70", "s71", "s72", "s73", "s74", "s76", "s77", "s78", "s79", "vcc", "scc"

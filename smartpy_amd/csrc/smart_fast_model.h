@@ -942,9 +942,12 @@ struct FastModel {
     // is report 0, which sets the constant the moments are taken about.  sum_a / sum_b: the sum of the outflows (means;
     // sum_b unused) or the two sums of the raw groundwater ratio (LAST).  QUICK waves only; the asm requests two chunks
     // beyond the stretch: the caller keeps the last interval of the forcing array away from it.
-    template <bool LAST>
+    // ODD: intervals of any whole number of chunks (half = that number; the stretch may start in either register buffer:
+    // first_chunk_odd); otherwise an even number (half = half of it).
+    template <bool LAST, bool ODD = false>
     __device__ __forceinline__ void stream_stretch(const double2 *f_asm, const uint2 *codes, const double *obs_p,
-                                                   const double *dev_p, long n_iv, int half, bool reporting, bool storing,
+                                                   const double *dev_p, long n_iv, int half, bool first_chunk_odd,
+                                                   bool reporting, bool storing,
                                                    bool first_is_0, double inv_gap, double &acc, double &mA, double &mB,
                                                    double &mC1, double &mC2, double &mC3, double &shift, double &sum_a,
                                                    double &sum_b, double *&row, long ld)
@@ -972,24 +975,32 @@ struct FastModel {
         const int n = __builtin_amdgcn_readfirstlane((int)n_iv), rep_i = __builtin_amdgcn_readfirstlane((int)reporting),
                   sto_i = __builtin_amdgcn_readfirstlane((int)(storing && reporting)),
                   hob_i = __builtin_amdgcn_readfirstlane((int)(has_obs && reporting)),
-                  r0_i = __builtin_amdgcn_readfirstlane((int)(first_is_0 && reporting));
+                  r0_i = __builtin_amdgcn_readfirstlane((int)(first_is_0 && reporting)),
+                  par_i = __builtin_amdgcn_readfirstlane((int)(ODD && first_chunk_odd));
 #define SMART_STRETCH_OUT                                                                                              \
     [mA] "+v"(mA), [mB] "+v"(mB), [mC1] "+v"(mC1), [mC2] "+v"(mC2), [mC3] "+v"(mC3), [shift] "+v"(shift),              \
         [row] "+v"(row_bits), [rv] "=&v"(rv), [rd] "=&v"(rd), [ru] "=&v"(ru)
 #define SMART_STRETCH_IN                                                                                               \
     [fp] "s"(f_asm), [cp] "s"(codes), [half] "s"(half), [niv] "s"(n), [op] "s"(obs_p), [wp] "s"(dev_p),                \
-        [rep] "s"(rep_i), [sto] "s"(sto_i), [hob] "s"(hob_i), [r0] "s"(r0_i), [ig] "v"(inv_gap), [ld] "s"(ld)
-        if constexpr (LAST)
-            asm volatile(SMART_A_PAIRS_STRETCH(SMART_A_ROUTE_LAST, SMART_P_REPORT_LAST, "", "", "", "", "", "")
-                         : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_LAST, SMART_STRETCH_OUT, [numr] "+v"(sum_a),
-                           [denr] "+v"(sum_b)
-                         : SMART_ARM_CONSTS, SMART_STRETCH_IN
-                         : SMART_S_CLOBBERS);
-        else
-            asm volatile(SMART_A_PAIRS_STRETCH(SMART_A_ROUTE, SMART_P_REPORT_MEAN, "", "", "", "", "", "")
-                         : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_STRETCH_OUT, [qtot] "+v"(sum_a)
-                         : SMART_ARM_CONSTS, SMART_STRETCH_IN
-                         : SMART_S_CLOBBERS);
+        [rep] "s"(rep_i), [sto] "s"(sto_i), [hob] "s"(hob_i), [r0] "s"(r0_i), [par] "s"(par_i), [ig] "v"(inv_gap),     \
+        [ld] "s"(ld)
+#define SMART_STRETCH_ASM(STRETCH)                                                                                     \
+    if constexpr (LAST)                                                                                                \
+        asm volatile(STRETCH(SMART_A_ROUTE_LAST, SMART_P_REPORT_LAST, "", "", "", "", "", "")                          \
+                     : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_LAST, SMART_STRETCH_OUT, [numr] "+v"(sum_a),       \
+                       [denr] "+v"(sum_b)                                                                              \
+                     : SMART_ARM_CONSTS, SMART_STRETCH_IN                                                              \
+                     : SMART_S_CLOBBERS);                                                                              \
+    else                                                                                                               \
+        asm volatile(STRETCH(SMART_A_ROUTE, SMART_P_REPORT_MEAN, "", "", "", "", "", "")                               \
+                     : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_STRETCH_OUT, [qtot] "+v"(sum_a)                        \
+                     : SMART_ARM_CONSTS, SMART_STRETCH_IN                                                              \
+                     : SMART_S_CLOBBERS)
+        if constexpr (ODD) {
+            SMART_STRETCH_ASM(SMART_A_PAIRS_STRETCH_ODD);
+        } else {
+            SMART_STRETCH_ASM(SMART_A_PAIRS_STRETCH);
+        }
         row = (double *)row_bits;
     }
 

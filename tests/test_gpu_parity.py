@@ -1198,14 +1198,15 @@ def test_randomized_raw_and_every_step_reports(eng, monkeypatch):
 
 
 @pytest.mark.parametrize('report, gap', [('summary', 24), ('summary', 8), ('raw', 16), ('summary', 48), ('summary', 1),
-                                         ('raw', 1)])
+                                         ('raw', 1), ('summary', 4), ('summary', 12), ('raw', 20), ('raw', 4)])
 def test_pair_blocks_are_bit_identical_to_the_threaded_chunks(eng, monkeypatch, report, gap):
     """The streaming step loop as pair blocks behind computed jumps (smart_fast_arms.h: SMART_A_PAIRS_STRETCH; the kinds
     of the steps from smart_forcing_scan's code words) against the threaded chunks of the same library
     (SMART_PAIR_BLOCKS=0 at run time): a forcing that holds every one of the 81 kinds of chunk -- calm, dry and rain
     steps in every order -- on both chunk parities, each followed by every other at least once in a shuffled order;
     missing observations; a warm-up; sliced and not.  Every output bit for bit, and the oracle within tolerance.
-    gap 1: a report every step -- the stream of records with the report in the asm (SMART_A_EVERY_STREAM) against the
+    gaps 4, 12, 20: an odd number of chunks per interval -- the second form of the stretch asm (both buffers' tails count,
+    a stretch may start in either buffer: five slices of such a run do).  gap 1: a report every step -- the stream of records with the report in the asm (SMART_A_EVERY_STREAM) against the
     step-by-step loop with its compiled report; with and without the discharge matrix, with and without observations."""
     rng = np.random.default_rng(gap * 7 + len(report))
     kinds = [(a, b, c, d) for a in range(3) for b in range(3) for c in range(3) for d in range(3)]

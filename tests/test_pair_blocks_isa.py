@@ -41,17 +41,25 @@ def test_every_pair_block_lies_where_the_code_words_point(kernel):
     insts = _kernel(kernel)
     at = {x['addr']: i for i, x in enumerate(insts)}
     entries = [i for i, x in enumerate(insts) if x['op'] == 's_getpc_b64' and 's[78:79]' in x['args']]
-    assert len(entries) == 1, 'one instance of the interval asm per kernel'
-    i = entries[0]
+    assert len(entries) == 2, 'two instances of the stretch asm per kernel: even / any number of chunks per interval'
+    for i in entries:
+        _check_instance(insts, at, i, stride)
+
+
+def _check_instance(insts, at, i, stride):
     assert insts[i + 1]['op'] == 's_add_u32' and insts[i + 1]['args'].startswith('s78, s78,')
     base = insts[i]['addr'] + 4 + int(insts[i + 1]['args'].split(',')[-1], 0)
     assert base % 64 == 0
-    # the entry ends with the jump to the first block, nothing falls into the blocks
+    # the entry (the second form has two: a stretch may start in either buffer) ends with the jump to the first block,
+    # nothing falls into the blocks
     j = i
-    while insts[j]['op'] != 's_setpc_b64':
-        assert insts[j]['cls'] != 'branch' or insts[j]['op'] == 's_setpc_b64'
+    while insts[j]['addr'] < base:
+        last = insts[j]
         j += 1
-    assert insts[j]['addr'] < base
+    while last['op'] == 's_nop':
+        j -= 1
+        last = insts[j - 1]
+    assert last['op'] == 's_setpc_b64'
 
     def block(n, names, tail_loads):
         b = base + n * stride
