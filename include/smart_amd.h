@@ -165,8 +165,8 @@ int smart_check_ensemble(const SmartEnsemble *e);
 /* Bytes of device scratch the call wants in e->workspace for these sizes and outputs (pointers are not read):
  * a header (status word, counters, per-catchment forcing flags), the observation statistics if e->objfn is set,
  * plus -- on a machine with a HIP device -- the hand-over buffer of the time-sliced launch the library would
- * choose, plus 8 bytes per four time steps and catchment for fast summary / raw runs whose report gap is a multiple
- * of four steps (the kinds of the steps, worked out once per launch).  The library allocates nothing itself: the caller owns every buffer, which also lets the call be captured
+ * choose, plus, for fast summary / raw runs over whole report intervals, 8 bytes per four time steps and catchment
+ * (the kinds of the steps, worked out once per launch; 68 bytes per two steps where the gap is no multiple of four).  The library allocates nothing itself: the caller owns every buffer, which also lets the call be captured
  * into a HIP graph.  A launch without a workspace runs unsliced and reports no status. */
 int64_t smart_workspace_bytes(const SmartEnsemble *e);
 

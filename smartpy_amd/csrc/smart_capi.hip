@@ -223,14 +223,15 @@ __global__ void smart_forcing_scan(KArgs a, const double2 *__restrict__ forcing)
             double r[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             unsigned code = 0;
             if (2 * p + 1 < a.T) {
-                for (int j = 0; j < 2; ++j) {
-                    const long t = 2 * p + j;
+                for (int j = 0; j < 2; ++j) { // the report that step t ends: number (t + 1) / gap - 1, if any
+                    const long t = 2 * p + j, rr = (t + 1) % a.gap == 0 ? (t + 1) / a.gap - 1 : -1;
                     r[4 * j] = f[t].x;
                     r[4 * j + 1] = f[t].y;
-                    r[4 * j + 2] = obs && dev && t < a.R ? obs[t] : 0.0;
-                    r[4 * j + 3] = obs && dev && t < a.R ? dev[t] : 0.0;
+                    r[4 * j + 2] = obs && dev && rr >= 0 && rr < a.R ? obs[rr] : 0.0;
+                    r[4 * j + 3] = obs && dev && rr >= 0 && rr < a.R ? dev[rr] : 0.0;
                 }
-                code = every_code(p, step_kind(f[2 * p]), step_kind(f[2 * p + 1]));
+                code = a.gap == 1 ? every_code(p, step_kind(f[2 * p]), step_kind(f[2 * p + 1]))
+                                  : gap_code(p, a.gap, step_kind(f[2 * p]), step_kind(f[2 * p + 1]));
             }
             for (int j = 0; j < 8; ++j)
                 rec[p * 8 + j] = r[j];
@@ -398,11 +399,19 @@ static size_t slices_need(const SmartEnsemble *e)
     return d && plan_time_slices(e, d->n_simd, &per_simd, &load) > 1 ? slice_bytes(e->n_samples, e->n_catchments) : 0;
 }
 
+// the stream of records (rain, PE, observation, deviation per step) instead of the pair blocks' code words: a report every
+// step, and the summary / raw reports whose gap is not a whole number of chunks
+static bool uses_records(const SmartEnsemble *e)
+{
+    const int merged = merged_report(e);
+    return merged == kReportEvery || ((merged == kReportMean || merged == kReportLast) && e->report_gap % kChunk != 0);
+}
+
 // the code words of the pair blocks: for the calls whose regular rows may take the streaming step loop; for a report every
 // step (gap 1, where there are no pair blocks of that kind) the stream of records and its code words instead
 static size_t codes_bytes(const SmartEnsemble *e)
 {
-    if (e->math_mode == SMART_MATH_FAST && merged_report(e) == kReportEvery)
+    if (e->math_mode == SMART_MATH_FAST && uses_records(e))
         return ((size_t)e->n_catchments * (size_t)every_pairs(e->n_steps) * (8 * sizeof(double) + sizeof(unsigned)) + 255) /
                256 * 256;
     if (e->math_mode != SMART_MATH_FAST || e->report_gap % kChunk != 0)
@@ -615,7 +624,7 @@ static void set_codes(const SmartEnsemble *e, KArgs *a, const Workspace &w)
     a->codes = nullptr, a->estream = nullptr, a->ecodes = nullptr;
     if (!w.codes || !pair_blocks_wanted())
         return;
-    if (merged_report(e) == kReportEvery) {
+    if (uses_records(e)) {
         a->estream = (const double *)w.codes;
         a->ecodes = (const unsigned *)(a->estream + (size_t)e->n_catchments * (size_t)every_pairs(e->n_steps) * 8);
     } else {

@@ -814,6 +814,13 @@ __device__ __forceinline__ unsigned every_code(long pair, unsigned k0, unsigned 
 {
     return (unsigned)(((pair & 1) * 9 + k0 * 3 + k1) * kEveryStride + (k0 == 2 ? 4 : 0));
 }
+// ... for report gaps that are not whole chunks (SMART_A_GAP_STREAM): three variants of every block -- no report in the
+// pair, the report behind its first arm, behind its second
+__device__ __forceinline__ unsigned gap_code(long pair, long gap, unsigned k0, unsigned k1)
+{
+    const unsigned v = (2 * pair + 1) % gap == 0 ? 1u : ((2 * pair + 2) % gap == 0 ? 2u : 0u);
+    return (unsigned)(((pair & 1) * 27 + v * 9 + k0 * 3 + k1) * kEveryStride + (k0 == 2 ? 4 : 0));
+}
 // the two code words of a chunk; four calm or four dry steps: one block for the chunk (36 + 2 x chunk parity + kind)
 __device__ __forceinline__ uint2 chunk_codes(long chunk, unsigned k0, unsigned k1, unsigned k2, unsigned k3)
 {
@@ -1412,6 +1419,37 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                     // jumps add a 32-bit offset to the address of block 0 without a carry: not for a code object that
                     // straddles a 4 GB line -- that launch walks the threaded chunks.  (Observations and deviations
                     // through a.obs / a.ws, not through the __restrict__ arguments: see f_asm.)
+                    // Gaps that are not whole chunks (2, 3, 6 ... steps; FastModel::stream_gap): the stream of records, the
+                    // report behind the arms whose steps end an interval.  From an interval that starts on a multiple of
+                    // four steps on, as many groups of lcm(gap, 4) steps as the stretch has.
+                    if constexpr (Q && !Model::kSplit) {
+                        const unsigned pc_lo = (unsigned)__builtin_amdgcn_s_getpc();
+                        if (a.estream && gap % kChunk != 0 && pc_lo > 0x00400000u && pc_lo < 0xffc00000u) {
+                            const long unit = gap % 2 ? 4 : 2; // intervals per lcm(gap, 4) steps
+                            const long lead = (unit - i0 % unit) % unit;
+                            const long n_stream = i1 - i0 > lead ? (i1 - i0 - lead) / unit * unit : 0;
+                            if (n_stream > 0) {
+                                const bool reporting = stretch == 1;
+                                if (lead > 0)
+                                    arm_intervals<Q, REPORT == kReportLast>(m, f + i0 * gap, lead, gap, false, acc,
+                                                                            [&]() __attribute__((always_inline)) {
+                                                                                if (stretch == 1)
+                                                                                    report();
+                                                                            });
+                                const long first = (i0 + lead) * gap;
+                                double unused = 0.0;
+                                m.template stream_gap<REPORT == kReportLast>(
+                                    a.estream + (x.c * every_pairs(a.T) + first / 2) * 8,
+                                    a.ecodes + x.c * every_pairs(a.T) + first / 2, (int)(n_stream * gap / 4), reporting,
+                                    a.discharge != nullptr, rep.want_obj, r == 0, inv_gap, acc, rep.A, rep.B, rep.C1, rep.C2,
+                                    rep.C3, rep.shift, REPORT == kReportLast ? num_raw : q_out_total,
+                                    REPORT == kReportLast ? den_raw : unused, rep.row, a.ld);
+                                if (reporting)
+                                    r += n_stream;
+                                done = lead + n_stream;
+                            }
+                        }
+                    }
                     if constexpr (Q && !Model::kSplit) {
                         const unsigned pc_lo = (unsigned)__builtin_amdgcn_s_getpc();
                         // whole intervals whose last chunk has two chunks of the array behind it (the asm's requests)

@@ -422,7 +422,8 @@
 // nothing during the warm-up (%[rep] = 0); the value (value: the instruction that puts it into %[rv]); report 0 sets the
 // constant the moments are taken about (s85: is the next report number 0?); the discharge through the lane's row pointer;
 // the moments (e, w in s[80:83], requested when the interval began); `after`: what the run keeps of the interval.
-#define SMART_P_REPORT(value, after)                                                                                   \
+#define SMART_P_REPORT(value, after) SMART_P_REPORT_X(value, after, "s[80:81]", "s[82:83]", "s83")
+#define SMART_P_REPORT_X(value, after, e, w, whi)                                                                      \
     "s_cmp_eq_u32 %[rep], 0\n\t"                                                                                       \
     "s_cbranch_scc1 96f\n\t" value "s_cmp_eq_u32 s85, 0\n\t"                                                           \
     "s_cbranch_scc1 93f\n\t"                                                                                           \
@@ -435,12 +436,13 @@
     "v_lshl_add_u64 %[row], %[ld], 3, %[row]\n\t"                                                                      \
     "97:\n\t"                                                                                                          \
     "s_cmp_eq_u32 %[hob], 0\n\t"                                                                                       \
-    "s_cbranch_scc1 98f\n\t" SMART_R_MOMENTS("%[rv]", "s[80:81]", "s[82:83]", "s83") "98:\n\t" after "96:\n\t"
-#define SMART_P_REPORT_MEAN                                                                                            \
-    SMART_P_REPORT("v_mul_f64 %[rv], %[acc], %[ig]\n\t", "v_add_f64 %[qtot], %[qtot], %[acc]\n\tv_mov_b64_e64 %[acc], 0\n\t")
-#define SMART_P_REPORT_LAST                                                                                            \
-    SMART_P_REPORT("v_mov_b64_e64 %[rv], %[acc]\n\t",                                                                  \
-                   "v_add_f64 %[numr], %[numr], %[qg]\n\tv_add_f64 %[denr], %[denr], %[qi]\n\t")
+    "s_cbranch_scc1 98f\n\t" SMART_R_MOMENTS("%[rv]", e, w, whi) "98:\n\t" after "96:\n\t"
+#define SMART_P_VALUE_MEAN "v_mul_f64 %[rv], %[acc], %[ig]\n\t"
+#define SMART_P_AFTER_MEAN "v_add_f64 %[qtot], %[qtot], %[acc]\n\tv_mov_b64_e64 %[acc], 0\n\t"
+#define SMART_P_VALUE_LAST "v_mov_b64_e64 %[rv], %[acc]\n\t"
+#define SMART_P_AFTER_LAST "v_add_f64 %[numr], %[numr], %[qg]\n\tv_add_f64 %[denr], %[denr], %[qi]\n\t"
+#define SMART_P_REPORT_MEAN SMART_P_REPORT(SMART_P_VALUE_MEAN, SMART_P_AFTER_MEAN)
+#define SMART_P_REPORT_LAST SMART_P_REPORT(SMART_P_VALUE_LAST, SMART_P_AFTER_LAST)
 // a STRETCH of %[niv] report intervals of %[half] pairs of chunks (EVEN) / chunks (ODD) each: %[fp] / %[cp] = the first chunk in the forcing /
 // the code words, %[op] / %[wp] = the first interval's observation / deviation (anything readable without objective
 // functions).  s75 counts the intervals, s84 is the byte offset of the observation at hand.
@@ -587,6 +589,61 @@
 #define SMART_E_CLOBBERS                                                                                               \
     "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",    \
         "s68", SMART_P_CLOBBERS
+
+// ---- report gaps that are not whole chunks (2, 3, 6 ... steps): the stream of records again (round 4) --------------------
+// As SMART_A_EVERY_STREAM -- records of rain, PE, observation and deviation per step, a code word per pair of steps, two
+// register buffers, the exit test in P1's tails -- but the report (SMART_P_REPORT_X: the interval's, with its flags) sits
+// behind the arm whose step ends an interval, and nowhere else: the code word picks among three variants of every block
+// (no report / behind the first arm / behind the second), smart_forcing_scan knows the gap.  2 x 3 x 9 = 54 blocks.
+// An s_nop behind the report: eleven 4-byte instructions in it.
+#define SMART_G_ARM1(arm, rep) arm rep
+#define SMART_G_NINE(pos, v, route, rx, px, r0, ry, py, r1, tail)                                                      \
+    SMART_E_BLOCK(pos, v "*9+0", SMART_P_ARM_C_N(route, "0", "", "") r0 SMART_P_ARM_C_Q(route, "", "") r1              \
+                                     tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                                     \
+    SMART_E_BLOCK(pos, v "*9+1", SMART_P_ARM_C_N(route, "0", "", "") r0 SMART_A_DRY(route, py, "") r1                  \
+                                     tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                                     \
+    SMART_E_BLOCK(pos, v "*9+2", SMART_P_ARM_C_N(route, "0", "", "") r0 "s_nop 0\n\t" SMART_P_ARM_R_Q(                 \
+        route, ry, py, "", "", "", "") "s_nop 0\n\t" r1 tail SMART_P_OOL(SMART_A_CASC_CALM_OOL("0")))                  \
+    SMART_E_BLOCK(pos, v "*9+3", SMART_A_DRY(route, px, "") r0 SMART_P_ARM_C_F(route, "", "") r1 tail)                 \
+    SMART_E_BLOCK(pos, v "*9+4", SMART_A_DRY(route, px, "") r0 SMART_A_DRY(route, py, "") r1 tail)                     \
+    SMART_E_BLOCK(pos, v "*9+5", SMART_A_DRY(route, px, "") r0 "s_nop 0\n\t" SMART_P_ARM_R_F(                          \
+        route, ry, py, "", "", "", "") "s_nop 0\n\t" r1 tail)                                                          \
+    SMART_E_BLOCK(pos, v "*9+6", "s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", "", "", "", "") "s_nop 0\n\t" r0      \
+                                     SMART_P_ARM_C_N(route, "1", "", "") r1                                            \
+                                         tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0"))                                  \
+                                             SMART_P_OOL(SMART_A_CASC_CALM_OOL("1")))                                  \
+    SMART_E_BLOCK(pos, v "*9+7", "s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", "", "", "", "") "s_nop 0\n\t" r0      \
+                                     SMART_A_DRY(route, py, "") r1 tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0")))       \
+    SMART_E_BLOCK(pos, v "*9+8", "s_nop 0\n\t" SMART_P_ARM_R(route, rx, px, "0", "", "", "", "") "s_nop 0\n\t" r0      \
+                                     "s_nop 0\n\t" SMART_P_ARM_R(route, ry, py, "1", "", "", "", "") "s_nop 0\n\t" r1  \
+                                         tail SMART_P_OOL(SMART_A_CASC_RAIN_OOL("0"))                                  \
+                                             SMART_P_OOL(SMART_A_CASC_RAIN_OOL("1")))
+#define SMART_G_REP(value, after, e, w, whi) SMART_P_REPORT_X(value, after, e, w, whi) "s_nop 0\n\t"
+#define SMART_G_THREE(pos, route, value, after, rx, px, e0, w0, h0, ry, py, e1, w1, h1, tail)                          \
+    SMART_G_NINE(pos, "0", route, rx, px, "", ry, py, "", tail)                                                        \
+    SMART_G_NINE(pos, "1", route, rx, px, SMART_G_REP(value, after, e0, w0, h0), ry, py, "", tail)                     \
+    SMART_G_NINE(pos, "2", route, rx, px, "", ry, py, SMART_G_REP(value, after, e1, w1, h1), tail)
+// block number = position x 27 + variant x 9 + pattern: SMART_E_BLOCK's "pos*9 + k" with pos = 3 x position
+#define SMART_A_GAP_STREAM(route, value, after)                                                                        \
+    "s_getpc_b64 s[78:79]\n\t"                                                                                         \
+    "90:\n\t"                                                                                                          \
+    "s_add_u32 s78, s78, 91f-90b\n\t"                                                                                  \
+    "s_addc_u32 s79, s79, 0\n\t"                                                                                       \
+    "s_mov_b32 s77, s79\n\t"                                                                                           \
+    "s_load_dwordx16 s[36:51], %[sp], 0x0\n\t"                                                                         \
+    "s_load_dword s68, %[cp], 0x0\n\t"                                                                                 \
+    "s_mov_b32 s73, 64\n\t"                                                                                            \
+    "s_load_dwordx16 s[52:67], %[sp], s73\n\t"                                                                         \
+    "s_mov_b32 s74, 4\n\t"                                                                                             \
+    "s_load_dword s70, %[cp], s74\n\t"                                                                                 \
+    "s_sub_u32 s72, 0, %[quads]\n\t"                                                                                   \
+    "s_mov_b32 s85, %[r0]\n\t"                                                                                         \
+    "s_waitcnt lgkmcnt(0)\n\t" SMART_P_JUMP("s68") ".p2align 6\n\t"                                                    \
+    "91:\n\t" SMART_G_THREE("0", route, value, after, "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", "s43",           \
+                            "s[44:45]", "s[46:47]", "s[48:49]", "s[50:51]", "s51", SMART_E_TAIL_P0)                    \
+        SMART_G_THREE("3", route, value, after, "s[52:53]", "s[54:55]", "s[56:57]", "s[58:59]", "s59", "s[60:61]",     \
+                      "s[62:63]", "s[64:65]", "s[66:67]", "s67", SMART_E_TAIL_P1) ".p2align 3\n\t"                     \
+                                                                                   "99:\n\t"
 
 // ---- the wet interval of the interval engine (FastModel::wet_interval, merged regular variant, no exits) ----------
 // `n` wet steps with one excess: 73 vector instructions a step (5 routing, 22 filling, 34 for the three leak passes

@@ -1033,6 +1033,41 @@ struct FastModel {
         row = (double *)row_bits;
     }
 
+    // `quads` x 4 steps of a run whose report gap is not a whole number of chunks, through the blocks of SMART_A_GAP_STREAM:
+    // the stream of records and code words of stream_every(), the interval's report (stream_stretch()'s: flags, report 0's
+    // constant, row pointer, moments, sums) behind the arms whose steps end an interval -- the code words know which.
+    // The steps are whole intervals (the caller sees to it); acc, the interval's sum, is zero going in and coming out.
+    template <bool LAST>
+    __device__ __forceinline__ void stream_gap(const double *records, const unsigned *codes, int quads, bool reporting,
+                                               bool storing, bool has_obs, bool first_is_0, double inv_gap, double &acc,
+                                               double &mA, double &mB, double &mC1, double &mC2, double &mC3, double &shift,
+                                               double &sum_a, double &sum_b, double *&row, long ld)
+    {
+        static_assert(!SPLIT, "stream_gap: the SPLIT models take the threaded chunks");
+        SMART_ARM_LOCALS;
+        double rv, rd, ru;
+        unsigned long long row_bits = (unsigned long long)row;
+        const int q = __builtin_amdgcn_readfirstlane(quads), rep_i = __builtin_amdgcn_readfirstlane((int)reporting),
+                  sto_i = __builtin_amdgcn_readfirstlane((int)(storing && reporting)),
+                  hob_i = __builtin_amdgcn_readfirstlane((int)(has_obs && reporting)),
+                  r0_i = __builtin_amdgcn_readfirstlane((int)(first_is_0 && reporting));
+#define SMART_GAP_IN                                                                                                   \
+    SMART_ARM_CONSTS, [sp] "s"(records), [cp] "s"(codes), [quads] "s"(q), [rep] "s"(rep_i), [sto] "s"(sto_i),          \
+        [hob] "s"(hob_i), [r0] "s"(r0_i), [ig] "v"(inv_gap), [ld] "s"(ld)
+        if constexpr (LAST)
+            asm volatile(SMART_A_GAP_STREAM(SMART_A_ROUTE_LAST, SMART_P_VALUE_LAST, SMART_P_AFTER_LAST)
+                         : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_LAST, SMART_STRETCH_OUT, [numr] "+v"(sum_a),
+                           [denr] "+v"(sum_b)
+                         : SMART_GAP_IN
+                         : SMART_S_CLOBBERS);
+        else
+            asm volatile(SMART_A_GAP_STREAM(SMART_A_ROUTE, SMART_P_VALUE_MEAN, SMART_P_AFTER_MEAN)
+                         : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_STRETCH_OUT, [qtot] "+v"(sum_a)
+                         : SMART_GAP_IN
+                         : SMART_S_CLOBBERS);
+        row = (double *)row_bits;
+    }
+
     // ---- a whole report interval without rain excess (run_ensemble_merged) ------------------------------------
     // While no lane gets inflow the routing half of the model is linear with constant coefficients:
     //   U_j' = dec_j U_j  (j = quick, inter, groundwater),   U_riv' = (1 - a_r) U_riv + a_r (U_q + U_i + U_g)

@@ -98,7 +98,7 @@ def test_workspace_has_room_for_the_step_loops_code_words(L):
     """smart_workspace_bytes (no device needed for this part): fast summary / raw runs over whole intervals of a multiple
     of four steps get 8 bytes per four steps and catchment -- the kinds of the steps for the pair blocks of the step loop
     (smart_device.h: code_chunks) --, a report every step 68 bytes per pair of steps -- the stream of records and its code
-    words (every_pairs); other gaps, and the literal mode, nothing of the kind."""
+    words (every_pairs), and so do gaps that are not whole chunks of four steps; the literal mode nothing of the kind."""
     from smartpy_amd import _lib
 
     def need(gap, report, T=9600, C=3, math=1):
@@ -106,12 +106,12 @@ def test_workspace_has_room_for_the_step_loops_code_words(L):
         e.n_catchments, e.n_samples, e.n_steps, e.n_warm, e.report_gap = C, 10, T, 0, gap
         e.report_type, e.math_mode, e.delta_sec = report, math, 3600.0
         return L.smart_workspace_bytes(ctypes.byref(e))
-    plain = need(6, 1)                                  # header only (no objfn, no device: no hand-over)
+    plain = need(24, 1, math=0)                         # header only (no objfn, no device: no hand-over)
     rnd = lambda x: (x + 255) // 256 * 256              # noqa: E731
     assert need(24, 1) - plain == rnd(3 * (9600 // 4 + 4) * 8)
     assert need(8, 2) - plain == rnd(3 * (9600 // 4 + 4) * 8)
-    assert need(1, 1) - plain == rnd(3 * (9600 // 2 + 4) * 68) == need(1, 2) - plain
-    assert need(12, 1) - plain == rnd(3 * (9600 // 4 + 4) * 8) and plain == need(24, 1, math=0) == need(1, 1, math=0)
+    assert need(1, 1) - plain == rnd(3 * (9600 // 2 + 4) * 68) == need(1, 2) - plain == need(6, 1) - plain
+    assert need(12, 1) - plain == rnd(3 * (9600 // 4 + 4) * 8) and plain == need(1, 1, math=0)
     assert need(16, 2, T=9601) == plain                 # raw over a ragged time axis: smart_fast_plain
 
 

@@ -6,6 +6,7 @@ Gates
                  fp64 bit patterns; and within 1e-11 of the reference-exact oracle / the reference's own values.
   fast mode    : relative difference <= 1e-9 on discharge (contract of BASELINE.json: 1e-6), 1e-10 on gw.
 """
+import math
 import os
 
 import numpy as np
@@ -1198,7 +1199,9 @@ def test_randomized_raw_and_every_step_reports(eng, monkeypatch):
 
 
 @pytest.mark.parametrize('report, gap', [('summary', 24), ('summary', 8), ('raw', 16), ('summary', 48), ('summary', 1),
-                                         ('raw', 1), ('summary', 4), ('summary', 12), ('raw', 20), ('raw', 4)])
+                                         ('raw', 1), ('summary', 4), ('summary', 12), ('raw', 20), ('raw', 4),
+                                         ('summary', 2), ('summary', 3), ('summary', 6), ('raw', 6), ('summary', 10),
+                                         ('raw', 7)])
 def test_pair_blocks_are_bit_identical_to_the_threaded_chunks(eng, monkeypatch, report, gap):
     """The streaming step loop as pair blocks behind computed jumps (smart_fast_arms.h: SMART_A_PAIRS_STRETCH; the kinds
     of the steps from smart_forcing_scan's code words) against the threaded chunks of the same library
@@ -1206,7 +1209,8 @@ def test_pair_blocks_are_bit_identical_to_the_threaded_chunks(eng, monkeypatch, 
     steps in every order -- on both chunk parities, each followed by every other at least once in a shuffled order;
     missing observations; a warm-up; sliced and not.  Every output bit for bit, and the oracle within tolerance.
     gaps 4, 12, 20: an odd number of chunks per interval -- the second form of the stretch asm (both buffers' tails count,
-    a stretch may start in either buffer: five slices of such a run do).  gap 1: a report every step -- the stream of records with the report in the asm (SMART_A_EVERY_STREAM) against the
+    a stretch may start in either buffer: five slices of such a run do).  gaps 2, 3, 6, 7, 10: not whole chunks -- the stream
+    of records with the interval's report behind the arms whose steps end one (SMART_A_GAP_STREAM).  gap 1: a report every step -- the stream of records with the report in the asm (SMART_A_EVERY_STREAM) against the
     step-by-step loop with its compiled report; with and without the discharge matrix, with and without observations."""
     rng = np.random.default_rng(gap * 7 + len(report))
     kinds = [(a, b, c, d) for a in range(3) for b in range(3) for c in range(3) for d in range(3)]
@@ -1214,7 +1218,8 @@ def test_pair_blocks_are_bit_identical_to_the_threaded_chunks(eng, monkeypatch, 
     for rep in range(6):                                   # six shuffles: both parities, many successions
         order = rng.permutation(len(kinds))
         chunks += [kinds[i] for i in order] + ([kinds[order[0]]] if rep % 2 else [])
-    n_chunks = len(chunks) // max(gap // 4, 1) * max(gap // 4, 1)
+    unit = gap // math.gcd(gap, 4)                          # chunks per lcm(gap, 4) steps: whole report intervals
+    n_chunks = len(chunks) // unit * unit
     kind = np.array(chunks[:n_chunks]).ravel()             # 0 calm, 1 dry, 2 rain
     T = kind.size
     rain = np.where(kind == 2, rng.gamma(0.5, 1.5, T) + 1e-3, 0.0)

@@ -41,9 +41,39 @@ def test_every_pair_block_lies_where_the_code_words_point(kernel):
     insts = _kernel(kernel)
     at = {x['addr']: i for i, x in enumerate(insts)}
     entries = [i for i, x in enumerate(insts) if x['op'] == 's_getpc_b64' and 's[78:79]' in x['args']]
-    assert len(entries) == 2, 'two instances of the stretch asm per kernel: even / any number of chunks per interval'
-    for i in entries:
+    # the stream of records (SMART_A_GAP_STREAM) loads ONE code word per pair, the pair blocks two per chunk
+    pairs = [i for i in entries if not any(x['op'] == 's_load_dword' for x in insts[i:i + 12])]
+    assert len(pairs) == 2, 'two instances of the stretch asm per kernel: even / any number of chunks per interval'
+    for i in pairs:
         _check_instance(insts, at, i, stride)
+    streams = [i for i in entries if i not in pairs]
+    assert len(streams) == 1
+    _check_gap_stream(insts, at, streams[0], _stride('SMART_E_STRIDE'))
+
+
+def _check_gap_stream(insts, at, i, stride):
+    """54 blocks: 2 buffers x 3 variants (no report in the pair / behind its first arm / behind its second) x 9 patterns;
+    every main path ends with the computed jump inside the block's room, requests one pair, and holds the report's
+    row-pointer move exactly where its variant says"""
+    base = insts[i]['addr'] + 4 + int(insts[i + 1]['args'].split(',')[-1], 0)
+    assert base % 64 == 0
+    for n in range(54):
+        variant, pattern = (n % 27) // 9, n % 9
+        names = KINDS[pattern // 3] + KINDS[pattern % 3]
+        b = base + n * stride
+        assert b in at, 'block %d does not start on an instruction' % n
+        k = at[b]
+        if names[0] == 'R':
+            assert insts[k]['op'] == 's_nop' and insts[k]['size'] == 4
+            k += 1
+        assert insts[k]['op'].startswith(FIRST[names[0]]), (n, names, insts[k]['op'])
+        loads = reports = 0
+        while insts[k]['op'] != 's_setpc_b64':
+            assert insts[k]['addr'] < b + stride, 'block %d (%s) outgrew its %d bytes' % (n, names, stride)
+            loads += insts[k]['op'].startswith('s_load_dwordx16')
+            reports += insts[k]['op'] == 'v_lshl_add_u64'
+            k += 1
+        assert loads == 1 and reports == (variant != 0), (n, names, variant, loads, reports)
 
 
 def _check_instance(insts, at, i, stride):
@@ -106,7 +136,8 @@ def test_a_dry_pair_is_eighteen_instructions_on_the_boundary():
     stride = _stride()
     insts = _kernel('smart_fast_steps')
     at = {x['addr']: i for i, x in enumerate(insts)}
-    i = [k for k, x in enumerate(insts) if x['op'] == 's_getpc_b64' and 's[78:79]' in x['args']][0]
+    i = [k for k, x in enumerate(insts) if x['op'] == 's_getpc_b64' and 's[78:79]' in x['args'] and
+         not any(y['op'] == 's_load_dword' for y in insts[k:k + 12])][0]
     base = insts[i]['addr'] + 4 + int(insts[i + 1]['args'].split(',')[-1], 0)
     k = at[base + 4 * stride]
     body = insts[k:k + 20]
