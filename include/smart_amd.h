@@ -166,8 +166,9 @@ int smart_check_ensemble(const SmartEnsemble *e);
  * a header (status word, counters, per-catchment forcing flags), the observation statistics if e->objfn is set,
  * plus -- on a machine with a HIP device -- the hand-over buffer of the time-sliced launch the library would
  * choose, plus, for fast summary / raw runs over whole report intervals, 8 bytes per four time steps and catchment
- * (the kinds of the steps, worked out once per launch; 68 bytes per two steps where the gap is no multiple of four).  The library allocates nothing itself: the caller owns every buffer, which also lets the call be captured
- * into a HIP graph.  A launch without a workspace runs unsliced and reports no status. */
+ * (the kinds of the steps, worked out once per launch; 68 bytes per two steps where the gap is no multiple of four).
+ * The library allocates nothing itself: the caller owns every buffer, which also lets the call be captured into a HIP
+ * graph.  A launch without a workspace runs unsliced and reports no status. */
 int64_t smart_workspace_bytes(const SmartEnsemble *e);
 
 /* Classify the parameter rows and the forcing of a SMART_MATH_FAST call on the device (two small kernels on
