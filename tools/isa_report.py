@@ -185,15 +185,16 @@ def main():
                 lines.append(';; ==== LOOP L%d END' % lp['id'])
     with open(out + '.s', 'w') as fh:
         fh.write('\n'.join(lines) + '\n')
+    # (one block, one loop per line: the tables of the kernels with several instances of their asm run to thousands of rows)
+    block_rows = [{k: b[k] for k in ('id', 'loops', 'hist')} | {
+        'addr': insts[b['lo']]['addr'], 'n': b['hi'] - b['lo'], 'ends_with': insts[b['hi'] - 1]['op'],
+        'target': insts[b['hi'] - 1]['target']} for b in blocks]
+    loop_rows = [{k: lp[k] for k in ('id', 'depth', 'n_insts', 'hist')} | {
+        'head_addr': insts[lp['head']]['addr'], 'tail_addr': insts[lp['tail']]['addr']} for lp in loops]
     with open(out + '.json', 'w') as fh:
-        json.dump({'kernel': symbol, 'n_insts': len(insts),
-                   'blocks': [{k: b[k] for k in ('id', 'loops', 'hist')} | {
-                       'addr': insts[b['lo']]['addr'], 'n': b['hi'] - b['lo'],
-                       'ends_with': insts[b['hi'] - 1]['op'],
-                       'target': insts[b['hi'] - 1]['target']} for b in blocks],
-                   'loops': [{k: lp[k] for k in ('id', 'depth', 'n_insts', 'hist')} | {
-                       'head_addr': insts[lp['head']]['addr'], 'tail_addr': insts[lp['tail']]['addr']} for lp in loops]},
-                  fh, indent=1)
+        fh.write('{"kernel": %s, "n_insts": %d,\n "blocks": [\n  %s\n ],\n "loops": [\n  %s\n ]}\n' % (
+            json.dumps(symbol), len(insts), ',\n  '.join(json.dumps(r) for r in block_rows),
+            ',\n  '.join(json.dumps(r) for r in loop_rows)))
     print('\n'.join(lines[:2]))
     for lp in sorted(loops, key=lambda l: -l['hist'].get('fp64', 0))[:6]:
         print('  L%d depth %d, %d instructions: %s' % (lp['id'], lp['depth'], lp['n_insts'], fmt_hist(lp['hist'])))
