@@ -159,6 +159,19 @@ def pmc_summary(pmc_key, path=None, source_hash=None):
     return pmc, pmc.get('source', 'profiles/traffic_latest.json')
 
 
+def leg_roofline(leg, launch_ms):
+    """Issue-roof figures of one leg of the line (the same runs under another mode) from that leg's own committed PMC
+    summary (profiles/r04_<leg>.md through profiles/traffic_latest.json, key leg:<leg>): vector instructions x 4 issue
+    cycles over the issue cycles 1,024 SIMDs have in the leg's launch at the peak clock; {} when the kernel sources are
+    not the profiled ones."""
+    pmc, _ = pmc_summary('leg:' + leg)
+    if not pmc.get('valu_insts_per_launch') or not launch_ms:
+        return {}
+    return {'frac': pmc['valu_insts_per_launch'] * VALU_ISSUE_CYCLES / (N_SIMD * CLOCK_HZ * launch_ms * 1e-3),
+            'frac_at_held_clock_profiled': pmc.get('issue_frac_at_held_clock'),
+            'valu_insts_per_launch': pmc['valu_insts_per_launch'], 'bound': 'fp64 vector-ALU issue'}
+
+
 def isa_model_summary(pmc_key, path=None, source_hash=None):
     """The vector-instruction count of one workload as tools/isa_model.py derives it from the TREE (hipcc's assembly of
     the hot loops weighed with the workload's path frequencies; cross-compiled, no GPU) -> (figures, source); like the
@@ -499,7 +512,8 @@ def main():
                 'what': 'same runs, daily totals spread unevenly over the hours (rain in ~6 random hours, PE on a '
                         'daytime sine): forcing varies inside the report interval, the interval engine does not apply',
                 'kernel': flat.describe(), 'launch_ms': f_ms, 'value': units_per_launch / (f_ms * 1e-3),
-                'unit': 'sample-timesteps/s', 'wet_fraction': wet_fraction(vary, W)}
+                'unit': 'sample-timesteps/s', 'wet_fraction': wet_fraction(vary, W),
+                'roofline': leg_roofline('flat_forcing', f_ms)}
             del flat
         if strong is not None:
             line['strong_1e6'] = strong
@@ -513,7 +527,8 @@ def main():
                 'what': 'same runs, daily totals as four 6-hour values spread equally over their six steps (6-hourly '
                         'input files in an hourly run, timeframe.py:167-186): the interval engine over runs of 6 steps',
                 'kernel': runs.describe(), 'launch_ms': r_ms, 'value': units_per_launch / (r_ms * 1e-3),
-                'unit': 'sample-timesteps/s', 'wet_fraction': wet_fraction(six, W)}
+                'unit': 'sample-timesteps/s', 'wet_fraction': wet_fraction(six, W),
+                'roofline': leg_roofline('runs_of_6', r_ms)}
             del runs
         if world == 1 and cfg == 3 and store and not args.no_flat and args.math == 'fast':
             # the same runs the way MonteCarlo.run() launches them by default (save_sim=False): objective functions and
@@ -540,17 +555,17 @@ def main():
                 'what': "same runs with report='raw' (the outflow of each day's last hour, groundwater ratio from those "
                         "steps only): the interval engine over 23 + 1 steps",
                 'kernel': raw.describe(), 'launch_ms': w_ms, 'value': units_per_launch / (w_ms * 1e-3),
-                'unit': 'sample-timesteps/s'}
+                'unit': 'sample-timesteps/s', 'roofline': leg_roofline('raw_gap24', w_ms)}
             del raw
             every = engine.prepare_ensemble(d_params, d_forcing, AREA, dt, W, 1, obs=np.repeat(obs, gap),
                                             gw_obs=GW_OBS, **dict(kw, want_discharge=False))
             _, e_ms, _ = timed_steps(every.launch, max(2, args.steps // 2), 1, device)
             every.verify()
             line['gap1'] = {
-                'what': 'same runs with a report every step (hourly reports of the hourly run, %d observations): '
-                        'single-step arms with the objective-function moments between them' % (R * gap),
+                'what': 'same runs with a report every step (hourly reports of the hourly run, %d observations): the '
+                        'run as a stream of records, arm and report in one asm' % (R * gap),
                 'kernel': every.describe(), 'launch_ms': e_ms, 'value': units_per_launch / (e_ms * 1e-3),
-                'unit': 'sample-timesteps/s'}
+                'unit': 'sample-timesteps/s', 'roofline': leg_roofline('gap1', e_ms)}
             del every
         if not args.no_cpu_baseline:
             # rank 0's host cores and rank 0's GPU, whatever the world size (the other ranks wait at the barrier below)

@@ -174,3 +174,19 @@ def test_bench_with_two_ranks_launched_the_way_the_driver_does(config, samples):
         assert len(st['launch_ms_per_rank']) == 2 and st['value'] > 0
     per_step = c['runs_total'] * 96432            # sample-timesteps of one step, warm-up included
     assert abs(d['value'] - per_step / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+
+
+def test_the_legs_of_the_line_are_priced_against_the_issue_roof_with_their_own_counts():
+    """bench.leg_roofline: a leg's launch time against the issue cycles of 1,024 SIMDs with the vector-instruction count of
+    that leg's own committed PMC summary (profiles/traffic_latest.json, key leg:<name>) -- and nothing at all when the
+    kernel sources are not the ones that were profiled"""
+    import bench
+    for leg in ('flat_forcing', 'runs_of_6', 'raw_gap24', 'gap1'):
+        pmc, _ = bench.pmc_summary('leg:' + leg)
+        r = bench.leg_roofline(leg, 12.0)
+        if not pmc:
+            assert r == {}
+            continue
+        assert r['frac'] == pmc['valu_insts_per_launch'] * 4 / (1024 * 2.4e9 * 12.0e-3) and 0.3 < r['frac'] < 1.0
+        assert 0.5 < r['frac_at_held_clock_profiled'] < 1.0
+    assert bench.leg_roofline('no_such_leg', 12.0) == {} and bench.leg_roofline('flat_forcing', 0.0) == {}

@@ -9,7 +9,10 @@ python $S gpurun_out/prof_r04_config4_shard profiles/r04_config4_shard "config4:
 python $S gpurun_out/prof_r04_config4_1gpu profiles/r04_config4_1gpu "config4:runs_per_gpu=1000000:discharge=0:math=fast" > /dev/null
 python $S gpurun_out/prof_r04_config5_1gpu profiles/r04_config5_1gpu "config5:runs_per_gpu=640000:discharge=0:math=fast" > /dev/null
 python $S gpurun_out/prof_r04_config2 profiles/r04_config2 "config2:runs_per_gpu=10000:discharge=1:math=fast" > /dev/null
-for t in flat_forcing flat_forcing_1e6 runs_of_6 raw_gap24 raw_gap24_flat gap1; do python $S gpurun_out/prof_r04_$t profiles/r04_$t > /dev/null; done
+# (the legs of the bench line under keys of their own in profiles/traffic_latest.json: bench.py prices each leg's launch
+# against the issue roof with its own instruction count)
+for t in flat_forcing runs_of_6 raw_gap24 gap1; do python $S gpurun_out/prof_r04_$t profiles/r04_$t "leg:$t" > /dev/null; done
+for t in flat_forcing_1e6 raw_gap24_flat; do python $S gpurun_out/prof_r04_$t profiles/r04_$t > /dev/null; done
 # the three kernels that took over from smart_fast_plain, side by side (the verdict's profiles/r04_plain.md)
 { echo "# Raw reports and a report every step (round 4): the kernels that took over from smart_fast_plain"; echo
   echo "1e5 LHS samples x hourly 10 yr + 1 yr warm-up, objective functions fused, no discharge matrix (tools/debug/reports_only.py);"
@@ -18,7 +21,7 @@ for t in flat_forcing flat_forcing_1e6 runs_of_6 raw_gap24 raw_gap24_flat gap1; 
 cp gpurun_out/r04_recip_bits.txt profiles/
 [ -f gpurun_out/soak_round.log ] && cp gpurun_out/soak_round.log profiles/r04_time_slice_soak.txt
 for c in "" _c2 _c4 _c5 _c4shard; do grep '^{' gpurun_out/bench_r04$c.log > profiles/r04_bench_${c#_}.jsonl; done
-mv profiles/r04_bench_.jsonl profiles/r04_bench_config3.jsonl
+mv profiles/r04_bench_.jsonl profiles/r04_bench_config3.jsonl   # (tools/gpu_final_check.sh's line is appended to it afterwards)
 for k in steps intervals steps_every intervals_raw; do python tools/isa_report.py smart_fast_$k profiles/r04_isa_$k --hot > /dev/null; done
 # (the listings of the two kernels with four instances of their loop each run to 1.5 MB of text: their block tables stay,
 # the text is one command away -- python tools/isa_report.py smart_fast_steps_every /tmp/every --hot)
