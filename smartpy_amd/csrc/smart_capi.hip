@@ -208,7 +208,7 @@ __global__ void smart_forcing_scan(KArgs a, const double2 *__restrict__ forcing)
             uint2 w = make_uint2(0u, 0u);
             if ((ch + 1) * kChunk <= a.T) {
                 const double2 *__restrict__ v = f + ch * kChunk;
-                w = chunk_codes(ch, step_kind(v[0]), step_kind(v[1]), step_kind(v[2]), step_kind(v[3]));
+                w = chunk_codes(ch, step_kind(v[0]), step_kind(v[1]), step_kind(v[2]), step_kind(v[3]), a.pair_stride);
             }
             codes[ch] = w;
         }
@@ -591,6 +591,7 @@ static KArgs kernel_args(const SmartEnsemble *e, const Workspace &w)
     a.objfn = e->objfn;
     a.final_vars = e->final_vars;
     a.np_mean = e->math_mode == SMART_MATH_LITERAL && e->report_type == SMART_REPORT_SUMMARY && a.gap >= 8 && a.gap <= 128;
+    a.pair_stride = e->final_vars ? (int)kPairStrideSplit : (int)kPairStride;
     a.n_catch = e->n_catchments;
     a.n_blocks = (a.N + kWave - 1) / kWave;
     a.seg_blocks = a.n_blocks * a.n_catch;
@@ -1017,8 +1018,25 @@ static int allsteps(double area_m2, double delta_sec, int64_t length_simu, const
     }
 
     // ---- the small block: parameters, states, area in; discharge, ratio, final row out; a workspace header
+    // (SMART_ALLSTEPS_MATH=fast: room for what the fast launch wants beside the header -- the code words of the step loop)
+    const char *math = getenv("SMART_ALLSTEPS_MATH");
+    const bool fast = math && std::strcmp(math, "fast") == 0;
+    size_t ws_doubles = kHookHeaderDoubles;
+    if (fast) {
+        SmartEnsemble sized;
+        std::memset(&sized, 0, sizeof(sized));
+        sized.n_catchments = sized.n_samples = 1;
+        sized.n_steps = length_simu;
+        sized.report_gap = report_gap;
+        sized.report_type = report_type;
+        sized.math_mode = SMART_MATH_FAST;
+        sized.time_slices = 1;
+        sized.final_vars = (double *)1; // (asked for: decides which kernels, and with them what the workspace holds)
+        const size_t want = ((size_t)workspace_bytes(&sized) + 7) / 8;
+        ws_doubles = want > ws_doubles ? want : ws_doubles;
+    }
     const size_t n_in = 10 + 12 + 1, n_out = n_rep + 1 + 19;
-    if ((rc = hook_reserve(&h.io, &h.io_cap, n_in + n_out + kHookHeaderDoubles)))
+    if ((rc = hook_reserve(&h.io, &h.io_cap, n_in + n_out + ws_doubles)))
         return rc;
     double in[n_in];
     std::memcpy(in, nd_parameters, 10 * sizeof(double));
@@ -1045,12 +1063,10 @@ static int allsteps(double area_m2, double delta_sec, int64_t length_simu, const
     e.gw = o + n_rep;
     e.final_vars = e.gw + 1;
     e.workspace = o + n_out;
-    e.workspace_bytes = (int64_t)(kHookHeaderDoubles * sizeof(double));
+    e.workspace_bytes = (int64_t)(ws_doubles * sizeof(double));
     e.time_slices = 1;
     // SMART_ALLSTEPS_MATH=fast: the fast kernels for this one sample (interval engine / step loop, SPLIT: the final row is
     // asked for) -- <= 1e-9 of the reference instead of its bits, at a tenth of the time.  Default: literal arithmetic.
-    const char *math = getenv("SMART_ALLSTEPS_MATH");
-    const bool fast = math && std::strcmp(math, "fast") == 0;
     e.math_mode = fast ? SMART_MATH_FAST : SMART_MATH_LITERAL;
     rc = run(&e, /*literal_recip=*/true);
     if (rc == SMART_OK && fast) {

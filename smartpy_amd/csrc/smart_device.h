@@ -50,6 +50,8 @@ struct KArgs {
     // code word per pair of steps (SMART_A_EVERY_STREAM), from smart_forcing_scan; null: time_loop_arms_each
     const double *estream = nullptr;  // [C][every_pairs(T)][8]
     const unsigned *ecodes = nullptr; // [C][every_pairs(T)]
+    int pair_stride = 0;              // bytes between the pair blocks of the kernel that will read the code words: the
+                                      // models with the final state vector have larger blocks (SMART_PS_STRIDE)
     const uint2 *codes = nullptr; // [C][code_chunks(T)]: per chunk of four steps the two code words of the pair blocks
                                   // (SMART_A_PAIRS_STRETCH), from smart_forcing_scan; null: the threaded chunks
     // run lengths a catchment's forcing is tested for: the divisors of the report gap, largest first (div[0] = gap)
@@ -113,6 +115,9 @@ __device__ __forceinline__ void raise_status(const KArgs &a, int bit)
 #endif
 #ifndef SMART_PAIR_BLOCKS
 #define SMART_PAIR_BLOCKS 1 // the streaming step loop as pair blocks behind computed jumps (0: the threaded chunks; A/B builds)
+#endif
+#ifndef SMART_PS_STRIDE
+#define SMART_PS_STRIDE 2368 // ... of the SPLIT models (two more reservoirs in every arm)
 #endif
 #ifndef SMART_E_STRIDE
 #define SMART_E_STRIDE 2240 // bytes from one block of the every-step stream to the next (smart_fast_arms.h)
@@ -797,15 +802,15 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
 // lie kPairStride bytes apart, ordered by (chunk parity, pair, kind of the first step, kind of the second); kinds as the
 // arms tell them apart on the bits of the forcing: rain != +0 -> rain step (2), else PE != +0 -> dry (1), else calm (0).
 // A block that starts with a rain step is entered 4 bytes in.  Meaningful for sane forcing only (the QUICK waves).
-constexpr long kPairStride = SMART_P_STRIDE; // (smart_fast_arms.h)
+constexpr long kPairStride = SMART_P_STRIDE, kPairStrideSplit = SMART_PS_STRIDE; // (smart_fast_arms.h; KArgs::pair_stride)
 __host__ __device__ constexpr long code_chunks(long T) { return T / kChunk + 4; } // (+ the requests beyond a stretch)
 __device__ __forceinline__ unsigned step_kind(const double2 v)
 {
     return __builtin_bit_cast(unsigned long long, v.x) != 0 ? 2u : (__builtin_bit_cast(unsigned long long, v.y) != 0 ? 1u : 0u);
 }
-__device__ __forceinline__ unsigned pair_code(long chunk, int pair, unsigned k0, unsigned k1)
+__device__ __forceinline__ unsigned pair_code(long chunk, int pair, unsigned k0, unsigned k1, long stride)
 {
-    return (unsigned)((((chunk & 1) * 2 + pair) * 9 + k0 * 3 + k1) * kPairStride + (k0 == 2 ? 4 : 0));
+    return (unsigned)((((chunk & 1) * 2 + pair) * 9 + k0 * 3 + k1) * stride + (k0 == 2 ? 4 : 0));
 }
 // the every-step stream: pairs of steps, two register buffers by the pair's parity
 constexpr long kEveryStride = SMART_E_STRIDE;
@@ -822,11 +827,11 @@ __device__ __forceinline__ unsigned gap_code(long pair, long gap, unsigned k0, u
     return (unsigned)(((pair & 1) * 27 + v * 9 + k0 * 3 + k1) * kEveryStride + (k0 == 2 ? 4 : 0));
 }
 // the two code words of a chunk; four calm or four dry steps: one block for the chunk (36 + 2 x chunk parity + kind)
-__device__ __forceinline__ uint2 chunk_codes(long chunk, unsigned k0, unsigned k1, unsigned k2, unsigned k3)
+__device__ __forceinline__ uint2 chunk_codes(long chunk, unsigned k0, unsigned k1, unsigned k2, unsigned k3, long stride)
 {
     if (k0 != 2 && k0 == k1 && k0 == k2 && k0 == k3)
-        return make_uint2((unsigned)((36 + (chunk & 1) * 2 + k0) * kPairStride), 0u);
-    return make_uint2(pair_code(chunk, 0, k0, k1), pair_code(chunk, 1, k2, k3));
+        return make_uint2((unsigned)((36 + (chunk & 1) * 2 + k0) * stride), 0u);
+    return make_uint2(pair_code(chunk, 0, k0, k1, stride), pair_code(chunk, 1, k2, k3, stride));
 }
 
 // ---- piecewise-constant forcing ------------------------------------------------------------------------------
@@ -1450,11 +1455,14 @@ __device__ __forceinline__ void run_ensemble_merged(const KArgs &a, const double
                             }
                         }
                     }
-                    if constexpr (Q && !Model::kSplit) {
+                    if constexpr (Q) {
                         const unsigned pc_lo = (unsigned)__builtin_amdgcn_s_getpc();
-                        // whole intervals whose last chunk has two chunks of the array behind it (the asm's requests)
+                        // whole intervals whose last chunk has two chunks of the array behind it (the asm's requests) --
+                        // and, for the models that park their state ahead of the run's last report interval, not that one
                         const long cpi = gap / kChunk, room = gap % kChunk == 0 ? (a.T / kChunk - 2) / cpi - i0 : 0;
-                        const long n_stream = room < i1 - i0 ? room : i1 - i0;
+                        long n_stream = room < i1 - i0 ? room : i1 - i0;
+                        if (Model::kSplit && stretch == 1 && n_stream > a.R - 1 - r)
+                            n_stream = a.R - 1 - r;
                         if (codes_c && n_stream > 0 && pc_lo > 0x00400000u && pc_lo < 0xffc00000u) {
                             const bool reporting = stretch == 1, fetch = reporting && rep.want_obj;
                             double unused = 0.0;

@@ -952,9 +952,7 @@ struct FastModel {
                                                    double &mC1, double &mC2, double &mC3, double &shift, double &sum_a,
                                                    double &sum_b, double *&row, long ld)
     {
-        // (the models with the final state vector keep the threaded chunks: two rain arms with their two extra
-        // reservoirs do not fit a block)
-        static_assert(!SPLIT, "stream_stretch: the SPLIT models take the threaded chunks");
+        static_assert(!(SPLIT && LAST), "raw reports with the final state vector take smart_fast_plain");
         SMART_ARM_LOCALS;
         const int has_obs = obs_p != nullptr;
         if (!obs_p) {
@@ -996,7 +994,29 @@ struct FastModel {
                      : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_STRETCH_OUT, [qtot] "+v"(sum_a)                        \
                      : SMART_ARM_CONSTS, SMART_STRETCH_IN                                                              \
                      : SMART_S_CLOBBERS)
-        if constexpr (ODD) {
+        if constexpr (SPLIT) {
+            // the models with the final state vector: two more reservoirs in every arm, blocks SMART_PS_STRIDE bytes apart
+            // (the macros read SMART_P_STRIDE where they are expanded: here)
+            double xd, dp;
+#pragma push_macro("SMART_P_STRIDE")
+#undef SMART_P_STRIDE
+#define SMART_P_STRIDE SMART_PS_STRIDE
+            if constexpr (ODD)
+                asm volatile(SMART_A_PAIRS_STRETCH_ODD(SMART_A_ROUTE, SMART_P_REPORT_MEAN, SMART_A_DEEP, SMART_A_CALM_SPLIT,
+                                                       SMART_A_RAIN_ZEROS_SPLIT, SMART_A_RAIN_DRAIN_SPLIT,
+                                                       SMART_A_RAIN_SPLIT, SMART_A_DRY_SPLIT)
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_SPLIT, SMART_STRETCH_OUT, [qtot] "+v"(sum_a)
+                             : SMART_ARM_CONSTS, SMART_STRETCH_IN
+                             : SMART_S_CLOBBERS);
+            else
+                asm volatile(SMART_A_PAIRS_STRETCH(SMART_A_ROUTE, SMART_P_REPORT_MEAN, SMART_A_DEEP, SMART_A_CALM_SPLIT,
+                                                   SMART_A_RAIN_ZEROS_SPLIT, SMART_A_RAIN_DRAIN_SPLIT, SMART_A_RAIN_SPLIT,
+                                                   SMART_A_DRY_SPLIT)
+                             : SMART_ARM_STATES, SMART_ARM_TEMPS, SMART_ARM_SPLIT, SMART_STRETCH_OUT, [qtot] "+v"(sum_a)
+                             : SMART_ARM_CONSTS, SMART_STRETCH_IN
+                             : SMART_S_CLOBBERS);
+#pragma pop_macro("SMART_P_STRIDE")
+        } else if constexpr (ODD) {
             SMART_STRETCH_ASM(SMART_A_PAIRS_STRETCH_ODD);
         } else {
             SMART_STRETCH_ASM(SMART_A_PAIRS_STRETCH);
@@ -1207,6 +1227,10 @@ __device__ inline int wave_class(const KArgs &a, long block, long catchment)
 #pragma unroll
     for (int i = 0; i < 10; ++i)
         wild = wild || (__builtin_bit_cast(unsigned long long, p[i]) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+    // ... or a share that is none: a drain fraction D or an overland share H outside [0, 1], a negative rain factor T hand
+    // the reservoirs NEGATIVE inflows, and what the reference's clamps make of those (structure.py:429-450) only its
+    // own operation order reproduces (round 4: D = 300 with a soil of half a millimetre, fast mode off by a factor)
+    wild = wild || !(p[3] >= 0.0 && p[3] <= 1.0) || !(p[2] >= 0.0 && p[2] <= 1.0) || !(p[0] >= 0.0);
     // ... and a caller's INITIAL states the fast arithmetic is not made for: a NaN, an infinity, a negative volume (the
     // reference's clamps and compares decide what follows), or soil so far above its capacity that s' = S tot / Z
     // starts beyond the 0.5 the guard class stops at (tot / Z <= 1 from the first wet step on: the filling clamps)

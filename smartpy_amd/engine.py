@@ -93,7 +93,8 @@ def variant_classes(params, delta_sec, initial=None, area=None):
     """Which arithmetic variant of the fast kernels a parameter row needs -- the rules of wave_class() in
     csrc/smart_fast_model.h: 0 regular, 1 stiff (some k*3600 < dt: clamps / river rule reachable), 2 guarded
     (S outside [0, 0.5], C < 0 or Z <= 0), 3 ill-conditioned (dt / (RK*3600) > 2, the river: literal arithmetic) --
-    and any row with a NaN or an infinite parameter, for the literal arithmetic to decide what comes of it; likewise a
+    and any row with a NaN or an infinite parameter, or a share that is none (D or H outside [0, 1], T < 0), for the
+    literal arithmetic to decide what comes of it; likewise a
     row whose INITIAL states (initial [C, N, 12] or [N, 12], with the catchments' areas) hold a NaN, an infinity, a
     negative volume, or soil so far above its capacity that S * sum(levels) / Z starts beyond 0.5 or H * sum(levels) / Z
     beyond 1 (in any catchment)."""
@@ -103,6 +104,9 @@ def variant_classes(params, delta_sec, initial=None, area=None):
     cls[~((params[:, 4] >= 0.0) & (params[:, 4] <= 0.5) & (params[:, 1] >= 0.0) & (params[:, 5] > 0.0))] = 2
     cls[~(k[:, 3] >= 0.5 * delta_sec)] = 3
     cls[~torch.isfinite(params).all(dim=1)] = 3
+    # shares that are none (D or H outside [0, 1], a negative T): negative inflows, the reference's clamps -- literal too
+    cls[~((params[:, 3] >= 0.0) & (params[:, 3] <= 1.0) & (params[:, 2] >= 0.0) & (params[:, 2] <= 1.0) &
+          (params[:, 0] >= 0.0))] = 3
     if initial is not None:
         st = initial.reshape(-1, params.shape[0], 12)
         ar = torch.as_tensor(area, dtype=torch.float64, device=params.device).reshape(-1, 1)

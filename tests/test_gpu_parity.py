@@ -1017,6 +1017,28 @@ def test_randomized_wide_parameter_ranges(eng):
     assert seen & {'smart_fast_intervals_states', 'smart_fast_steps_states'}, seen
 
 
+def test_rows_with_shares_that_are_none_take_the_literal_arithmetic(eng):
+    """D = 300 (a drain FRACTION) with a soil of half a millimetre hands the quick reservoir large negative inflows; what the
+    reference's clamps make of them the fast arithmetic does not reproduce (found through the hook: off by a factor).  Such
+    rows -- D or H outside [0, 1], T < 0 -- are class 3: the literal model inside the fast launch."""
+    rng = np.random.default_rng(77)
+    T, gap = 24 * 120, 24
+    rain = rng.gamma(0.5, 2.0, T) * (rng.random(T) < 0.3)
+    peva = np.where(rain > 0, 0.0, rng.uniform(0.0, 0.2, T) * (rng.random(T) < 0.6))
+    params = lhs_oracle.lhs_params(130, seed=5)
+    params[5] = [1.0, 0.2, 0.2, 300.0, 0.3, 0.5, 2000.0, 200.0, 20000.0, 20.0]
+    params[70, 3], params[71, 2], params[72, 0], params[73, 3] = 1.7, 1.2, -0.3, -0.2
+    odd = [5, 70, 71, 72, 73]
+    fast = eng.run_ensemble(params, forcing_of(rain, peva), 2.3e8, 3600.0, 0, gap)
+    assert 'smart_fast_illcond' in fast._prepared.describe()
+    d1, g1, _ = so.run_batch(2.3e8, 3600.0, T, 0, rain, peva, params, None, so.REPORT_SUMMARY, gap, want_final=True)
+    got = fast.discharge.cpu().numpy()
+    # (the step's bits; the interval mean in the fast launch's summation order, not numpy's pairwise one)
+    assert excess(got[odd], d1[odd], 1e-13) <= 1.0 and excess(fast.gw.cpu().numpy()[odd], g1[odd], 1e-12, top=1.0) <= 1.0
+    rest = np.setdiff1d(np.arange(130), odd)
+    assert excess(got[rest], d1[rest], REL_FAST) <= 1.0
+
+
 def test_ill_conditioned_rows_with_soil_above_capacity(eng):
     """Round 4's fuzzer (tools/debug/fuzz_wide.py, seeds 9001 / 9040 / 9055) found rows of class 3 whose fast-mode
     results left the literal kernel's by 1e-5 (and, amplified by the river, by 1e-3): a negative C had left the second
@@ -1254,6 +1276,17 @@ def test_pair_blocks_are_bit_identical_to_the_threaded_chunks(eng, monkeypatch, 
     for key, got in outs.items():
         for a, b in zip(got, outs['1', '0']):
             assert bits_equal(a, b), key
+    if report == 'summary' and gap % 4 == 0:    # the models with the final state vector: pair blocks of their own
+        fin = {}
+        for pairs in ('1', '0'):
+            monkeypatch.setenv('SMART_PAIR_BLOCKS', pairs)
+            q = eng.run_ensemble(params, forcing_of(rain, peva), 2.1e8, 3600.0, W, gap, obs=obs, gw_obs=0.2, report=report,
+                                 want_final=True)
+            assert 'smart_fast_steps_states' in q._prepared.describe()
+            fin[pairs] = [x.cpu().numpy().copy() for x in (q.discharge, q.gw, q.objfn, q.final_vars)]
+        for a, b in zip(fin['1'], fin['0']):
+            assert bits_equal(a, b)
+        assert bits_equal(fin['1'][0], outs['5', '1'][0])       # (and the final row does not change the discharge)
     d1, g1, _ = so.run_batch(2.1e8, 3600.0, T, W, rain, peva, params, None, rtype, gap, want_final=True)
     good = ~(params[:, 9] * 3600.0 < 0.5 * 3600.0)
     assert excess(outs['1', '1'][0][good], d1[good], REL_FAST) <= 1.0

@@ -34,9 +34,10 @@ def _kernel(name):
     return insts
 
 
-@pytest.mark.parametrize('kernel', ['smart_fast_steps', 'smart_fast_steps_raw'])
+@pytest.mark.parametrize('kernel', ['smart_fast_steps', 'smart_fast_steps_raw', 'smart_fast_steps_states'])
 def test_every_pair_block_lies_where_the_code_words_point(kernel):
-    stride = _stride()
+    split = kernel.endswith('_states')      # the models with the final state vector: larger blocks, no stream of records
+    stride = _stride('SMART_PS_STRIDE' if split else 'SMART_P_STRIDE')
     assert stride % 64 == 0
     insts = _kernel(kernel)
     at = {x['addr']: i for i, x in enumerate(insts)}
@@ -47,8 +48,9 @@ def test_every_pair_block_lies_where_the_code_words_point(kernel):
     for i in pairs:
         _check_instance(insts, at, i, stride)
     streams = [i for i in entries if i not in pairs]
-    assert len(streams) == 1
-    _check_gap_stream(insts, at, streams[0], _stride('SMART_E_STRIDE'))
+    assert len(streams) == (0 if split else 1)
+    if streams:
+        _check_gap_stream(insts, at, streams[0], _stride('SMART_E_STRIDE'))
 
 
 def _check_gap_stream(insts, at, i, stride):
@@ -114,7 +116,7 @@ def _check_instance(insts, at, i, stride):
             if insts[m]['op'].startswith(('v_', 's_branch', 's_cbranch')):
                 end = insts[m]['addr'] + insts[m]['size']
             m += 1
-        assert end <= b + stride
+        assert end <= b + stride or n == 39      # (behind the last block: the report blocks, not bound to its room)
         return k
 
     n = 0
