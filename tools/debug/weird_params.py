@@ -1,3 +1,6 @@
+"""Fast mode against the literal arithmetic through the hook (one sample per call) for a parameter vector far outside every
+sampling range, and for each of its values alone in an otherwise ordinary vector: which combination leaves the fast
+arithmetic (round 4: D = 300 with a soil of half a millimetre -- now a row of the literal class, wave_class)."""
 import os, sys
 sys.path.insert(0, '.')
 import numpy as np
