@@ -1231,6 +1231,18 @@ __device__ inline int wave_class(const KArgs &a, long block, long catchment)
     // the reservoirs NEGATIVE inflows, and what the reference's clamps make of those (structure.py:429-450) only its
     // own operation order reproduces (round 4: D = 300 with a soil of half a millimetre, fast mode off by a factor)
     wild = wild || !(p[3] >= 0.0 && p[3] <= 1.0) || !(p[2] >= 0.0 && p[2] <= 1.0) || !(p[0] >= 0.0);
+    // ... or a residence time that is none: with k <= 0 a reservoir grows by itself, step after step -- the reference's
+    // numbers explode in the reference's own way, and the stiff variant's clamps know nothing of it
+    wild = wild || !(p[6] > 0.0 && p[7] > 0.0 && p[8] > 0.0 && p[9] > 0.0);
+    // ... or a soil without capacity (Z <= 0: levels are quotients by it -- 0 / 0, x / 0 and what the reference's compares
+    // make of the NaNs and infinities)
+    wild = wild || !(p[5] > 0.0);
+    // ... or a discharge orders below what the rain would make (T < 0.01, or a soil of more than a metre that takes
+    // all of it): the fast arithmetic's sums carry the rain's last place -- 1e-15 mm a step -- which is 1e-6 of such
+    // a row's small values
+    wild = wild || !(p[0] >= 0.01) || !(p[5] <= 1.0e3);
+    // ... or a soil of less than a millimetre, which every rainy step overflows (met with C < 0: a NaN on one side only)
+    wild = wild || !(p[5] >= 1.0);
     // ... and a caller's INITIAL states the fast arithmetic is not made for: a NaN, an infinity, a negative volume (the
     // reference's clamps and compares decide what follows), or soil so far above its capacity that s' = S tot / Z
     // starts beyond the 0.5 the guard class stops at (tot / Z <= 1 from the first wet step on: the filling clamps)

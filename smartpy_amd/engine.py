@@ -93,7 +93,7 @@ def variant_classes(params, delta_sec, initial=None, area=None):
     """Which arithmetic variant of the fast kernels a parameter row needs -- the rules of wave_class() in
     csrc/smart_fast_model.h: 0 regular, 1 stiff (some k*3600 < dt: clamps / river rule reachable), 2 guarded
     (S outside [0, 0.5], C < 0 or Z <= 0), 3 ill-conditioned (dt / (RK*3600) > 2, the river: literal arithmetic) --
-    and any row with a NaN or an infinite parameter, or a share that is none (D or H outside [0, 1], T < 0), for the
+    and any row with a NaN or an infinite parameter, or a share or a residence time that is none (D or H outside [0, 1], T < 0, a k <= 0), for the
     literal arithmetic to decide what comes of it; likewise a
     row whose INITIAL states (initial [C, N, 12] or [N, 12], with the catchments' areas) hold a NaN, an infinity, a
     negative volume, or soil so far above its capacity that S * sum(levels) / Z starts beyond 0.5 or H * sum(levels) / Z
@@ -107,6 +107,10 @@ def variant_classes(params, delta_sec, initial=None, area=None):
     # shares that are none (D or H outside [0, 1], a negative T): negative inflows, the reference's clamps -- literal too
     cls[~((params[:, 3] >= 0.0) & (params[:, 3] <= 1.0) & (params[:, 2] >= 0.0) & (params[:, 2] <= 1.0) &
           (params[:, 0] >= 0.0))] = 3
+    cls[~(params[:, 6:10] > 0.0).all(dim=1)] = 3      # ... and residence times that are none (k <= 0)
+    cls[~(params[:, 5] > 0.0)] = 3                    # ... and a soil without capacity (Z <= 0: quotients by it)
+    cls[~(params[:, 0] >= 0.01) | ~(params[:, 5] <= 1.0e3)] = 3   # ... and a discharge orders below the rain's
+    cls[~(params[:, 5] >= 1.0)] = 3                   # ... and a soil of less than a millimetre
     if initial is not None:
         st = initial.reshape(-1, params.shape[0], 12)
         ar = torch.as_tensor(area, dtype=torch.float64, device=params.device).reshape(-1, 1)
