@@ -15,7 +15,9 @@ vary = bench.hourly_varying_forcing(base)
 T, W = base.shape[0], 8760
 obs = torch.rand(T // 24, dtype=torch.float64, device=dev) + 0.5
 params = torch.as_tensor(latin_hypercube(n, Parameters().ranges, seed=2718), device=dev)
-p = engine.prepare_ensemble(params, vary, bench.AREA, 3600.0, W, 24, extra=bench.EXTRA, obs=obs, gw_obs=0.12667)
+store = not (len(sys.argv) > 3 and sys.argv[3] == 'objectives')      # third argument 'objectives': no discharge matrix
+p = engine.prepare_ensemble(params, vary, bench.AREA, 3600.0, W, 24, extra=bench.EXTRA, obs=obs, gw_obs=0.12667,
+                            want_discharge=store)
 print(p.describe())
 for _ in range(reps):
     torch.cuda.synchronize()

@@ -131,6 +131,21 @@ turns)
       echo -n "$(basename $f .so | sed s/libsmart_amd_//): "; python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-strong 2>/dev/null | tail -1 | python tools/bench_digest.py | grep " ms" | awk '{printf "%s %s | ", $1, $2}'; echo
     done; done 2>&1 | tee gpurun_out/wet_ab.log
     ;;
+icache) # instruction-cache requests / misses of the time-loop kernels (the pair blocks are 84 KB of code an instance)
+    export TMPDIR=/tmp
+    run() { tag=$1; shift
+      rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVES --kernel-trace --output-format csv -d gpurun_out/icache_$tag -o pmc -- python3 "$@" > gpurun_out/icache_$tag.log 2>&1
+      echo "== $tag ($*) rc=$?"; grep " ms" gpurun_out/icache_$tag.log | sort -n | head -2 | tr '\n' ' '; echo
+      python3 tools/pmc_digest.py gpurun_out/icache_$tag; }
+    ( run steps_1e6 tools/debug/flat_only.py 1000000 3
+      run steps_1e5 tools/debug/flat_only.py 100000 6
+      export SMART_PAIR_BLOCKS=0
+      run threaded_1e6 tools/debug/flat_only.py 1000000 3
+      run threaded_1e5 tools/debug/flat_only.py 100000 6
+      unset SMART_PAIR_BLOCKS
+      run intervals_1e6 bench.py --config 4 --steps 3 --warmup 1 --no-cpu-baseline --no-flat --no-strong
+      run intervals_1e5 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-flat --no-strong ) 2>&1 | tee gpurun_out/icache.log
+    ;;
 *)
     echo "unknown stage $STAGE"; exit 2
     ;;
