@@ -81,7 +81,7 @@ __device__ __forceinline__ void raise_status(const KArgs &a, int bit)
 
 
 #ifndef SMART_NT_STORE
-#define SMART_NT_STORE 0
+#define SMART_NT_STORE 1
 #endif
 #ifndef SMART_IV_DEFER
 #define SMART_IV_DEFER 0 // interval / run engine: 1 = a dry interval defers its evaporation demand to the next wet one (measured:

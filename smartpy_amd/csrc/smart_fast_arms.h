@@ -423,6 +423,16 @@
 // constant the moments are taken about (s85: is the next report number 0?); the discharge through the lane's row pointer;
 // the moments (e, w in s[80:83], requested when the interval began); `after`: what the run keeps of the interval.
 #define SMART_P_REPORT(value, after) SMART_P_REPORT_X(value, after, "s[80:81]", "s[82:83]", "s83")
+// (the discharge matrix is written once and read by another kernel, if at all: `nt` keeps it from displacing what the L2
+// holds for the loop -- 1 % of a leg, profiles/r04_ab_store_and_icache.txt)
+#ifndef SMART_STORE_NT
+#define SMART_STORE_NT 1
+#endif
+#if SMART_STORE_NT
+#define SMART_STORE_MOD " nt"
+#else
+#define SMART_STORE_MOD ""
+#endif
 #define SMART_P_REPORT_X(value, after, e, w, whi)                                                                      \
     "s_cmp_eq_u32 %[rep], 0\n\t"                                                                                       \
     "s_cbranch_scc1 96f\n\t" value "s_cmp_eq_u32 s85, 0\n\t"                                                           \
@@ -432,7 +442,7 @@
     "93:\n\t"                                                                                                          \
     "s_cmp_eq_u32 %[sto], 0\n\t"                                                                                       \
     "s_cbranch_scc1 97f\n\t"                                                                                           \
-    "global_store_dwordx2 %[row], %[rv], off\n\t"                                                                      \
+    "global_store_dwordx2 %[row], %[rv], off" SMART_STORE_MOD "\n\t"                                                     \
     "v_lshl_add_u64 %[row], %[ld], 3, %[row]\n\t"                                                                      \
     "97:\n\t"                                                                                                          \
     "s_cmp_eq_u32 %[hob], 0\n\t"                                                                                       \
@@ -527,7 +537,7 @@
 // deviation carries the missing-observation mark (its upper word: one scalar compare), the sum of the outflows.
 // 18 blocks, SMART_E_STRIDE bytes apart.  After a rain arm -- which ends at 4 mod 8 -- and ahead of one an s_nop: the
 // reports and the other arms on the 8-byte boundary.
-#define SMART_E_STORE "global_store_dwordx2 %[row], %[acc], off\n\tv_lshl_add_u64 %[row], %[ld], 3, %[row]\n\t"
+#define SMART_E_STORE "global_store_dwordx2 %[row], %[acc], off" SMART_STORE_MOD "\n\tv_lshl_add_u64 %[row], %[ld], 3, %[row]\n\t"
 #define SMART_E_MOMENTS(e, w, whi) SMART_R_MOMENTS("%[acc]", e, w, whi)
 #define SMART_E_SUM "v_add_f64 %[qtot], %[qtot], %[acc]\n\t"
 // rep(e, w, whi): the report text of a step (the caller composes it from the three pieces above)

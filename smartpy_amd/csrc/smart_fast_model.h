@@ -1237,10 +1237,10 @@ __device__ inline int wave_class(const KArgs &a, long block, long catchment)
     // ... or a soil without capacity (Z <= 0: levels are quotients by it -- 0 / 0, x / 0 and what the reference's compares
     // make of the NaNs and infinities)
     wild = wild || !(p[5] > 0.0);
-    // ... or a discharge orders below what the rain would make (T < 0.01, or a soil of more than a metre that takes
+    // ... or a discharge orders below what the rain would make (T < 0.2, or a soil of more than a metre that takes
     // all of it): the fast arithmetic's sums carry the rain's last place -- 1e-15 mm a step -- which is 1e-6 of such
     // a row's small values
-    wild = wild || !(p[0] >= 0.01) || !(p[5] <= 1.0e3);
+    wild = wild || !(p[0] >= 0.2) || !(p[5] <= 1.0e3);
     // ... or a soil of less than a millimetre, which every rainy step overflows (met with C < 0: a NaN on one side only)
     wild = wild || !(p[5] >= 1.0);
     // ... and a caller's INITIAL states the fast arithmetic is not made for: a NaN, an infinity, a negative volume (the

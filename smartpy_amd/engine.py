@@ -109,7 +109,7 @@ def variant_classes(params, delta_sec, initial=None, area=None):
           (params[:, 0] >= 0.0))] = 3
     cls[~(params[:, 6:10] > 0.0).all(dim=1)] = 3      # ... and residence times that are none (k <= 0)
     cls[~(params[:, 5] > 0.0)] = 3                    # ... and a soil without capacity (Z <= 0: quotients by it)
-    cls[~(params[:, 0] >= 0.01) | ~(params[:, 5] <= 1.0e3)] = 3   # ... and a discharge orders below the rain's
+    cls[~(params[:, 0] >= 0.2) | ~(params[:, 5] <= 1.0e3)] = 3   # ... and a discharge orders below the rain's
     cls[~(params[:, 5] >= 1.0)] = 3                   # ... and a soil of less than a millimetre
     if initial is not None:
         st = initial.reshape(-1, params.shape[0], 12)

@@ -437,12 +437,12 @@ def test_rows_are_classified_and_grouped_by_arithmetic_variant():
     # ... or a share that is none (round 4): D or H outside [0, 1], a negative T -- negative inflows, the reference's clamps
     q = lhs_oracle.lhs_params(96, seed=13)
     for row, (col, val) in enumerate([(3, 300.0), (3, -0.1), (2, 1.5), (2, -1e-9), (0, -0.5), (6, -3.0), (8, 0.0),
-                                      (5, 0.0), (0, 0.001), (5, 2.0e4), (5, 0.5), (3, 1.0), (2, 1.0)]):
+                                      (5, 0.0), (0, 0.15), (5, 2.0e4), (5, 0.5), (3, 1.0), (2, 1.0)]):
         q[row * 7, col] = val
     got = engine.variant_classes(torch.from_numpy(q), 3600.0).numpy()
     odd = [0, 7, 14, 21, 28, 35, 42, 49, 56, 63, 70]  # (the bounds of the shares themselves are fine; a k or a Z <= 0 is not)
     assert (got[odd] == 3).all() and (np.delete(got, odd) == 0).all()
-    # (... and T < 0.01 or Z > 1 m, rows 56 and 63: discharges orders below the rain's, where the last place of
+    # (... and T < 0.2 or Z > 1 m, rows 56 and 63: discharges orders below the rain's, where the last place of
     # the fast arithmetic's sums shows; Z < 1 mm, row 70)
     # ... and wild INITIAL states: a NaN, an infinity, a negative volume, soil so far above capacity that S tot / Z > 0.5
     q = lhs_oracle.lhs_params(64, seed=11)

@@ -43,6 +43,12 @@ worst = err.max(axis=1)
 bad = np.flatnonzero(worst > 1.0)
 c3 = cls == 3
 print('  (class 3 = the literal model in both launches: %d rows differ by more than the sums\' order: 1e-12 relative)' % int(((np.where(both_nan, 0.0, np.abs(a - b) / (1e-12 * np.abs(b) + 1e-300)) > 1.0).any(axis=1) & c3).sum()))
+with np.errstate(invalid='ignore', divide='ignore'):
+    d3 = np.where(both_nan | (a == b), 0.0, np.abs(a - b) / (1e-12 * np.abs(b) + 1e-300))
+for i in np.flatnonzero((np.where(np.isnan(d3), np.inf, d3) > 1.0).any(axis=1) & c3)[:6]:
+    k = int(np.nanargmax(np.where(np.isnan(d3[i]), np.inf, d3[i])))
+    print('  class-3 row %d: report %d fast %r literal %r (row peak %.3g)  params %s' % (
+        i, k, a[i, k], b[i, k], top[i, 0], np.array2string(p[i], precision=6)))
 bad = np.flatnonzero((worst > 1.0) & ~c3)
 print('seed %d: %d rows, classes %s; rows beyond 1e-9 relative / 1e-12 of the row\'s peak: %d' % (
     seed, n, np.bincount(cls, minlength=4).tolist(), len(bad)))
