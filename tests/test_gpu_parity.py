@@ -1039,6 +1039,55 @@ def test_rows_with_shares_that_are_none_take_the_literal_arithmetic(eng):
     assert excess(got[rest], d1[rest], REL_FAST) <= 1.0
 
 
+def adversarial_rows(rng, n):
+    """One to four of a row's ten values thrown far out of the sampling ranges (x 1..1000 above the upper bound, down to
+    1e-4 of the lower, negative, or zero), the others ordinary (tools/debug/adversarial_params.py)."""
+    lo = np.array([0.9, 0.0, 0.0, 0.0, 0.0, 15.0, 1.0, 48.0, 1200.0, 1.0])
+    hi = np.array([1.1, 1.0, 0.3, 1.0, 0.013, 150.0, 240.0, 1440.0, 4800.0, 96.0])
+    p = lo + (hi - lo) * rng.random((n, 10))
+    for i in range(n):
+        for j in rng.choice(10, size=int(rng.integers(1, 5)), replace=False):
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                p[i, j] = hi[j] * 10.0 ** rng.uniform(0.0, 3.0)
+            elif kind == 1:
+                p[i, j] = max(lo[j], 1e-3) * 10.0 ** -rng.uniform(0.0, 4.0)
+            elif kind == 2:
+                p[i, j] = -abs(p[i, j]) * 10.0 ** rng.uniform(-2.0, 1.0)
+            else:
+                p[i, j] = 0.0
+    return p
+
+
+@pytest.mark.parametrize('seed', [26, 30])
+def test_adversarial_parameter_rows_against_the_oracle(eng, seed):
+    """Round 4's adversarial fuzz (profiles/r04_fuzz.txt): rows the fast arithmetic is not made for -- a share, a residence
+    time or a soil that is none, discharges orders below the rain's (T < 0.2, Z > 1 m) -- are rows of the literal class
+    (smart_fast_model.h wave_class = engine.variant_classes), so that a fast launch stays within its tolerance of the
+    reference-exact oracle whatever the parameters; NaNs and infinities where the oracle has them.  (Seeds 26 and 30 had
+    rows beyond it before the last rule.)"""
+    rng = np.random.default_rng(seed)
+    T, gap, n = 24 * 200, 24, 4096
+    rain = rng.gamma(0.5, 3.0, T) * (rng.random(T) < 0.35)
+    peva = np.where(rain > 0, 0.0, rng.uniform(0.0, 0.3, T) * (rng.random(T) < 0.6))
+    p = adversarial_rows(rng, n)
+    import torch
+    cls = eng.variant_classes(torch.as_tensor(p), 3600.0).numpy()
+    assert all((cls == c).sum() > 50 for c in range(4)), np.bincount(cls, minlength=4)
+    fast = eng.run_ensemble(p, forcing_of(rain, peva), 2.0e8, 3600.0, 0, gap)
+    got = fast.discharge.cpu().numpy()
+    want, _, _ = so.run_batch(2.0e8, 3600.0, T, 0, rain, peva, p, None, so.REPORT_SUMMARY, gap)
+    finite = np.isfinite(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[np.isinf(want)], want[np.isinf(want)])
+    rows = finite.all(axis=1)
+    assert rows.sum() > 0.5 * n
+    # (rows with a NaN or an infinity somewhere: their finite values next to the row's largest finite one)
+    with np.errstate(invalid='ignore'):
+        top = np.nanmax(np.where(finite, np.abs(want), 0.0), axis=1, keepdims=True)
+    g, w = np.where(finite, got, 0.0), np.where(finite, want, 0.0)
+    assert excess(g, w, REL_FAST, top=top, top_frac=1e-12) <= 1.0
+
+
 def test_ill_conditioned_rows_with_soil_above_capacity(eng):
     """Round 4's fuzzer (tools/debug/fuzz_wide.py, seeds 9001 / 9040 / 9055) found rows of class 3 whose fast-mode
     results left the literal kernel's by 1e-5 (and, amplified by the river, by 1e-3): a negative C had left the second
