@@ -1075,6 +1075,9 @@ def test_adversarial_parameter_rows_against_the_oracle(eng, seed):
     cls = eng.variant_classes(torch.as_tensor(p), 3600.0).numpy()
     assert all((cls == c).sum() > 50 for c in range(4)), np.bincount(cls, minlength=4)
     fast = eng.run_ensemble(p, forcing_of(rain, peva), 2.0e8, 3600.0, 0, gap)
+    # (the host's classes grouped the rows; a wavefront whose device-side class -- wave_class -- is another one would have
+    # met a kernel that was not planned for it and said so in the status word)
+    assert fast._prepared.status() == 0 and fast._prepared.describe().count('smart_fast_') == 4
     got = fast.discharge.cpu().numpy()
     want, _, _ = so.run_batch(2.0e8, 3600.0, T, 0, rain, peva, p, None, so.REPORT_SUMMARY, gap)
     finite = np.isfinite(want)
