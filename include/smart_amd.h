@@ -51,7 +51,9 @@ extern "C" {
                              /* wavefronts holding a sample with delta_sec / (k * 3600) > 2 (where the  */
                              /* reference's explicit update amplifies rounding differences) run the     */
                              /* literal arithmetic instead, and so do rows with a NaN or an infinite    */
-                             /* parameter.  The FORCING must be finite in this mode: what the           */
+                             /* parameter or one that is none (D or H outside [0, 1], a k <= 0,         */
+                             /* T < 0.2, Z outside [1 mm, 1 m]: smart_fast_model.h wave_class).         */
+                             /* The FORCING must be finite in this mode: what the                       */
                              /* reference's branches make of a NaN in it (structure.py:359, :409-419)   */
                              /* only SMART_MATH_LITERAL reproduces -- a fast launch that meets one      */
                              /* raises SMART_STATUS_NONFINITE_FORCING                                   */
@@ -75,7 +77,8 @@ extern "C" {
 #define SMART_PLAN_CLASS_STIFF 0x02      /* some k*3600 < delta_sec: clamps (structure.py:429-450) and the river's */
                                          /* 95 % rule (:492-496) are reachable                                     */
 #define SMART_PLAN_CLASS_GUARD 0x04      /* S, C or Z outside those ranges: the leak guards (:383,390,397) matter  */
-#define SMART_PLAN_CLASS_ILLCOND 0x08    /* delta_sec / (RK*3600) > 2 (the river): run in the literal arithmetic   */
+#define SMART_PLAN_CLASS_ILLCOND 0x08    /* delta_sec / (RK*3600) > 2 (the river), or a parameter that is none     */
+                                         /* (SMART_MATH_FAST above): run in the literal arithmetic                 */
 #define SMART_PLAN_FORCING_PIECEWISE 0x10 /* a catchment whose forcing is constant within every report interval    */
 #define SMART_PLAN_FORCING_VARYING 0x20   /* a catchment whose forcing varies from step to step                    */
 #define SMART_PLAN_FORCING_RUNS 0x80      /* a catchment whose forcing is constant over runs of k steps, k >= 2 a  */
