@@ -31,7 +31,7 @@ UNITS = {
     'smart_hostio.cpp': ['-pthread'],      # host only: the sampling-database writer
 }
 COMMON = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-fno-gpu-rdc', '-Wall']
-DEPS = ['smart_device.h', 'smart_literal_model.h', 'smart_fast_model.h', 'smart_fast_arms.h', 'smart_fast_entry.h', os.path.join('..', '..', 'include', 'smart_amd.h')]
+DEPS = ['smart_device.h', 'smart_literal_model.h', 'smart_literal_lanes.h', 'smart_fast_model.h', 'smart_fast_arms.h', 'smart_fast_entry.h', os.path.join('..', '..', 'include', 'smart_amd.h')]
 
 
 def hipcc():

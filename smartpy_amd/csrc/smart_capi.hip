@@ -803,7 +803,8 @@ static int run(const SmartEnsemble *e, bool literal_recip = false)
             const size_t lds = x.per_simd <= 3 ? lds_for_residency(d, l.k, 4 * x.per_simd) : 0;
             return launch_kernel(l.k, a_sliced, dim3((unsigned)(a.seg_blocks * n_seg), 1), lds, st);
         }
-        return launch_kernel(l.k, a, grid, 0, st);
+        // (the ill-conditioned rows: one sample per DPP row, sixteen workgroups per block of 64 samples)
+        return launch_kernel(l.k, a, l.k == kIllCond ? dim3(grid.x * kIllCondWaves, grid.y) : grid, 0, st);
     };
     if (n_todo == 1) {
         HIP_TRY(launch(x.todo[0], s));

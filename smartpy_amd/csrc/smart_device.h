@@ -133,6 +133,7 @@ __device__ __forceinline__ void raise_status(const KArgs &a, int bit)
 #endif
 
 constexpr int kWave = 64;
+constexpr int kIllCondWaves = 16; // workgroups per block of 64 samples of the kernels that take one sample per DPP row
 
 // NaN test on the bit pattern (missing observation / absent constraint): survives -fno-honor-nans, and for the
 // wave-uniform values it is applied to it is scalar integer work.
@@ -245,6 +246,12 @@ struct chunk_hook : std::false_type {};
 template <class Model>
 struct chunk_hook<Model, std::enable_if_t<Model::kChunkHook>> : std::true_type {};
 
+// ... and does its step come in two forms chosen per chunk (LiteralLanesModel::quick)?
+template <class Model, class = void>
+struct chunk_modes : std::false_type {};
+template <class Model>
+struct chunk_modes<Model, std::enable_if_t<Model::kChunkModes>> : std::true_type {};
+
 // The rain excess of the kChunk steps of a chunk is evaluated together, ahead of the steps (independent FMAs that
 // fill issue slots while the first step's dependent chain starts).
 template <class Model, class Body, class ChunkEnd>
@@ -269,9 +276,24 @@ __device__ __forceinline__ void time_loop_chunked(const Model &m, const double2 
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
             ex[j] = m.excess(cur[j].x, cur[j].y);
+        if constexpr (chunk_modes<Model>::value) {
+            // the model's step comes in two forms and begin_chunk() has just said which one this chunk takes (wave-uniform,
+            // unchanged by the steps): decided here, once, the four steps carry no test of their own -- a lone wavefront
+            // pays 16 cycles for a branch it does not take (profiles/r04_microbench_lone.txt)
+            if (__builtin_expect(m.quick, 1)) {
 #pragma unroll
-        for (int j = 0; j < kChunk; ++j)
-            body(cur[j], ex[j]);
+                for (int j = 0; j < kChunk; ++j)
+                    body(cur[j], ex[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kChunk; ++j)
+                    body(cur[j], ex[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kChunk; ++j)
+                body(cur[j], ex[j]);
+        }
         chunk_end();
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
@@ -535,6 +557,27 @@ __device__ __forceinline__ LaneCtx lane_ctx(const KArgs &a, long block, long cat
 
 __device__ __forceinline__ LaneCtx lane_ctx(const KArgs &a) { return lane_ctx(a, (long)blockIdx.x, (long)blockIdx.y); }
 
+// ... for the models that spread ONE sample over the sixteen lanes of a DPP row (smart_literal_lanes.h): a block of 64
+// samples is sixteen wavefronts, wavefront `sub` of the block takes its samples 4 sub .. 4 sub + 3, one per row, and
+// the first lane of a row does the row's stores
+__device__ __forceinline__ LaneCtx lane_ctx_rows(const KArgs &a, long block, long catchment, int sub)
+{
+    LaneCtx x;
+    x.lane = threadIdx.x;
+    x.c = catchment;
+    x.n = block * kWave + sub * 4 + (x.lane >> 4);
+    x.live = x.n < a.N && (x.lane & 15) == 0;
+    if (x.n >= a.N)
+        x.n = a.N - 1;
+    return x;
+}
+
+template <class Model, class = void>
+struct lanes_per_sample : std::integral_constant<int, 1> {};
+template <class Model>
+struct lanes_per_sample<Model, std::enable_if_t<(Model::kLanesPerSample > 1)>>
+    : std::integral_constant<int, Model::kLanesPerSample> {};
+
 // parameters, derived constants and the initial states of structure.py:97-140 (educated guess / given states)
 template <class Model>
 __device__ __forceinline__ void init_model(const KArgs &a, const LaneCtx &x, Model &m)
@@ -710,13 +753,15 @@ __device__ __forceinline__ void write_results(const KArgs &a, const LaneCtx &x, 
         for (int i = 0; i < 8; ++i)
             op[i] = o[i];
     }
-    if (a.final_vars && x.live) {
+    if (a.final_vars) { // (wave-uniform; a model that spreads a sample over a row collects it with DPP: all lanes in)
         double v[19];
         m.get_vars(v, flows);
-        double *fp = a.final_vars + (x.c * a.N + x.n) * 19;
+        if (x.live) {
+            double *fp = a.final_vars + (x.c * a.N + x.n) * 19;
 #pragma unroll
-        for (int i = 0; i < 19; ++i)
-            fp[i] = v[i];
+            for (int i = 0; i < 19; ++i)
+                fp[i] = v[i];
+        }
     }
 }
 
@@ -730,9 +775,10 @@ __device__ __forceinline__ void write_results(const KArgs &a, const LaneCtx &x, 
 template <class Model, bool NP_MEAN>
 __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__restrict__ forcing,
                                              const double *__restrict__ obs_all, const double *__restrict__ ws_all,
-                                             double *lds, long block, long catchment)
+                                             double *lds, long block, long catchment, int sub = 0)
 {
-    const LaneCtx x = lane_ctx(a, block, catchment);
+    const LaneCtx x = lanes_per_sample<Model>::value == 16 ? lane_ctx_rows(a, block, catchment, sub)
+                                                           : lane_ctx(a, block, catchment);
     Model m;
     init_model(a, x, m);
     const double2 *__restrict__ f = forcing + x.c * a.T;

@@ -6,7 +6,7 @@
 // (tests/test_gpu_parity.py), which pins every branch and every operation order of the GPU path.
 //
 // This mode is the parity anchor, not the fast path: ~39 (wet) / 26 (dry) fp64 divisions per step.
-#include "smart_literal_model.h"
+#include "smart_literal_lanes.h"
 
 namespace smart {
 
@@ -22,18 +22,25 @@ __global__ __launch_bounds__(kWave) void smart_ensemble_literal(KArgs a, const d
 }
 
 // The kernel behind smartcpp.allsteps (smart_allsteps_hip: one sample, a latency chain of one wavefront): the same loop
-// with the divisions by per-sample constants through cached reciprocals + correction step -- the division's bits
-// (smart_literal_model.h, RECIP), a quarter fewer instructions per step.  The ensemble's literal mode above keeps the
-// true divisions: it is the anchor the reciprocal path is compared with.
-__global__ __launch_bounds__(kWave) void smart_ensemble_literal_recip(KArgs a, const double2 *__restrict__ forcing,
-                                                                      const double *__restrict__ obs,
-                                                                      const double *__restrict__ ws)
+// on LiteralLanesModel (smart_literal_lanes.h) -- the sample spread over the sixteen lanes of a DPP row, six layers and
+// five reservoirs one instruction each, the reference's sums as v_fmac_f64_dpp chains in the reference's order, the
+// divisions by per-sample constants through cached reciprocals + correction step: the division's bits, a third of
+// the instructions per step.  Grid: sixteen wavefronts per block of 64 samples, four samples each (one: a single
+// wavefront).  The ensemble's literal mode above keeps the true divisions, one sample per lane: it is the anchor this
+// form is compared with (tests/test_gpu_parity.py, tests/test_gpu_api.py).
+__global__ __launch_bounds__(kWave) void smart_ensemble_literal_rows(KArgs a, const double2 *__restrict__ forcing,
+                                                                     const double *__restrict__ obs,
+                                                                     const double *__restrict__ ws)
 {
     extern __shared__ double lds[];
+    const long block = (long)(blockIdx.x >> 4);
+    const int sub = (int)(blockIdx.x & 15u);
+    if (block * kWave + sub * 4 >= a.N)
+        return;
     if (a.np_mean)
-        run_ensemble<LiteralModelRecip, true>(a, forcing, obs, ws, lds, (long)blockIdx.x, (long)blockIdx.y);
+        run_ensemble<LiteralLanesModel, true>(a, forcing, obs, ws, lds, block, (long)blockIdx.y, sub);
     else
-        run_ensemble<LiteralModelRecip, false>(a, forcing, obs, ws, lds, (long)blockIdx.x, (long)blockIdx.y);
+        run_ensemble<LiteralLanesModel, false>(a, forcing, obs, ws, lds, block, (long)blockIdx.y, sub);
 }
 
 // smartcpp.onestep stand-in: n independent single steps (structure.py:200-264)
@@ -80,11 +87,11 @@ void launch_river(long n, const double *in, double *out, hipStream_t s)
     hipLaunchKernelGGL(smart_river_literal, dim3((unsigned)((n + kWave - 1) / kWave)), dim3(kWave), 0, s, n, in, out);
 }
 
-void launch_literal(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s, bool recip)
+void launch_literal(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s, bool rows)
 {
-    if (recip)
-        hipLaunchKernelGGL(smart_ensemble_literal_recip, grid, dim3(kWave), lds_bytes, s, a,
-                           reinterpret_cast<const double2 *>(a.forcing), a.obs, a.ws);
+    if (rows)
+        hipLaunchKernelGGL(smart_ensemble_literal_rows, dim3(grid.x * kIllCondWaves, grid.y), dim3(kWave), lds_bytes, s,
+                           a, reinterpret_cast<const double2 *>(a.forcing), a.obs, a.ws);
     else
         hipLaunchKernelGGL(smart_ensemble_literal, grid, dim3(kWave), lds_bytes, s, a,
                            reinterpret_cast<const double2 *>(a.forcing), a.obs, a.ws);
