@@ -792,6 +792,31 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
     const double inv_gap = 1.0 / (double)a.gap;
     Reporter rep;
     rep.init(a, x, obs_all, ws_all);
+    // a wavefront of the row form is alone on its SIMD and sits out every latency it meets: the observation of a report
+    // and its deviation are requested one report ahead (a report every step: one step of the model ahead)
+    constexpr bool kAhead = lanes_per_sample<Model>::value > 1;
+    if constexpr (kAhead)
+        rep.prime(a, 0);
+    const bool every_step = a.gap == 1; // (a mean over one value is the value: x / 1.0 == x, no division)
+
+    if constexpr (kAhead) {
+        if (every_step) {
+            // A report every step (a daily run with daily reports: BASELINE config 2's ill-conditioned rows), either
+            // report type -- the mean over one step is the step's outflow, and the groundwater sums of the reported rows
+            // are those of all rows -- as a loop of its own: step, report, nothing to count and nothing to branch on.
+            // (In the general loop below the report sits out of line behind `++k == len`: two taken branches and the
+            // counters' bookkeeping per step cost the lone wavefront as much as half a step of the model.)
+            double sink = 0.0, num1 = 0.0, den1 = 0.0;
+            long r1 = 0;
+            time_loop(m, f, a.T, [&](const double2 v, const double ex) {
+                m.step(v.x, v.y, ex, sink, num1, den1);
+                rep.emit_ahead(a, x, r1, m.q_out);
+                ++r1;
+            });
+            write_results(a, x, m, rep, num1 / den1, nullptr);
+            return;
+        }
+    }
 
     double num = 0.0, den = 0.0;         // groundwater sums over every step (summary, structure.py:191)
     double num_raw = 0.0, den_raw = 0.0; // ... over the reported rows only (raw, structure.py:194-195)
@@ -811,6 +836,8 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
             if (summary) {
                 if (NP_MEAN)
                     val = np_pairwise_lds(lds + x.lane, len) / (double)a.gap;
+                else if (kAhead && every_step)
+                    val = acc;
                 else
                     val = Model::kExactDivide ? acc / (double)a.gap : acc * inv_gap;
             } else {
@@ -818,7 +845,10 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
                 num_raw += m.q_gw;
                 den_raw += m.q_in;
             }
-            rep.emit(a, x, r, val);
+            if constexpr (kAhead)
+                rep.emit_ahead(a, x, r, val);
+            else
+                rep.emit(a, x, r, val);
             ++r;
             k = 0;
             len = a.gap;

@@ -74,9 +74,13 @@ __global__ __launch_bounds__(64) void per_lane(long N, long T, double area, doub
 }
 
 __global__ __launch_bounds__(64) void per_row(long N, long T, double area, double dt, const double *params,
-                                              const double2 *__restrict__ f, double *out, unsigned long long *cyc)
+                                              const double2 *__restrict__ f, double *out, unsigned long long *cyc, int pad,
+                                              unsigned *where)
 {
-    long n = (long)blockIdx.x * 4 + (threadIdx.x >> 4);
+    if ((int)blockIdx.x < pad) // (workgroups that return at once ahead of the working ones: the real grid's other classes)
+        return;
+    const long wg = (long)blockIdx.x - pad;
+    long n = wg * 4 + (threadIdx.x >> 4);
     const bool live = n < N && (threadIdx.x & 15) == 0;
     if (n >= N)
         n = N - 1;
@@ -99,8 +103,11 @@ __global__ __launch_bounds__(64) void per_row(long N, long T, double area, doubl
     if (live)
         for (int i = 0; i < kOut; ++i)
             out[n * kOut + i] = o[i];
-    if (threadIdx.x == 0)
-        cyc[blockIdx.x] = c1 - c0;
+    if (threadIdx.x == 0) {
+        cyc[wg] = c1 - c0;
+        where[wg] = (__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 20) |      // HW_REG_XCC_ID
+                    (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) & 0xfffff);      // HW_REG_HW_ID: SIMD 5:4, CU 11:8, SE 15:13
+    }
 }
 
 
@@ -180,6 +187,7 @@ int main(int argc, char **argv)
     }
     const long N = argc > 1 ? atol(argv[1]) : 1160, T = argc > 2 ? atol(argv[2]) : 4018;
     const double rk_hi = argc > 3 ? atof(argv[3]) : 12.0;
+    const int pad = argc > 5 ? atoi(argv[5]) : 0;
     const int mode = argc > 4 ? (!strcmp(argv[4], "wet") ? 1 : (!strcmp(argv[4], "dry") ? 2 : 0)) : 0; // every step wet / dry / as it comes
     const double area = 175.46e6, dt = 86400.0;
     const double lo[10] = {0.9, 0.0, 0.0, 0.0, 0.0, 15.0, 1.0, 48.0, 1200.0, 1.0};
@@ -203,6 +211,8 @@ int main(int argc, char **argv)
     CHECK(hipMalloc(&d_out_a, (size_t)N * kOut * 8));
     CHECK(hipMalloc(&d_out_b, (size_t)N * kOut * 8));
     CHECK(hipMalloc(&d_cyc, (size_t)blocks_b * 8));
+    unsigned *d_where;
+    CHECK(hipMalloc(&d_where, (size_t)blocks_b * 4));
     CHECK(hipMemcpy(d_par, params.data(), params.size() * 8, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_f, forcing.data(), forcing.size() * 8, hipMemcpyHostToDevice));
     CHECK(hipMemset(d_out_a, 0xff, (size_t)N * kOut * 8));
@@ -227,12 +237,27 @@ int main(int argc, char **argv)
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         report("per_lane", blocks_a, ms);
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(per_row, dim3((unsigned)blocks_b), dim3(64), 0, 0, N, T, area, dt, d_par, (const double2 *)d_f,
-                           d_out_b, d_cyc);
+        hipLaunchKernelGGL(per_row, dim3((unsigned)(blocks_b + pad)), dim3(64), 0, 0, N, T, area, dt, d_par, (const double2 *)d_f,
+                           d_out_b, d_cyc, pad, d_where);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         report("per_row", blocks_b, ms);
+    }
+    {   // how the working wavefronts of the row form were spread over the chip's SIMDs
+        std::vector<unsigned> w(blocks_b);
+        CHECK(hipMemcpy(w.data(), d_where, (size_t)blocks_b * 4, hipMemcpyDeviceToHost));
+        std::vector<unsigned> key(blocks_b);
+        for (long i = 0; i < blocks_b; ++i)
+            key[i] = ((w[i] >> 20) << 16) | (((w[i] >> 13) & 7) << 8) | (((w[i] >> 8) & 15) << 4) | ((w[i] >> 4) & 3);
+        std::sort(key.begin(), key.end());
+        long simds = 0, worst = 0, run = 0;
+        for (long i = 0; i < blocks_b; ++i) {
+            run = (i && key[i] == key[i - 1]) ? run + 1 : 1;
+            simds += run == 1;
+            worst = std::max(worst, run);
+        }
+        printf("per_row: %ld wavefronts (behind %d that return at once) on %ld SIMDs, at most %ld on one\n", blocks_b, pad, simds, worst);
     }
     std::vector<double> a((size_t)N * kOut), b((size_t)N * kOut);
     CHECK(hipMemcpy(a.data(), d_out_a, a.size() * 8, hipMemcpyDeviceToHost));
