@@ -46,7 +46,8 @@ HBM_PEAK_GBS = 8000.0           # same table
 N_SIMD = 256 * 4                # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9                # peak engine clock, same table
 VALU_ISSUE_CYCLES = 4           # a wave64 fp64 (or any vector) instruction occupies its SIMD for 4 cycles
-PARITY_GATE = 1e-6              # BASELINE.json: discharge <= 1e-6 relative against the CPU reference path
+PARITY_CONTRACT = 1e-6          # BASELINE.json: discharge <= 1e-6 relative against the CPU reference path
+PARITY_GATE = 1e-9              # what this run is held to: 1,000 x tighter (measured: 3e-12); non-zero exit above it
 GW_OBS = 0.12667
 
 
@@ -223,7 +224,7 @@ def cpu_baseline_and_parity(forcing, n_warm, gap, dt, device, budget_s=12.0):
     gw = got.gw.cpu().numpy()
     rel = float(np.max(np.abs(dis - want) / np.maximum(np.abs(want), 1e-300)))
     gw_abs = float(np.max(np.abs(gw - want_gw)))
-    parity = {'max_rel_discharge': rel, 'max_abs_gw_ratio': gw_abs, 'gate': PARITY_GATE,
+    parity = {'max_rel_discharge': rel, 'max_abs_gw_ratio': gw_abs, 'gate': PARITY_GATE, 'contract': PARITY_CONTRACT,
               'ok': bool(rel <= PARITY_GATE and gw_abs <= PARITY_GATE),
               'against': 'oracle/smart_oracle.c (reference operation order, libm pow, numpy summation order)',
               'rows': n, 'values': int(dis.size)}
@@ -268,7 +269,7 @@ def rank_evidence(device, launch_ms):
                     ranks=[mine])
     everyone = [None] * dist.get_world_size()
     dist.all_gather_object(everyone, mine)
-    return dict(lib, backend=dist.get_backend(), world_size=dist.get_world_size(),
+    return dict(lib, backend=sdist.data_backend(), group_backend=str(dist.get_backend()), world_size=dist.get_world_size(),
                 devices=[r['device'] for r in everyone], launch_ms_per_rank=[r['launch_ms'] for r in everyone],
                 ranks=everyone)
 
@@ -333,12 +334,17 @@ def main():
 
     # observations: the CPU twin's discharge of the "truth" parameter set x lognormal noise, 12 % NaN.
     # Input data of the benchmark, made before anything is timed by the same checker the cpu_baseline leg times (round 3
-    # took them from a run of the engine itself: circular)
-    from oracle import smart_oracle as so
-    truth = so.run_batch(AREA, dt, T, W, np.ascontiguousarray(forcing[:, 0]), np.ascontiguousarray(forcing[:, 1]),
-                         np.array([TRUTH]), EXTRA, so.REPORT_SUMMARY, gap, want_discharge=True)[0]
-    obs = truth[0] * np.exp(rng.normal(0.0, 0.2, R))
-    obs[rng.random(R) < 0.12] = np.nan
+    # took them from a run of the engine itself: circular) -- on RANK 0 ONLY, and broadcast (29 KB): the checker is a
+    # gcc-built library next to its source, and N ranks of a freshly pushed tree building and loading it side by side
+    # is a race the benchmark has no business running (round 4's advisor; oracle.smart_oracle.build() is atomic as well)
+    obs = None
+    if rank == 0:
+        from oracle import smart_oracle as so
+        truth = so.run_batch(AREA, dt, T, W, np.ascontiguousarray(forcing[:, 0]), np.ascontiguousarray(forcing[:, 1]),
+                             np.array([TRUTH]), EXTRA, so.REPORT_SUMMARY, gap, want_discharge=True)[0]
+        obs = truth[0] * np.exp(rng.normal(0.0, 0.2, R))
+        obs[rng.random(R) < 0.12] = np.nan
+    obs = sdist.broadcast_matrix(obs if rank == 0 else np.empty(0), src=0)
 
     store = not args.no_discharge and cfg in (2, 3)     # configs 4 and 5 gather objective functions only
     kw = dict(extra=EXTRA, math_mode=args.math, want_discharge=store, device=device)

@@ -22,9 +22,20 @@ _dp = ctypes.POINTER(ctypes.c_double)
 
 
 def build(force=False):
+    """Build libsmart_oracle.so with oracle/Makefile when it is missing or older than its source.  Atomic: the compiler
+    writes a name of this process's own and the finished file is renamed onto the library (os.replace), so that a
+    process that loads the library while another one builds it -- the ranks of a multi-GPU bench on a freshly pushed
+    tree, where the mtimes are arbitrary -- sees either the old file or the new one, never half of one.  A library
+    that is current is left alone (no `make -B`)."""
     src = os.path.join(_HERE, "smart_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libsmart_oracle.so"])
+        tmp = "libsmart_oracle.%d.tmp.so" % os.getpid()
+        try:
+            subprocess.check_call(["make", "-s", "-C", _HERE, "-B", tmp])
+            os.replace(os.path.join(_HERE, tmp), _SO)
+        finally:
+            if os.path.exists(os.path.join(_HERE, tmp)):
+                os.remove(os.path.join(_HERE, tmp))
     return _SO
 
 

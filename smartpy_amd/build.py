@@ -66,10 +66,18 @@ def build(force=False, verbose=False, extra_flags=(), lib_path=LIB):
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
             list(pool.map(subprocess.check_call, jobs))
     if force or _stale(lib_path, objs):
-        cmd = [cc, '-shared', '-fPIC', '-pthread', '--offload-arch=' + ARCH, '-o', lib_path] + objs
+        # linked under a name of this process's own, then renamed onto the library: a process that loads it meanwhile sees
+        # the old file or the new one, never half of one
+        tmp = '%s.%d.tmp' % (lib_path, os.getpid())
+        cmd = [cc, '-shared', '-fPIC', '-pthread', '--offload-arch=' + ARCH, '-o', tmp] + objs
         if verbose:
             print(' '.join(cmd))
-        subprocess.check_call(cmd)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, lib_path)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return lib_path
 
 

@@ -17,8 +17,18 @@ The helpers work on CPU tensors with the gloo backend too, which is how tests/te
 """
 import os
 
-import torch
-import torch.distributed as dist
+# RCCL between the processes of a node hands device memory from rank to rank through IPC handles, and the host driver
+# of the MI355X pool this was built on supports dmabuf IPC only: with the legacy mode left on, hipIpcGetMemHandle
+# fails ("invalid argument") and with it the first collective of any N > 1 run.  The pool's own environment exports
+# HSA_ENABLE_IPC_MODE_LEGACY=0 for that reason (the build notes say so; that, not a measurement of ours, decides it:
+# no run with more than one GPU was available to the builder).  The HSA runtime reads the variable when it starts,
+# i.e. at this process's first GPU call -- so it is set here, at import, ahead of anything that could make one, for
+# every way the ranks may have been started (torchrun, mpirun, srun, bench.py's own launcher).  A value the user set
+# stands.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch                            # noqa: E402
+import torch.distributed as dist        # noqa: E402
 
 
 def shard_bounds(n_rows, world_size, rank):
@@ -39,9 +49,34 @@ def env_world():
             int(os.environ.get('LOCAL_RANK', '0')))
 
 
+#: how device tensors travel in this process group: None = as the group's backend takes them (RCCL for device tensors);
+#: True = staged through the host over gloo, because two ranks of the group sit on ONE device, which RCCL refuses.
+#: Decided by init(); a group initialised elsewhere (the tests' own gloo groups) is read off its backend.
+_STAGED = None
+
+
+def device_identity(device):
+    """What tells one physical GPU from another across the processes of a job: host name + the device's UUID (the PCI
+    bus id where the runtime has no UUID to give).  Independent of how the launcher numbered or masked the devices."""
+    props = torch.cuda.get_device_properties(device)
+    uuid = str(getattr(props, 'uuid', '') or '')
+    return '%s/%s' % (os.uname().nodename, uuid or 'pci-%s' % getattr(props, 'pci_bus_id', device.index))
+
+
 def init(backend=None):
     """Initialise torch.distributed from the environment (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE).
-    Returns (rank, world_size, device).  backend defaults to nccl (= RCCL) when a GPU is visible, else gloo."""
+    Returns (rank, world_size, device).
+
+    With GPUs the group is created with BOTH backends (gloo for host tensors, RCCL for device tensors; RCCL's
+    communicator is only built by the first device collective), the ranks then tell each other which physical device
+    each of them sits on (host name + UUID, over gloo), and only if two of them share one -- a one-GPU box running the
+    N-rank code path -- are device tensors staged through the host instead of handed to RCCL, which refuses two ranks
+    on a device.  The decision does not look at WORLD_SIZE against device_count(): a launch with one visible device
+    per rank (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES per task, `srun --gpus-per-task=1`) or over several nodes has
+    more ranks than visible devices with every rank on a GPU of its own, and keeps RCCL.  `backend` /
+    SMART_DIST_BACKEND ('nccl' | 'gloo') overrides."""
+    global _STAGED
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # (see the top of the module; before the first GPU call)
     rank, world, local = env_world()
     backend = backend or os.environ.get('SMART_DIST_BACKEND') or None      # e.g. gloo: two ranks sharing one GPU
     use_gpu = torch.cuda.is_available()
@@ -51,15 +86,20 @@ def init(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        if backend is None and use_gpu and world > torch.cuda.device_count():
-            # more ranks than devices (a one-GPU box running the N-rank code path): RCCL refuses two ranks on one
-            # device, gloo stages the small result blocks through the host.  The bench line's `ranks.backend` says so.
-            import warnings
-            warnings.warn("smartpy_amd.distributed: %d ranks on %d device(s): collectives go through gloo, not RCCL"
-                          % (world, torch.cuda.device_count()))
-            backend = 'gloo'
-        # lazy communicator creation (no device_id): the first collective binds RCCL to the current device, set above
-        dist.init_process_group(backend=backend or ('nccl' if use_gpu else 'gloo'), rank=rank, world_size=world)
+        if backend is not None or not use_gpu:
+            backend = backend or 'gloo'
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            _STAGED = backend == 'gloo'
+        else:
+            # lazy communicator creation (no device_id): the first device collective binds RCCL to the current device
+            dist.init_process_group(backend='cpu:gloo,cuda:nccl', rank=rank, world_size=world)
+            where = [None] * world
+            dist.all_gather_object(where, device_identity(device))         # host objects: gloo
+            _STAGED = len(set(where)) < world
+            if _STAGED and rank == 0:
+                import warnings
+                warnings.warn("smartpy_amd.distributed: %d ranks on %d physical device(s): device tensors are staged "
+                              "through the host over gloo, not handed to RCCL" % (world, len(set(where))))
     return rank, world, device
 
 
@@ -68,8 +108,18 @@ def is_distributed():
 
 
 def _host_staged():
-    """gloo moves host memory: device tensors are staged through the CPU (test set-ups only; RCCL takes them as is)."""
-    return dist.get_backend() == 'gloo'
+    """Are device tensors staged through the CPU for the collectives (gloo moves host memory; test set-ups and ranks that
+    share a device only: RCCL takes device tensors as they are)?"""
+    if _STAGED is not None:
+        return _STAGED
+    return dist.get_backend() == 'gloo'        # a group somebody else initialised
+
+
+def data_backend():
+    """What carries the result blocks between the ranks: 'nccl' (= RCCL) or 'gloo'; None without a group."""
+    if not is_distributed():
+        return None
+    return 'gloo' if _host_staged() else 'nccl'
 
 
 def rank_world():
@@ -80,11 +130,14 @@ def rank_world():
 
 
 def barrier():
+    """Every rank has got here.  One small all-reduce in the memory the group's data path uses (a device tensor over
+    RCCL: the barrier then also orders behind the collectives queued on the device; a host tensor over gloo)."""
     if is_distributed():
-        if dist.get_backend() == 'nccl':
-            dist.barrier(device_ids=[torch.cuda.current_device()])
-        else:
-            dist.barrier()
+        t = torch.zeros(1, dtype=torch.float64,
+                        device='cpu' if _host_staged() else torch.device('cuda', torch.cuda.current_device()))
+        dist.all_reduce(t)
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
 
 
 def gather_rows(local, n_rows_total, out=None):
@@ -109,6 +162,64 @@ def gather_rows(local, n_rows_total, out=None):
         out = torch.empty((world * per,) + tail, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out[:n_rows_total].to(device)
+
+
+#: bytes the last collect_rows() moved through THIS rank's buffers (sent or received): what the tests hold the
+#: "discharge travels to rank 0 only" promise against
+last_collect_bytes = 0
+
+
+def collect_rows(local, n_rows_total, dst=0):
+    """Row blocks produced under shard_bounds() -> ONE host matrix [n_rows_total, ...] on rank `dst` (a numpy array of
+    local's dtype), None on the others.  Point to point, one block at a time into one staging buffer: rank r sends its
+    block and is done; rank dst never holds more than its own block plus one peer's on the device.
+
+    This is how the simulated series of MonteCarlo.run(save_sim=True) reach the rank that writes the database -- the
+    reference's MPI farm sends each series to the master only, too (montecarlo.py:211-231) -- where an all-gather
+    would put the whole [N, R] matrix (29 GB of fp64 at N = 1e6) on every GPU and every host."""
+    global last_collect_bytes
+    import numpy as np
+    last_collect_bytes = 0
+    if not is_distributed():
+        return local.detach().cpu().numpy()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    staged = _host_staged() or not local.is_cuda
+    mine = local.contiguous()
+    if staged:
+        mine = mine.cpu()
+    tail = tuple(mine.shape[1:])
+    if rank != dst:
+        lo, hi = shard_bounds(n_rows_total, world, rank)
+        if hi > lo:
+            dist.send(mine[:hi - lo].contiguous(), dst=dst)
+            last_collect_bytes = (hi - lo) * int(np.prod(tail, dtype=np.int64)) * mine.element_size()
+        return None
+    out = np.empty((n_rows_total,) + tail, dtype=torch.empty(0, dtype=mine.dtype).numpy().dtype)
+    per = -(-n_rows_total // world)
+    buf = torch.empty((per,) + tail, dtype=mine.dtype, device=mine.device)
+    for r in range(world):
+        lo, hi = shard_bounds(n_rows_total, world, r)
+        if hi <= lo:
+            continue
+        if r == rank:
+            out[lo:hi] = mine[:hi - lo].cpu().numpy()
+        else:
+            dist.recv(buf[:hi - lo], src=r)
+            out[lo:hi] = buf[:hi - lo].cpu().numpy()
+            last_collect_bytes += (hi - lo) * int(np.prod(tail, dtype=np.int64)) * mine.element_size()
+    return out
+
+
+def agree_or_raise(failure, device=None):
+    """All ranks get here; `failure` is this rank's exception (or None).  If ANY rank failed, EVERY rank raises, in this
+    call: the failed one its own exception, the others a SmartEngineError that says so -- no rank is left waiting in a
+    collective its failed peer never joins."""
+    from .engine import SmartEngineError
+    worst = max_over_ranks(1.0 if failure is not None else 0.0, device)
+    if failure is not None:
+        raise failure
+    if worst > 0.0:
+        raise SmartEngineError(-6, "smartpy_amd: another rank's launch failed; the gathered results would not be complete")
 
 
 def broadcast_matrix(matrix, src=0):
@@ -240,18 +351,25 @@ class ShardedEnsemble(object):
         return self._prep
 
 
-def max_over_ranks(value, device):
-    """Scalar max-reduce (timings)."""
+def _scalar_device(device=None):
+    """Where a one-number reduction lives: the host when the group stages through it, else the given (or current) GPU."""
+    if _host_staged() or not torch.cuda.is_available():
+        return torch.device('cpu')
+    return device if device is not None else torch.device('cuda', torch.cuda.current_device())
+
+
+def max_over_ranks(value, device=None):
+    """Scalar max-reduce (timings, outcomes)."""
     if not is_distributed():
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device='cpu' if _host_staged() else device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_scalar_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def sum_over_ranks(value, device):
+def sum_over_ranks(value, device=None):
     if not is_distributed():
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device='cpu' if _host_staged() else device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_scalar_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())

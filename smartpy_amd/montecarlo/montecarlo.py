@@ -20,6 +20,7 @@ from ..smart import SMART
 from ..inout import get_dict_simulation_settings
 from ..objfunctions import groundwater_constraint
 from .. import distributed as sdist
+from ..engine import SmartEngineError
 from .database import database_for
 
 OBJ_FN_NAMES = ['NSE', 'KGE', 'KGEc', 'KGEa', 'KGEb', 'PBias', 'RMSE']      # montecarlo.py:71-74; 'GW' is appended
@@ -135,19 +136,35 @@ class MonteCarlo(object):
             return
         lo, hi = sdist.shard_bounds(n, world, rank)
         rows = self._device_sample if self._device_sample is not None else self._sample
-        out = self.model.simulate_ensemble(rows[lo:hi] if hi > lo else rows[:1],
-                                           objective_functions=True, gw_constraint=self.constraints['gw'],
-                                           save_discharge=self.save_sim, math_mode=self.math_mode)
-        block = [out.objfn[:hi - lo, :n_obj], out.gw[:hi - lo].unsqueeze(1)]
-        if self.save_sim:       # float32 is all the database keeps (montecarlo.py:225)
-            block.append(out.discharge[:hi - lo].to(torch.float64))
-        gathered = sdist.gather_rows(torch.cat(block, dim=1), n)
+        # one rank's launch failing (a status word its repeated launch could not clear) must not leave its peers waiting
+        # in the gather below: the outcome is agreed over the ranks first, and every rank raises if any did
+        failure, out = None, None
+        try:
+            out = self.model.simulate_ensemble(rows[lo:hi] if hi > lo else rows[:1],
+                                               objective_functions=True, gw_constraint=self.constraints['gw'],
+                                               save_discharge=self.save_sim, math_mode=self.math_mode)
+        except SmartEngineError as e:
+            failure = e
+        if world > 1:
+            sdist.agree_or_raise(failure)
+        elif failure is not None:
+            raise failure
+        # the [N, 9] block of objective functions and groundwater ratios goes to every rank (72 bytes per sample: second
+        # stages select from it on any rank) ...
+        block = torch.cat([out.objfn[:hi - lo, :n_obj], out.gw[:hi - lo].unsqueeze(1)], dim=1)
+        gathered = sdist.gather_rows(block, n)
         self.device_obj_fns, self.device_gw = gathered[:, :n_obj], gathered[:, n_obj]
         host = gathered.cpu().numpy()
         self.obj_fns, self.gw_contributions = host[:, :n_obj], host[:, n_obj]
+        # ... the simulated series, when they are to be saved, to the rank that writes the database ONLY, and as the
+        # float32 the database keeps (montecarlo.py:225; the reference's workers send theirs to the master alone:
+        # :211-231).  Never all-gathered: [N, R] is 29 GB of fp64 at N = 1e6.
+        series = None
+        if self.save_sim:
+            series = sdist.collect_rows(out.discharge[:hi - lo].to(torch.float32), n, dst=0)
         if rank == 0:
             db = self._open_database()
-            db.write_table(self.obj_fns, self._sample, host[:, n_obj + 1:] if self.save_sim else None)
+            db.write_table(self.obj_fns, self._sample, series)
             self._finish_database(db, compression)
         sdist.barrier()
 

@@ -112,7 +112,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r['hbm']['unit'] == 'GB/s' and 0 < r['hbm']['frac'] < 1 and r['algorithmic_ratio']['ratio'] > 0
     assert 'smart_fast_intervals' in r['kernel'] and r['launch_ms'] > 0
     p = d['parity']
-    assert p['ok'] is True and p['max_rel_discharge'] <= 1e-9 and p['gate'] == 1e-6 and p['rows'] >= 64
+    assert p['ok'] is True and p['max_rel_discharge'] <= 1e-9 and p['gate'] == 1e-9 and p['contract'] == 1e-6 and p['rows'] >= 64
+    print('bench parity: discharge %.2e relative, gw ratio %.2e absolute (gate %.0e, contract %.0e)' % (
+        p['max_rel_discharge'], p['max_abs_gw_ratio'], p['gate'], p['contract']))
     assert 'smart_fast_intervals' in d['objectives_only']['kernel'] and d['objectives_only']['value'] > 0.9 * d['value']
     f = d['flat_forcing']
     assert 'smart_fast_steps' in f['kernel'] and 0 < f['value'] < d['value'] * 1.05
@@ -168,12 +170,47 @@ def test_bench_with_two_ranks_launched_the_way_the_driver_does(config, samples):
     if config == 3:
         # N > 1 keeps rank 0's CPU baseline and the in-run parity check, and carries config 4's strong-scaled figure
         assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 1e6
-        assert d['parity']['ok'] and d['parity']['max_rel_discharge'] <= 1e-6
+        assert d['parity']['ok'] and d['parity']['max_rel_discharge'] <= 1e-9
         st = d['strong_1e6']
         assert st['scaling'] == 'strong' and st['runs_total'] == 1000000 and st['runs_per_gpu'] == 500000
         assert len(st['launch_ms_per_rank']) == 2 and st['value'] > 0
     per_step = c['runs_total'] * 96432            # sample-timesteps of one step, warm-up included
     assert abs(d['value'] - per_step / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('config, samples', [(3, 8000), (4, 8000), (5, 250)])
+def test_bench_with_eight_ranks_launched_the_way_the_driver_does(config, samples):
+    """What the driver's 8-GPU node runs -- `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` -- on
+    a one-GPU box: eight ranks share GPU 0, distributed.init() finds that out by itself (the ranks compare the UUIDs of
+    their devices) and stages the result blocks through gloo.  Everything else is the code of the real run: rank 0
+    alone builds the observations and broadcasts them, shards of 1,000 rows (config 4) / 8 catchments (config 5), the
+    all-gather, barrier + max-over-ranks timing, one JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k != 'SMART_DIST_BACKEND'}
+    out = subprocess.check_output(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr',
+         '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2',
+         '--warmup', '1', '--config', str(config), '--samples', str(samples), '--no-flat', '--no-strong',
+         '--no-cpu-baseline'], cwd=ROOT, env=env, stderr=subprocess.DEVNULL, timeout=1200).decode()
+    lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    c, r = d['config'], d['ranks']
+    assert d['n_gpus'] == 8 and r['world_size'] == 8 and len({x['pid'] for x in r['ranks']}) == 8
+    assert sorted(x['rank'] for x in r['ranks']) == list(range(8)) and len(r['launch_ms_per_rank']) == 8
+    import torch
+    assert r['backend'] == ('nccl' if torch.cuda.device_count() >= 8 else 'gloo')
+    if config == 3:
+        assert d['scaling'] == 'weak' and c['runs_per_gpu'] == samples and c['runs_total'] == 8 * samples
+    elif config == 4:
+        assert d['scaling'] == 'strong' and c['runs_total'] == samples and c['runs_per_gpu'] == samples // 8
+    else:
+        assert d['scaling'] == 'strong' and c['runs_total'] == 64 * samples and c['runs_per_gpu'] == 8 * samples
+    assert abs(d['value'] - c['runs_total'] * 96432 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
 
 
 def test_the_legs_of_the_line_are_priced_against_the_issue_roof_with_their_own_counts():

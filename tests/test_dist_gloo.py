@@ -1,5 +1,6 @@
-"""The N > 1 path on CPU: two processes, gloo backend.  Covers the sharding + single all-gather used by
-bench.py and MonteCarlo.run() (on the GPU box the same code runs over RCCL with one rank per GPU)."""
+"""The N > 1 path on CPU: two and EIGHT processes, gloo backend.  Covers the sharding + single all-gather used by
+bench.py and MonteCarlo.run() (on the GPU box the same code runs over RCCL with one rank per GPU), the rank-0-only
+collection of the saved series, empty shards, and a rank that fails."""
 import os
 import shutil
 import socket
@@ -90,22 +91,47 @@ def _make_root(tmp, days=120):
     return root
 
 
-def _worker_lhs(rank, world, port, root, save_sim, seeded=True):
+def _failing_simulate_ensemble(self, parameters, **kw):
+    """... and one whose launch on rank 3 reports a status its repeated launch could not clear."""
+    if dist.is_initialized() and dist.get_rank() == 3:
+        from smartpy_amd.engine import SmartEngineError
+        raise SmartEngineError(-6, 'the repeated launch reports status 0x1 as well')
+    return _oracle_simulate_ensemble(self, parameters, **kw)
+
+
+def _worker_lhs(rank, world, port, root, save_sim, seeded=True, n=13, failing=False):
     if world > 1:
         _init(rank, world, port)
     elif ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     from smartpy_amd.smart import SMART
     from smartpy_amd.montecarlo import LHS
-    SMART.simulate_ensemble = _oracle_simulate_ensemble
+    from smartpy_amd import distributed as sdist
+    from smartpy_amd.engine import SmartEngineError
+    SMART.simulate_ensemble = _failing_simulate_ensemble if failing else _oracle_simulate_ensemble
     # seeded: every rank draws the same sample.  Unseeded (what the reference's own scripts do): every process draws
     # another one from NumPy's global stream, and rank 0's has to win
     np.random.seed(2718 if seeded else 1000 + rank)
-    lhs = LHS('Catchment', root, 'csv', 'csv', 13, save_sim=save_sim)
+    lhs = LHS('Catchment', root, 'csv', 'csv', n, save_sim=save_sim)
     lhs.model.extra = {'aar': 1200, 'r-o_ratio': 0.45, 'r-o_split': (0.10, 0.15, 0.15, 0.30, 0.30)}
+    if failing:
+        # every rank raises, in the same call: the failed one its own error, the others one that says a peer failed --
+        # and all of them are still in step afterwards (the barrier below would hang otherwise)
+        try:
+            lhs.run()
+            outcome = 'returned'
+        except SmartEngineError as e:
+            outcome = 'peer' if 'another rank' in str(e) else 'own'
+        dist.barrier()
+        open(os.path.join(root, 'outcome_r%d.txt' % rank), 'w').write(outcome)
+        dist.destroy_process_group()
+        return
     lhs.run()
     np.save(os.path.join(root, 'objfns_w%d_r%d.npy' % (world, rank)), lhs.obj_fns)
     np.save(os.path.join(root, 'sample_w%d_r%d.npy' % (world, rank)), lhs._sample)
+    lo, hi = sdist.shard_bounds(n, world, rank)
+    open(os.path.join(root, 'bytes_w%d_r%d.txt' % (world, rank)), 'w').write(
+        '%d %d' % (sdist.last_collect_bytes, hi - lo))
     if world > 1:
         dist.destroy_process_group()
 
@@ -332,3 +358,64 @@ def test_sharded_ensemble_over_catchments_and_samples(tmp_path):
                             obs=obs[2], extra=extra).launch()
     assert np.array_equal(two['w'][:, :8], whole.objfn.numpy(), equal_nan=True)
     assert np.array_equal(two['w'][:, 8], whole.gw.numpy())
+
+
+# ---- eight ranks: what the driver's 8-GPU run starts (one process per GPU), on the CPU ---------------------------------
+def _worker_gather8(rank, world, port, out_dir):
+    _init(rank, world, port)
+    from smartpy_amd import distributed as sdist
+    ok = True
+    for n in (5, 8, 9, 64, 101):                    # 5 rows over 8 ranks: three empty shards
+        full = torch.arange(n * 9, dtype=torch.float64).reshape(n, 9) * 0.5
+        lo, hi = sdist.shard_bounds(n, world, rank)
+        ok = ok and torch.equal(sdist.gather_rows(full[lo:hi].clone(), n), full)
+        series = (torch.arange(n * 7, dtype=torch.float32).reshape(n, 7) + 0.25)
+        got = sdist.collect_rows(series[lo:hi].clone(), n, dst=0)
+        if rank == 0:
+            ok = ok and got.dtype == np.float32 and np.array_equal(got, series.numpy())
+            ok = ok and sdist.last_collect_bytes == (n - (hi - lo)) * 7 * 4      # everybody else's rows came in
+        else:
+            ok = ok and got is None and sdist.last_collect_bytes == (hi - lo) * 7 * 4   # its own rows went out, no more
+    ok = ok and sdist.max_over_ranks(rank) == world - 1 and sdist.data_backend() == 'gloo'
+    sdist.barrier()
+    open(os.path.join(out_dir, 'gather8_%d.txt' % rank), 'w').write('ok' if ok else 'FAILED')
+    dist.destroy_process_group()
+
+
+def test_gather_and_collect_rows_eight_ranks(tmp_path):
+    mp.spawn(_worker_gather8, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    assert [open(tmp_path / ('gather8_%d.txt' % r)).read() for r in range(8)] == ['ok'] * 8
+
+
+@pytest.mark.parametrize('n', [13, 5])
+def test_lhs_run_over_eight_ranks_with_saved_series(tmp_path, n):
+    """MonteCarlo.run(save_sim=True) over eight ranks (n = 5: three of them without a row): the database rank 0 writes
+    is the single process's, byte for byte; every rank holds the [N, 8] objective functions; and the simulated series
+    travelled to rank 0 ONLY -- a rank other than 0 moved its own rows as float32, nothing else (round 4 all-gathered
+    the fp64 matrix to every rank: 29 GB x 8 at config 4)."""
+    root1 = _make_root(str(tmp_path / 'one'))
+    root8 = _make_root(str(tmp_path / 'eight'))
+    _worker_lhs(0, 1, 0, root1, True, True, n)
+    mp.spawn(_worker_lhs, args=(8, _free_port(), root8, True, True, n), nprocs=8, join=True)
+    db1 = open(os.path.join(root1, 'out', 'Catchment', 'Catchment.SMART.lhs')).read()
+    db8 = open(os.path.join(root8, 'out', 'Catchment', 'Catchment.SMART.lhs')).read()
+    assert db1 == db8 and len(db1.strip().split('\n')) == n + 1
+    a = np.load(os.path.join(root1, 'objfns_w1_r0.npy'))
+    R = 120
+    for r in range(8):
+        assert np.array_equal(a, np.load(os.path.join(root8, 'objfns_w8_r%d.npy' % r)))
+        moved, n_local = (int(v) for v in open(os.path.join(root8, 'bytes_w8_r%d.txt' % r)).read().split())
+        if r == 0:
+            assert moved == (n - n_local) * R * 4
+        else:
+            assert moved == n_local * R * 4 <= n_local * (9 + R) * 8
+
+
+def test_a_failing_rank_makes_all_eight_raise(tmp_path):
+    """One rank's launch fails for good (rank 3): MonteCarlo.run() raises on EVERY rank in the same call -- the failed
+    one its own error, the seven others one that names a peer -- instead of leaving them in the gather until the
+    process group times out."""
+    root = _make_root(str(tmp_path / 'eight'))
+    mp.spawn(_worker_lhs, args=(8, _free_port(), root, True, True, 13, True), nprocs=8, join=True)
+    got = [open(os.path.join(root, 'outcome_r%d.txt' % r)).read() for r in range(8)]
+    assert got == ['peer'] * 3 + ['own'] + ['peer'] * 4
