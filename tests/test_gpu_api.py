@@ -78,6 +78,43 @@ def test_from_arrays_and_warmup_error(example):
         sm.get_evaluation_array()
 
 
+def test_a_repeated_simulate_uploads_its_ten_parameters_and_nothing_else(example):
+    """SMART.simulate() keeps the forcing, the output buffers and the plan on the device (engine.SingleRun): the second
+    call moves 80 bytes to the device -- no forcing, no planning -- and a row of another class (a stiff one, an
+    ill-conditioned one) gets its own kernel; every call equals the one-shot path bit for bit."""
+    import smartpy_amd
+    from smartpy_amd import engine, structure
+    sm = smartpy_amd.SMART.from_arrays(example['area'], datetime(2007, 1, 1, 9), datetime(2007, 12, 31, 9),
+                                       timedelta(days=1), timedelta(days=1), 30, example['rain_daily'][:365],
+                                       example['peva_daily'][:365])
+    sm.extra = EXTRA
+    names = sm.parameters.names
+    base = np.array(example['params'], dtype=float)
+    stiff, wild = base.copy(), base.copy()
+    stiff[6], wild[9] = 10.0, 3.0            # SK < 24 h: clamps reachable; RK < 12 h: the river is ill-conditioned
+    first = sm.simulate(dict(zip(names, base)))
+    for row in (stiff, wild, base, stiff):
+        before = engine.h2d_bytes
+        d, g = sm.simulate(dict(zip(names, row)))
+        assert engine.h2d_bytes - before == 80
+        want = structure.run(sm.area, sm.delta_simu, sm.nd_rain, sm.nd_peva, row, sm.extra, sm.timeseries,
+                             sm.timeseries_report, 'summary', warm_up=sm.warm_up)
+        assert bits_equal(d, want[0]) and g == want[1]
+    assert bits_equal(sm.simulate(dict(zip(names, base)))[0], first[0])
+    # another report type is another kept run; the series are looked up by identity: replacing one starts afresh
+    raw = sm.simulate(dict(zip(names, base)), report='raw')
+    assert raw[0].shape == first[0].shape and len(sm._single) == 2
+    sm.nd_rain = sm.nd_rain * 1.0
+    before = engine.h2d_bytes
+    again = sm.simulate(dict(zip(names, base)))
+    assert engine.h2d_bytes - before > 80 and bits_equal(again[0], first[0])
+
+
+def bits_equal(a, b):
+    a, b = np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+    return a.shape == b.shape and np.array_equal(a.view(np.int64), b.view(np.int64))
+
+
 def _settings(root, name, start, end, warm):
     with open(os.path.join(root, 'in', 'Catchment', name), 'w') as f:
         f.write('ARGUMENT,VALUE\ncatchment_area_km2,175.46\ngauged_area_km2,175.97\nstart_datetime,%s 09:00:00\n'

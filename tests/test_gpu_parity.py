@@ -32,12 +32,22 @@ def rel(a, b, floor=0.0):
     return float(np.max(r)) if r.size else 0.0
 
 
+#: what an excess() has to stay below.  1.0 is the tolerance itself; the call sites are held to a TENTH of it, which is
+#: where the measured margins allow it (round 5: the margins of a GPU run are printed at the end of the module and
+#: written to gpurun_out/parity_margins.txt -- the largest one this tree produces is 0.05).  A call site that needs more
+#: says so with a number of its own and the measurement behind it.
+EXCESS_GATE = 0.1
+MARGINS = {}        # call site (line of this file) -> largest excess() seen there in this run
+
+
 def excess(got, want, rtol, top=None, top_frac=1e-13, tiny=1e-40):
-    """Largest |got - want| / (rtol * |want| + top_frac * top + tiny); <= 1 passes.  `top` is the largest magnitude of
+    """Largest |got - want| / (rtol * |want| + top_frac * top + tiny); <= 1 is within the tolerance, and the call sites
+    ask for <= EXCESS_GATE.  `top` is the largest magnitude of
     the row (default: of `want` along its last axis): a value that has drained to 1e-9 of its row's peak carries the
     absolute rounding of the states it came from, not nine digits of its own.  `tiny`: a catchment that never held
     water carries storages of 1e-59 m3, whose last digits the river's 95 % rule flips on rounding noise -- zero, to any
-    hydrologist, in any of the units compared here (m3, m3/s, mm)."""
+    hydrologist, in any of the units compared here (m3, m3/s, mm).  Every call leaves its margin in MARGINS."""
+    import sys
     got, want = np.asarray(got, float), np.asarray(want, float)
     if want.size == 0:
         return 0.0
@@ -45,7 +55,26 @@ def excess(got, want, rtol, top=None, top_frac=1e-13, tiny=1e-40):
         top = np.abs(want).max(axis=-1, keepdims=True) if want.ndim > 1 else np.abs(want).max()
     with np.errstate(invalid='ignore', divide='ignore'):
         r = np.abs(got - want) / (rtol * np.abs(want) + top_frac * top + tiny)
-    return float(np.nanmax(np.where(np.abs(got - want) == 0, 0.0, r)))
+    worst = float(np.nanmax(np.where(np.abs(got - want) == 0, 0.0, r)))
+    frame = sys._getframe(1)
+    site = '%s:%d' % (frame.f_code.co_name, frame.f_lineno)
+    MARGINS[site] = max(MARGINS.get(site, 0.0), worst)
+    return worst
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _print_the_margins():
+    """The achieved margin of every tolerance-based comparison of this module, in the GPU log and in a file."""
+    yield
+    if not MARGINS:
+        return
+    lines = ['%-78s %.3g' % (site, m) for site, m in sorted(MARGINS.items(), key=lambda kv: -kv[1])]
+    text = 'excess() margins of this run (1.0 = the tolerance, gate %.2g), largest first:\n' % EXCESS_GATE + '\n'.join(lines)
+    print('\n' + text)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'parity_margins.txt'), 'w') as fh:
+            fh.write(text + '\n')
 
 
 def bits_equal(a, b):
@@ -647,11 +676,16 @@ def test_config2_daily_1e4_samples(eng, example):
     assert bits_equal(got_lit, dis) and bits_equal(lit.gw.cpu().numpy(), gw)
     ref, gw_ref, fin_ref = so.run_batch(example['area'], 86400.0, 3653, 365, rain, peva, params, example['extra'],
                                         so.REPORT_SUMMARY, 1, want_final=True)          # reference-exact (libm pow)
-    assert excess(got[~unstable], ref[~unstable], REL_FAST) <= 1.0
-    assert excess(out.gw.cpu().numpy()[~unstable], gw_ref[~unstable], 1e-10, top=1.0) <= 1.0
-    assert excess(out.final_vars.cpu().numpy()[~unstable], fin_ref[~unstable], 1e-8) <= 1.0
+    assert excess(got[~unstable], ref[~unstable], REL_FAST) <= EXCESS_GATE
+    assert excess(out.gw.cpu().numpy()[~unstable], gw_ref[~unstable], 1e-10, top=1.0) <= EXCESS_GATE
+    assert excess(out.final_vars.cpu().numpy()[~unstable], fin_ref[~unstable], 1e-8) <= EXCESS_GATE
     assert (params[~unstable, 6] * 3600.0 < 43200.0).sum() > 300          # rows with dt / SK > 2 are among them
-    assert rel(got, ref, floor=1e-300) <= 1e-3         # ill-conditioned rows: whatever libm's last bit does to them
+    # ... and ALL rows, the ill-conditioned ones included, against the reference-exact oracle: those run the reference's own
+    # operation order and differ from it by libm's pow against the product chain only -- measured 6e-16 over these 10,000
+    # rows x 3,653 days (round 4's gate here was 1e-3: nine orders above what is measured, three above the 1e-6 contract)
+    worst = rel(got, ref, floor=1e-300)
+    print('config 2, all rows against the reference-exact oracle: %.2e relative (gate 1e-9, contract 1e-6)' % worst)
+    assert worst <= 1e-9
     # permutation of the batch: bit-identical row by row, although the wavefronts are composed differently
     perm = np.random.default_rng(3).permutation(len(params))
     out_p = eng.run_ensemble(params[perm], f, example['area'], 86400.0, 365, 1, extra=example['extra'],
@@ -911,11 +945,11 @@ def test_parameter_and_forcing_corner_cases(eng, example):
                                       want_final=True)
             tag = '%s, %s %s: %s' % (name, 'hourly' if hourly else 'daily', report, out._prepared.describe())
             good = ~(params[:, 9] * 3600.0 < 0.5 * dt)          # dt / RK <= 2: not the literal model's
-            assert excess(out.discharge.cpu().numpy()[good], d1[good], REL_FAST) <= 1.0, tag
+            assert excess(out.discharge.cpu().numpy()[good], d1[good], REL_FAST) <= EXCESS_GATE, tag
             gg, ok = out.gw.cpu().numpy()[good], np.isfinite(g1[good])
             assert np.all(np.abs(gg[ok] - g1[good][ok]) <= 1e-9), tag
             assert np.array_equal(np.isnan(gg), np.isnan(g1[good])), tag        # 0 / 0 where nothing ever runs off
-            assert excess(out.final_vars.cpu().numpy()[good], f1[good], 1e-8) <= 1.0, tag
+            assert excess(out.final_vars.cpu().numpy()[good], f1[good], 1e-8) <= EXCESS_GATE, tag
 
 
 def run_batch_cases(eng, seed, n_cases, stress_initial=False):
@@ -996,14 +1030,14 @@ def run_batch_cases(eng, seed, n_cases, stress_initial=False):
                     want, gw1, f1 = so.all_steps(areas[c], dt, T, rain, peva, p[row], start, rtype, gap)
                 else:
                     want, gw1, f1 = so.run(areas[c], dt, T, W, rain, peva, p[row], extra, rtype, gap)
-                assert excess(dis[c, row], want, REL_FAST) <= 1.0, (tag, c, row)
+                assert excess(dis[c, row], want, REL_FAST) <= EXCESS_GATE, (tag, c, row)
                 if np.isfinite(gw1):
                     assert abs(gwr[c, row] - gw1) <= 1e-9, (tag, c, row)
                 wo = np.array(objfn_oracle.objective_functions(want, obs[c], gw1, gw_obs[c]), dtype=np.float64)
                 if np.isfinite(wo[:7]).all():
                     assert rel(obj[c, row, :7], wo[:7], floor=1e-9) <= 1e-6 and obj[c, row, 7] == wo[7], (tag, c, row)
                 if final:
-                    assert excess(fin[c, row], f1, 1e-8) <= 1.0, (tag, c, row)
+                    assert excess(fin[c, row], f1, 1e-8) <= EXCESS_GATE, (tag, c, row)
 
 
 def test_randomized_batches_catchments_and_initial_states(eng):
@@ -1034,9 +1068,9 @@ def test_rows_with_shares_that_are_none_take_the_literal_arithmetic(eng):
     d1, g1, _ = so.run_batch(2.3e8, 3600.0, T, 0, rain, peva, params, None, so.REPORT_SUMMARY, gap, want_final=True)
     got = fast.discharge.cpu().numpy()
     # (the step's bits; the interval mean in the fast launch's summation order, not numpy's pairwise one)
-    assert excess(got[odd], d1[odd], 1e-13) <= 1.0 and excess(fast.gw.cpu().numpy()[odd], g1[odd], 1e-12, top=1.0) <= 1.0
+    assert excess(got[odd], d1[odd], 1e-13) <= EXCESS_GATE and excess(fast.gw.cpu().numpy()[odd], g1[odd], 1e-12, top=1.0) <= EXCESS_GATE
     rest = np.setdiff1d(np.arange(130), odd)
-    assert excess(got[rest], d1[rest], REL_FAST) <= 1.0
+    assert excess(got[rest], d1[rest], REL_FAST) <= EXCESS_GATE
 
 
 def adversarial_rows(rng, n):
@@ -1088,7 +1122,7 @@ def test_adversarial_parameter_rows_against_the_oracle(eng, seed):
     with np.errstate(invalid='ignore'):
         top = np.nanmax(np.where(finite, np.abs(want), 0.0), axis=1, keepdims=True)
     g, w = np.where(finite, got, 0.0), np.where(finite, want, 0.0)
-    assert excess(g, w, REL_FAST, top=top, top_frac=1e-12) <= 1.0
+    assert excess(g, w, REL_FAST, top=top, top_frac=1e-12) <= EXCESS_GATE
 
 
 def test_ill_conditioned_rows_with_soil_above_capacity(eng):
@@ -1151,12 +1185,12 @@ def run_wide_cases(eng, seed, n_cases):
             continue
         # relative 1e-9, or absolute 1e-13 of the row's largest discharge: a catchment that has run dry carries flows of
         # 1e-20 m3/s whose sign the river's 95 % rule flips on rounding noise (dt / RK > 1) -- zero, to any hydrologist
-        assert excess(fast.discharge.cpu().numpy()[good], d1[good], REL_FAST) <= 1.0, tag
+        assert excess(fast.discharge.cpu().numpy()[good], d1[good], REL_FAST) <= EXCESS_GATE, tag
         ok = np.isfinite(g1[good])
-        assert excess(fast.gw.cpu().numpy()[good][ok], g1[good][ok], 1e-9, top=1.0) <= 1.0, tag   # a ratio in [0, 1]
+        assert excess(fast.gw.cpu().numpy()[good][ok], g1[good][ok], 1e-9, top=1.0) <= EXCESS_GATE, tag   # a ratio in [0, 1]
         # the final row: relative 1e-8, or absolute 1e-13 of the row's largest entry -- a layer that the reference empties
         # exactly (`lvl >= deficit` false by one ulp) may keep 1e-15 mm in the other arithmetic, and the other way round
-        assert excess(fast.final_vars.cpu().numpy()[good], f1[good], 1e-8) <= 1.0, tag
+        assert excess(fast.final_vars.cpu().numpy()[good], f1[good], 1e-8) <= EXCESS_GATE, tag
         if (~good).any():
             lit = eng.run_ensemble(params[~good], f, area, dt, W, gap, report=report, extra=extra, math_mode='literal',
                                    want_final=True)
@@ -1341,7 +1375,7 @@ def test_pair_blocks_are_bit_identical_to_the_threaded_chunks(eng, monkeypatch, 
         assert bits_equal(fin['1'][0], outs['5', '1'][0])       # (and the final row does not change the discharge)
     d1, g1, _ = so.run_batch(2.1e8, 3600.0, T, W, rain, peva, params, None, rtype, gap, want_final=True)
     good = ~(params[:, 9] * 3600.0 < 0.5 * 3600.0)
-    assert excess(outs['1', '1'][0][good], d1[good], REL_FAST) <= 1.0
+    assert excess(outs['1', '1'][0][good], d1[good], REL_FAST) <= EXCESS_GATE
 
 
 def run_interval_cases(eng, setenv, seed, n_cases, mode='summary'):
@@ -1420,18 +1454,18 @@ def run_interval_cases(eng, setenv, seed, n_cases, mode='summary'):
         good = ~(params[:, 9] * 3600.0 < 0.5 * dt)          # dt / RK <= 2: not the literal model's
         if good.any():
             got = fast.discharge.cpu().numpy()[good]
-            assert excess(got, d1[good], REL_FAST) <= 1.0, tag
+            assert excess(got, d1[good], REL_FAST) <= EXCESS_GATE, tag
             big = np.abs(d1[good]) > 1e-6 * np.abs(d1[good]).max(axis=1, keepdims=True)
             worst = max(worst, rel(got[big], d1[good][big]))
             ok = np.isfinite(g1[good])         # a ratio of sums: absolute floor of 1e-13 on a number in [0, 1]
-            assert excess(fast.gw.cpu().numpy()[good][ok], g1[good][ok], 1e-9, top=1.0) <= 1.0, tag
+            assert excess(fast.gw.cpu().numpy()[good][ok], g1[good][ok], 1e-9, top=1.0) <= EXCESS_GATE, tag
             want = objfn_oracle.objective_matrix(d1[good], obs, g1[good], 0.2)
             got = fast.objfn.cpu().numpy()[good]
             fin = np.isfinite(want[:, :7]).all(axis=1)
             # scores are O(1) combinations of moments: one that comes out as 1e-9 has cancelled eight of its digits
-            assert excess(got[fin, :7], want[fin, :7], 1e-7, top=1.0, top_frac=1e-12) <= 1.0, tag
+            assert excess(got[fin, :7], want[fin, :7], 1e-7, top=1.0, top_frac=1e-12) <= EXCESS_GATE, tag
             if want_final:
-                assert excess(fast.final_vars.cpu().numpy()[good], f1[good], 1e-8) <= 1.0, tag
+                assert excess(fast.final_vars.cpu().numpy()[good], f1[good], 1e-8) <= EXCESS_GATE, tag
     return worst
 
 
@@ -1467,12 +1501,12 @@ def test_run_length_interval_engine(eng, example, monkeypatch, run_len, shift):
         kern = out._prepared.describe()
         assert ('smart_fast_runs' in kern) == (expect >= 2) and ('_states' in kern) == final, (kern, expect)
         got = out.discharge.cpu().numpy()
-        assert excess(got, want_d, REL_FAST) <= 1.0, (run_len, shift, slices, rel(got, want_d))
-        assert excess(out.gw.cpu().numpy(), want_g, 1e-9, top=1.0) <= 1.0
+        assert excess(got, want_d, REL_FAST) <= EXCESS_GATE, (run_len, shift, slices, rel(got, want_d))
+        assert excess(out.gw.cpu().numpy(), want_g, 1e-9, top=1.0) <= EXCESS_GATE
         fin = np.isfinite(want_o[:, :7]).all(axis=1)
-        assert excess(out.objfn.cpu().numpy()[fin, :7], want_o[fin, :7], 1e-7, top=1.0, top_frac=1e-12) <= 1.0
+        assert excess(out.objfn.cpu().numpy()[fin, :7], want_o[fin, :7], 1e-7, top=1.0, top_frac=1e-12) <= EXCESS_GATE
         if final:
-            assert excess(out.final_vars.cpu().numpy(), want_f, 1e-8) <= 1.0
+            assert excess(out.final_vars.cpu().numpy(), want_f, 1e-8) <= EXCESS_GATE
         results.append((final, got, out.gw.cpu().numpy()))
     # time slices change nothing, and asking for the final row does not change the discharge
     assert bits_equal(results[0][1], results[1][1]) and bits_equal(results[2][1], results[3][1])
