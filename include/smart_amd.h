@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SMART_AMD_ABI_VERSION 5
+#define SMART_AMD_ABI_VERSION 6
 
 /* report_type, as structure.py:65-70 maps report='summary' / 'raw' */
 #define SMART_REPORT_SUMMARY 1
@@ -257,6 +257,8 @@ int64_t smart_db_parse_rows(const char *text, int64_t len, int64_t n_cols, const
 /* Device bookkeeping */
 int smart_device_count(void);           /* number of visible HIP devices (0 if none / no driver)      */
 int smart_abi_version(void);            /* SMART_AMD_ABI_VERSION the library was built with           */
+const char *smart_build_info(void);     /* the compiler that built the library ("hipcc <HIP version> | clang <version> |
+                                         * gfx950"): the layout lints of smartpy_amd/isa_lint.py hold for that build */
 const char *smart_last_error(void);     /* text of the calling thread's last error ("" if none)       */
 
 #ifdef __cplusplus

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get('SMART_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libsm
 
 REPORT_SUMMARY, REPORT_RAW = 1, 2
 MATH_LITERAL, MATH_FAST = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 PLAN_VALID = 0x100
 PLAN_CLASS_BITS = {0: 0x01, 1: 0x02, 2: 0x04, 3: 0x08}     # regular, stiff, guard, ill-conditioned
 PLAN_FORCING_PIECEWISE, PLAN_FORCING_VARYING, PLAN_FORCING_RUNS = 0x10, 0x20, 0x80
@@ -60,6 +60,7 @@ SYMBOLS = {
                                              ctypes.POINTER(ctypes.c_float), ctypes.c_int64, ctypes.c_int32]),
     'smart_device_count': (ctypes.c_int, []),
     'smart_abi_version': (ctypes.c_int, []),
+    'smart_build_info': (ctypes.c_char_p, []),
     'smart_last_error': (ctypes.c_char_p, []),
 }
 
@@ -72,6 +73,27 @@ class SmartEngineError(Exception):
     def __init__(self, code, message):
         Exception.__init__(self, message)
         self.code = code
+
+
+def _apply_lint_verdict():
+    """The streaming step loops jump through byte offsets that another kernel wrote (smart_fast_arms.h: pair blocks); the
+    offsets are right for a library whose code smartpy_amd.isa_lint has looked at -- smartpy_amd.build does that for
+    every library it links and leaves the outcome next to it.  A library without that record, or with one written for
+    another file (rebuilt elsewhere, by another hipcc), or whose blocks failed the lint, runs the THREADED CHUNKS instead
+    (SMART_PAIR_BLOCKS=0: the same arithmetic, bit for bit, without computed jumps) and says so; never wrong code
+    words.  A library whose hand-over or row chains failed the lint is refused.  SMART_PAIR_BLOCKS set by the caller
+    stands (A/B builds: tools/variants)."""
+    import warnings
+    from . import isa_lint
+    ok, pairs, reason = isa_lint.verdict_for(LIB_PATH)
+    if not ok:
+        raise ImportError("smartpy_amd: %s failed the code lints of smartpy_amd.isa_lint (%s); rebuild it with "
+                          "`python -m smartpy_amd.build --force`" % (LIB_PATH, reason))
+    if not pairs and 'SMART_PAIR_BLOCKS' not in os.environ:
+        os.environ['SMART_PAIR_BLOCKS'] = '0'
+        warnings.warn("smartpy_amd: %s; the step loops run their threaded chunks instead of the pair blocks "
+                      "(SMART_PAIR_BLOCKS=0).  `python -m smartpy_amd.build --force` builds and checks the library."
+                      % reason)
 
 
 def lib():
@@ -89,6 +111,7 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
+        _apply_lint_verdict()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)       # AttributeError here = the header and the library disagree

@@ -74,11 +74,44 @@ def build(force=False, verbose=False, extra_flags=(), lib_path=LIB):
             print(' '.join(cmd))
         try:
             subprocess.check_call(cmd)
+            report = lint(tmp, verbose)
             os.replace(tmp, lib_path)
+            from . import isa_lint
+            isa_lint.write_sidecar(report, lib_path)
         finally:
             if os.path.exists(tmp):
                 os.remove(tmp)
+    elif lint_missing(lib_path):
+        from . import isa_lint
+        isa_lint.write_sidecar(lint(lib_path, verbose), lib_path)
     return lib_path
+
+
+class BuildLintError(RuntimeError):
+    pass
+
+
+def lint_missing(lib_path):
+    from . import isa_lint
+    rep = isa_lint.read_sidecar(lib_path)
+    return rep is None or rep.get('sha256') != isa_lint.sha256_of(lib_path)
+
+
+def lint(path, verbose=False):
+    """smartpy_amd.isa_lint on a freshly linked library, BEFORE it is put in place: the pair blocks where the code words
+    point, the hand-over sequences, the DPP distances of the row form.  A hand-over or a row chain that fails refuses
+    the library (BuildLintError: those have no other form to fall back to); pair blocks that fail are recorded, and the
+    library will run its threaded chunks (smartpy_amd._lib)."""
+    from . import isa_lint
+    report = isa_lint.check_library(path)
+    report['library'] = os.path.basename(LIB)
+    if verbose or report['problems']:
+        print('isa_lint: %s' % ('; '.join(report['problems']) if report['problems'] else
+                                'pair blocks, hand-over and row chains of the linked library are in order'))
+    if report['handover'] is False or report['rows'] is False:
+        raise BuildLintError('smartpy_amd.build: the linked library fails the code lints and is not installed: '
+                             + '; '.join(report['problems']))
+    return report
 
 
 if __name__ == '__main__':

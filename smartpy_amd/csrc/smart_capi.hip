@@ -1218,6 +1218,14 @@ int smart_device_count(void)
 
 int smart_abi_version(void) { return SMART_AMD_ABI_VERSION; }
 
+#define SMART_STR_(x) #x
+#define SMART_STR(x) SMART_STR_(x)
+const char *smart_build_info(void)
+{
+    return "hipcc " SMART_STR(HIP_VERSION_MAJOR) "." SMART_STR(HIP_VERSION_MINOR) "." SMART_STR(HIP_VERSION_PATCH)
+           " | clang " __clang_version__ " | gfx950 | ABI " SMART_STR(SMART_AMD_ABI_VERSION);
+}
+
 const char *smart_last_error(void) { return g_err; }
 
 } // extern "C"

@@ -34,7 +34,8 @@ def test_every_declared_symbol_is_exported_and_bound(L):
     assert sorted(_lib.SYMBOLS) == names            # the ctypes table mirrors the header exactly
     for n in names:
         assert getattr(L, n) is not None
-    assert L.smart_abi_version() == _lib.ABI_VERSION == 5
+    assert L.smart_abi_version() == _lib.ABI_VERSION == 6
+    assert b"gfx950" in L.smart_build_info() and b"clang" in L.smart_build_info()
 
 
 def test_struct_layout_matches_the_header(tmp_path, L):

@@ -27,70 +27,17 @@ import tempfile
 from collections import Counter
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
-FP64 = ('v_fma_f64', 'v_fmac_f64', 'v_add_f64', 'v_mul_f64', 'v_min_f64', 'v_max_f64', 'v_ldexp_f64')
+sys.path.insert(0, ROOT)
+# the disassembly itself (code objects out of the library, one kernel's instructions, their classes) is shared with the
+# lints smartpy_amd.build runs on every library it links
+from smartpy_amd.isa_lint import OBJDUMP, FP64, classify, parse, Disassembly     # noqa: E402,F401
+
 VALU_CLASSES = ('fp64', 'vcmp', 'vmov', 'lane', 'valu')
 
 
-def classify(op):
-    base = op.replace('_e32', '').replace('_e64', '')
-    if base in FP64:
-        return 'fp64'
-    if base.startswith('v_cmp'):
-        return 'vcmp'
-    if base.startswith(('v_mov', 'v_cndmask', 'v_accvgpr')):
-        return 'vmov'
-    if base.startswith(('v_readlane', 'v_writelane', 'v_readfirstlane')):
-        return 'lane'
-    if base.startswith('v_'):
-        return 'valu'
-    if base.startswith(('s_branch', 's_cbranch')):
-        return 'branch'
-    if base.startswith(('s_load', 's_store', 's_buffer_load', 's_dcache')):
-        return 'smem'
-    if base.startswith(('global_', 'buffer_', 'flat_', 'scratch_', 'ds_')):
-        return 'vmem'
-    if base.startswith(('s_waitcnt', 's_nop', 's_sleep', 's_endpgm', 's_barrier', 's_code_end', 's_setprio', 's_trap')):
-        return 'other'
-    if base.startswith('s_'):
-        return 'salu'
-    return 'other'
-
-
-def code_objects(lib):
-    """the gfx950 code objects bundled in the shared library (llvm-objdump --offloading writes them next to its input:
-    done on a copy in a scratch directory)"""
-    tmp = tempfile.mkdtemp(prefix='smart_isa_')
-    copy = os.path.join(tmp, os.path.basename(lib))
-    shutil.copy(lib, copy)
-    subprocess.run([OBJDUMP, '--offloading', copy], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    return tmp, sorted(os.path.join(tmp, f) for f in os.listdir(tmp) if 'gfx950' in f)
-
-
 def disassemble(lib, kernel):
-    tmp, objs = code_objects(lib)
-    try:
-        for obj in objs:
-            text = subprocess.run([OBJDUMP, '-d', obj], check=True, capture_output=True, text=True).stdout
-            m = re.search(r'^([0-9a-f]+) <(_ZN5smart\d+%s[A-Z][^>]*)>:\n(.*?)(?=^\S|\Z)' % re.escape(kernel), text,
-                          re.M | re.S)
-            if m:
-                return int(m.group(1), 16), m.group(2), m.group(3)
-    finally:
-        shutil.rmtree(tmp)
-    raise SystemExit('kernel %s not found in %s' % (kernel, lib))
-
-
-def parse(start, body):
-    insts = []
-    for line in body.split('\n'):
-        m = re.match(r'\s+(\S+)\s*(.*?)\s*//\s*([0-9A-F]+):\s*[0-9A-F ]+(?:<[^+>]+\+0x([0-9a-f]+)>)?\s*$', line)
-        if not m:
-            continue
-        op, args, addr, off = m.group(1), m.group(2), int(m.group(3), 16), m.group(4)
-        target = start + int(off, 16) if off is not None and classify(op) == 'branch' else None
-        insts.append({'addr': addr, 'op': op, 'args': args, 'cls': classify(op), 'target': target})
-    return insts
+    """-> (address of the kernel's first instruction, its mangled name, llvm-objdump's text of it)"""
+    return Disassembly(lib).raw(kernel)
 
 
 def blocks_and_loops(insts):
