@@ -107,16 +107,24 @@ def wet_fraction(forcing, n_warm, t_lo=0.9, t_hi=1.1):
 
 
 def _code_only(text):
-    """C / C++ source without its comments, runs of white space collapsed (string literals left alone)."""
+    """C / C++ source without its comments, runs of white space collapsed (string literals left alone).  A ' opens a
+    character literal only where one stands ('x', '\\n', '\\''): a digit separator (1'000'000) or an apostrophe in an
+    #error text is an ordinary character -- round 4's scanner would have swallowed code up to the next quote."""
+    import re
+    char_literal = re.compile(r"'(\\.|[^\\'\n])'")
     out, i, n = [], 0, len(text)
     while i < n:
         c = text[i]
-        if c == '"' or c == "'":
+        if c == '"':
             j = i + 1
             while j < n and text[j] != c:
                 j += 2 if text[j] == '\\' else 1
             out.append(text[i:j + 1])
             i = j + 1
+        elif c == "'" and char_literal.match(text, i):
+            j = char_literal.match(text, i).end()
+            out.append(text[i:j])
+            i = j
         elif text.startswith('//', i):
             i = text.find('\n', i)
             i = n if i < 0 else i
@@ -130,14 +138,20 @@ def _code_only(text):
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources, comments and white space aside: a PMC summary is only quoted for the code it was
-    measured on -- and an edit of a comment is not an edit of the code."""
+    """sha256 over what decides the generated code: the kernel sources and the C ABI header, comments and white space
+    aside -- a PMC summary is only quoted for the code it was measured on, and an edit of a comment is not an edit of
+    the code -- and the compiler flags of every translation unit (smartpy_amd/build.py: -ffp-contract, -fno-honor-nans,
+    the -D switches change the code as much as the text does)."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, 'smartpy_amd', 'csrc')
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith(('.hip', '.h', '.cpp')):
-            with open(os.path.join(csrc, name), 'r', encoding='utf-8', errors='replace') as fh:
-                h.update(name.encode() + b'\0' + _code_only(fh.read()).encode())
+    files = [os.path.join(csrc, name) for name in sorted(os.listdir(csrc)) if name.endswith(('.hip', '.h', '.cpp'))]
+    files.append(os.path.join(ROOT, 'include', 'smart_amd.h'))
+    for path in files:
+        with open(path, 'r', encoding='utf-8', errors='replace') as fh:
+            h.update(os.path.basename(path).encode() + b'\0' + _code_only(fh.read()).encode())
+    from smartpy_amd import build as hip_build
+    for unit in sorted(hip_build.UNITS):
+        h.update(('%s: %s\0' % (unit, ' '.join(hip_build.COMMON + hip_build.UNITS[unit]))).encode())
     return h.hexdigest()[:16]
 
 

@@ -207,7 +207,8 @@ int smart_allsteps_hip(double area_m2, double delta_sec, int64_t length_simu, co
                        double *groundwater_component, double *final_vars);
 
 /* Counters of the smartcpp.allsteps stand-in, for tests and logs: counters[0..n) of { calls, device allocations made,
- * bytes of forcing uploaded, calls served in fast arithmetic } since the library was loaded (n <= 4). */
+ * bytes of forcing uploaded, calls served in fast arithmetic, planning passes made for them (ABI 6: one per series,
+ * length and report, not one per call) } since the library was loaded (n <= 5). */
 int smart_hook_counters(int64_t *counters, int64_t n);
 
 /*

@@ -12,7 +12,7 @@
 #include <vector>
 
 namespace smart {
-void launch_literal(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s, bool recip);
+void launch_literal(const KArgs &a, dim3 grid, size_t lds_bytes, hipStream_t s, bool rows);
 void launch_onestep(long n, const double *in, double *out, hipStream_t s);
 void launch_river(long n, const double *in, double *out, hipStream_t s);
 
@@ -737,7 +737,7 @@ static int decide(const SmartEnsemble *e, const DeviceCtx *d, const Workspace &w
     return SMART_OK;
 }
 
-static int run(const SmartEnsemble *e, bool literal_recip = false)
+static int run(const SmartEnsemble *e, bool literal_rows = false)
 {
     int rc = check(e);
     if (rc)
@@ -756,7 +756,7 @@ static int run(const SmartEnsemble *e, bool literal_recip = false)
         if (w.hdr) // a clean status word for smart_launch_status (a fast launch before this one may have left its own)
             reset_workspace(w, e->n_catchments, nullptr, 0, s);
         a.hdr = nullptr;
-        launch_literal(a, grid, a.np_mean ? (size_t)a.gap * kWave * sizeof(double) : 0, s, literal_recip);
+        launch_literal(a, grid, a.np_mean ? (size_t)a.gap * kWave * sizeof(double) : 0, s, literal_rows);
         HIP_TRY(hipGetLastError());
         return SMART_OK;
     }
@@ -939,6 +939,17 @@ struct HookCache {
     size_t io_cap = 0;         // doubles
     std::vector<double> stage;
     int64_t n_calls = 0, n_malloc = 0, bytes_up = 0, n_fast = 0;
+    // SMART_ALLSTEPS_MATH=fast: what smart_plan_ensemble said about the first `len` steps of the cached series under a
+    // report (gap, type) -- the kinds of forcing it holds, and whether the launch came back with a status word (a NaN or
+    // an infinity in the series: the literal kernel's business).  A calibration loop calls with the same (len, gap,
+    // type) thousands of times (two of them per simulate(): warm-up, run); the entries die with the cached series.
+    struct Known {
+        int64_t len, gap;
+        int type, forcing_bits;
+        bool literal_only;
+    };
+    std::vector<Known> known;
+    int64_t n_plans = 0;
 };
 static HookCache g_hook;
 static std::mutex g_hook_mu;
@@ -957,6 +968,43 @@ static int hook_reserve(double **buf, size_t *cap, size_t want)
     ++g_hook.n_malloc;
     *cap = room;
     return SMART_OK;
+}
+
+// wave_class() (smart_fast_model.h) for ONE row, on the host: which arithmetic class its kernel is.  The device's own
+// classification stays authoritative -- a row this function puts into the wrong class meets no kernel, raises
+// SMART_STATUS_STALE_PLAN, and the call repeats in literal arithmetic -- so what is needed here is agreement on ordinary
+// rows, which the rules being the same ones gives.
+static int host_row_class(const double *p, double dt, const double *st12, double area)
+{
+    auto nonfinite = [](double x) {
+        unsigned long long u;
+        std::memcpy(&u, &x, sizeof(u));
+        return (u & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+    };
+    const bool stiff = !(p[6] * 3600.0 >= dt && p[7] * 3600.0 >= dt && p[8] * 3600.0 >= dt && p[9] * 3600.0 >= dt);
+    const bool guard = !(p[4] >= 0.0 && p[4] <= 0.5 && p[1] >= 0.0 && p[5] > 0.0);
+    bool wild = !(p[9] * 3600.0 >= 0.5 * dt);
+    for (int i = 0; i < 10; ++i)
+        wild = wild || nonfinite(p[i]);
+    wild = wild || !(p[3] >= 0.0 && p[3] <= 1.0) || !(p[2] >= 0.0 && p[2] <= 1.0) || !(p[0] >= 0.0);
+    wild = wild || !(p[6] > 0.0 && p[7] > 0.0 && p[8] > 0.0 && p[9] > 0.0);
+    wild = wild || !(p[5] > 0.0) || !(p[0] >= 0.2) || !(p[5] <= 1.0e3) || !(p[5] >= 1.0);
+    if (st12) {
+        double lay = 0.0;
+        for (int i = 0; i < 12; ++i) {
+            unsigned long long u;
+            std::memcpy(&u, &st12[i], sizeof(u));
+            wild = wild || nonfinite(st12[i]) || u > 0x8000000000000000ull;
+            if (i >= 5 && i < 11)
+                lay += st12[i];
+        }
+        if (!wild) {
+            const double fill = (lay / area * 1e3) / p[5];
+            const double s_init = p[4] * fill, h_init = p[2] * fill;
+            wild = !(s_init <= 0.5) || !(h_init <= 1.0); // (a NaN fails both compares)
+        }
+    }
+    return wild ? 3 : (guard ? 2 : (stiff ? 1 : 0));
 }
 
 static int allsteps(double area_m2, double delta_sec, int64_t length_simu, const double *nd_rain,
@@ -983,6 +1031,7 @@ static int allsteps(double area_m2, double delta_sec, int64_t length_simu, const
         h.cap = h.io_cap = 0;
         h.rain.clear();
         h.peva.clear();
+        h.known.clear();
         h.device = dev;
     }
     ++h.n_calls;
@@ -996,6 +1045,7 @@ static int allsteps(double area_m2, double delta_sec, int64_t length_simu, const
                  std::memcmp(h.peva.data(), nd_peva, have * sizeof(double)))) {
         h.rain.clear();
         h.peva.clear();
+        h.known.clear();
     }
     if (2 * L > h.cap) { // a longer series than the buffer holds: a new buffer, everything uploaded again.  The first
                          // one has room for 15 years of hourly steps: the warm-up call that usually comes first is short
@@ -1004,6 +1054,7 @@ static int allsteps(double area_m2, double delta_sec, int64_t length_simu, const
             return rc;
         h.rain.clear();
         h.peva.clear();
+        h.known.clear();
     }
     if (h.rain.size() < L) {
         const size_t from = h.rain.size(), n = L - from;
@@ -1069,12 +1120,43 @@ static int allsteps(double area_m2, double delta_sec, int64_t length_simu, const
     // SMART_ALLSTEPS_MATH=fast: the fast kernels for this one sample (interval engine / step loop, SPLIT: the final row is
     // asked for) -- <= 1e-9 of the reference instead of its bits, at a tenth of the time.  Default: literal arithmetic.
     e.math_mode = fast ? SMART_MATH_FAST : SMART_MATH_LITERAL;
-    rc = run(&e, /*literal_recip=*/true);
-    if (rc == SMART_OK && fast) {
+    if (fast) {
+        // ONE kernel for ONE row: the row's class worked out here (ten numbers), the kinds of forcing of this series
+        // remembered from the first call with this (length, gap, report type).  Round 4 left e.plan at 0: six kernels,
+        // the forcing scan, an auxiliary-stream fork and join per call -- for one sample, thousands of times.
+        HookCache::Known *k = nullptr;
+        for (auto &x : h.known)
+            if (x.len == length_simu && x.gap == report_gap && x.type == report_type)
+                k = &x;
+        if (!k) {
+            int32_t plan = 0;
+            if ((rc = make_plan(&e, &plan)))
+                return rc;
+            ++h.n_plans;
+            if (h.known.size() >= 8)
+                h.known.erase(h.known.begin());
+            h.known.push_back({length_simu, report_gap, report_type,
+                               plan & (SMART_PLAN_FORCING_PIECEWISE | SMART_PLAN_FORCING_VARYING | SMART_PLAN_FORCING_RUNS),
+                               false});
+            k = &h.known.back();
+        }
+        if (k->literal_only) { // (the series is known to hold a NaN or an infinity: straight to the literal kernel)
+            e.math_mode = SMART_MATH_LITERAL;
+        } else {
+            const int cls = host_row_class(nd_parameters, delta_sec, nd_initial + 7, area_m2);
+            e.plan = SMART_PLAN_VALID | k->forcing_bits | (1 << cls);
+        }
+    }
+    rc = run(&e, /*rows=*/true);
+    if (rc == SMART_OK && e.math_mode == SMART_MATH_FAST) {
         ++h.n_fast;
         int32_t word = 0;
         rc = launch_status(&e, &word);
-        if (rc == SMART_OK && word != 0) { // (a NaN in the series: the literal kernel's business)
+        if (rc == SMART_OK && word != 0) { // (a NaN in the series, a row this side put into the wrong class: literal)
+            if (word & SMART_STATUS_NONFINITE_FORCING)
+                for (auto &x : h.known)
+                    if (x.len == length_simu && x.gap == report_gap && x.type == report_type)
+                        x.literal_only = true;
             e.math_mode = SMART_MATH_LITERAL;
             rc = run(&e, true);
         }
@@ -1129,8 +1211,8 @@ int smart_hook_counters(int64_t *counters, int64_t n)
     if (!counters || n < 1)
         return fail(SMART_E_NULL, "smart_hook_counters: no room for the counters");
     std::lock_guard<std::mutex> lock(g_hook_mu);
-    const int64_t v[4] = {g_hook.n_calls, g_hook.n_malloc, g_hook.bytes_up, g_hook.n_fast};
-    for (int64_t i = 0; i < n && i < 4; ++i)
+    const int64_t v[5] = {g_hook.n_calls, g_hook.n_malloc, g_hook.bytes_up, g_hook.n_fast, g_hook.n_plans};
+    for (int64_t i = 0; i < n && i < 5; ++i)
         counters[i] = v[i];
     return SMART_OK;
 }

@@ -563,11 +563,11 @@ def allsteps(area_m2, delta_sec, length_simu, nd_rain, nd_peva, nd_parameters, n
 
 
 def hook_counters():
-    """{calls, allocations, forcing_bytes_uploaded, fast_calls} of the smartcpp.allsteps stand-in since the library
+    """{calls, allocations, forcing_bytes_uploaded, fast_calls, plans} of the smartcpp.allsteps stand-in since the library
     was loaded (smart_hook_counters)."""
-    c = (ctypes.c_int64 * 4)()
-    _lib.check(_lib.lib().smart_hook_counters(c, 4))
-    return dict(zip(('calls', 'allocations', 'forcing_bytes_uploaded', 'fast_calls'), (int(v) for v in c)))
+    c = (ctypes.c_int64 * 5)()
+    _lib.check(_lib.lib().smart_hook_counters(c, 5))
+    return dict(zip(('calls', 'allocations', 'forcing_bytes_uploaded', 'fast_calls', 'plans'), (int(v) for v in c)))
 
 
 def onestep(*args):
