@@ -799,23 +799,36 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
         rep.prime(a, 0);
     const bool every_step = a.gap == 1; // (a mean over one value is the value: x / 1.0 == x, no division)
 
-    if constexpr (kAhead) {
-        if (every_step) {
-            // A report every step (a daily run with daily reports: BASELINE config 2's ill-conditioned rows), either
-            // report type -- the mean over one step is the step's outflow, and the groundwater sums of the reported rows
-            // are those of all rows -- as a loop of its own: step, report, nothing to count and nothing to branch on.
-            // (In the general loop below the report sits out of line behind `++k == len`: two taken branches and the
-            // counters' bookkeeping per step cost the lone wavefront as much as half a step of the model.)
-            double sink = 0.0, num1 = 0.0, den1 = 0.0;
-            long r1 = 0;
-            time_loop(m, f, a.T, [&](const double2 v, const double ex) {
-                m.step(v.x, v.y, ex, sink, num1, den1);
-                rep.emit_ahead(a, x, r1, m.q_out);
-                ++r1;
-            });
-            write_results(a, x, m, rep, num1 / den1, nullptr);
-            return;
-        }
+    // the last row of the storage table holds the seven outputs of the last step (structure.py:197): models that do not
+    // track them take the last step on its own, after working them out from the state it starts from
+    const bool capture = a.final_vars != nullptr && !Model::kTracksOutputs;
+    if (every_step && !capture) {
+        // A report every step (a daily run with daily reports: BASELINE config 2), either report type -- the mean over
+        // one step is the step's outflow (x / 1.0 == x * 1.0 == x), and the groundwater sums of the reported rows are
+        // those of all rows -- as a loop of its own: step, report, nothing to count and nothing to branch on.  In the
+        // general loop below the report sits out of line behind `++k == len`: two taken branches and the counters'
+        // bookkeeping per step cost a lone wavefront as much as half a step of the literal model (round 5: the
+        // ill-conditioned rows of config 2 2.97 -> 2.18 ms, the stiff ones 1.62 -> see profiles/r05_config2.md).
+        double num1 = 0.0, den1 = 0.0, total1 = 0.0;
+        long r1 = 0;
+        if constexpr (Model::kBalanceSums)
+            m.begin_run();
+        time_loop(m, f, a.T, [&](const double2 v, const double ex) {
+            double acc1 = 0.0;
+            m.step(v.x, v.y, ex, acc1, num1, den1);
+            const double val = summary ? acc1 : m.q_out;
+            if constexpr (kAhead)
+                rep.emit_ahead(a, x, r1, val);
+            else
+                rep.emit(a, x, r1, val);
+            ++r1;
+            if constexpr (Model::kBalanceSums)
+                total1 += acc1;
+        });
+        if constexpr (Model::kBalanceSums)
+            m.balance_sums(total1, num1, den1);
+        write_results(a, x, m, rep, num1 / den1, nullptr);
+        return;
     }
 
     double num = 0.0, den = 0.0;         // groundwater sums over every step (summary, structure.py:191)
@@ -857,10 +870,7 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
             acc = 0.0;
         }
     };
-    // the last row of the storage table holds the seven outputs of the last step (structure.py:197): models that do not
-    // track them take the last step on its own, after working them out from the state it starts from
     double flows[7];
-    const bool capture = a.final_vars != nullptr && !Model::kTracksOutputs;
     time_loop(m, f, capture ? a.T - 1 : a.T, one_step);
     if (capture) {
         const double2 v = f[a.T - 1];
