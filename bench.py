@@ -559,7 +559,12 @@ def main():
             'frac_from_model': None if insts_model is None else
             insts_model * VALU_ISSUE_CYCLES / (N_SIMD * kern_s * CLOCK_HZ),
             'model_source': model_note,
-            'kernel': kernels, 'launch_ms': launch_ms, 'traffic': traffic, 'pmc_key': pmc_key, 'pmc_source': pmc_note,
+            'kernel': kernels, 'launch_ms': launch_ms, 'traffic': traffic,
+            # counters over algorithm: HBM bytes per launch as the PMC passes count them (FETCH_SIZE with the guide's gfx950
+            # correction + WRITE_SIZE) against the algorithmic bytes of `hbm` below; the excess is the time slices'
+            # hand-overs (1.3 x with the matrix stored; without one the hand-overs are all there is: 20 - 40 x of very little)
+            'traffic_ratio': None if traffic is None else traffic / (units_per_launch * bytes_per_step),
+            'pmc_key': pmc_key, 'pmc_source': pmc_note,
             # the reference's literal operation count against the fp64 vector peak: NOT a bound (the kernel executes
             # fewer operations than the reference writes down), kept as the algorithmic ratio
             'algorithmic_ratio': {'note': 'not a bound: the reference\'s operation count over the time of a kernel '
