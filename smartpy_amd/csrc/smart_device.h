@@ -701,6 +701,35 @@ struct Reporter {
         }
     }
 
+    // ... the same with the report's place in the discharge matrix kept as a per-lane pointer that moves on by ld per report
+    // (begin_rows() ahead of the first): a loop that reports every step spares itself a 64-bit multiply-add on the scalar
+    // unit -- and the scalar registers its operands live in -- per step
+    __device__ __forceinline__ void emit_ahead_row(const KArgs &a, const LaneCtx &x, long r, double val)
+    {
+        const double e = e_nx, w = w_nx;
+        prime(a, r + 1);
+        if (a.discharge) {
+            if (x.live)
+#if SMART_NT_STORE
+                __builtin_nontemporal_store(val, row);
+#else
+                *row = val;
+#endif
+            row += a.ld;
+        }
+        if (want_obj && r == 0)
+            shift = val;
+        if (want_obj && !is_nan_bits(e)) { // montecarlo.py:195-196
+            const double d = val - e;
+            const double u = val - shift;
+            A += d;
+            B += d * d;
+            C1 += u;
+            C2 += u * u;
+            C3 += w * u;
+        }
+    }
+
     // The streamed step loop (FastModel::stream_stretch) reports inside its asm (smart_fast_arms.h: SMART_P_REPORT) -- what
     // emit() does, operation for operation, with three differences of form: the report's place in the discharge matrix is
     // this per-lane pointer, moved on by ld per report (begin_rows / next_row keep it in step when emit() reports); a
@@ -811,6 +840,8 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
         // ill-conditioned rows of config 2 2.97 -> 2.18 ms, the stiff ones 1.62 -> see profiles/r05_config2.md).
         double num1 = 0.0, den1 = 0.0, total1 = 0.0;
         long r1 = 0;
+        if constexpr (kAhead)
+            rep.begin_rows(a, x, 0);
         if constexpr (Model::kBalanceSums)
             m.begin_run();
         time_loop(m, f, a.T, [&](const double2 v, const double ex) {
@@ -818,7 +849,7 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
             m.step(v.x, v.y, ex, acc1, num1, den1);
             const double val = summary ? acc1 : m.q_out;
             if constexpr (kAhead)
-                rep.emit_ahead(a, x, r1, val);
+                rep.emit_ahead_row(a, x, r1, val);
             else
                 rep.emit(a, x, r1, val);
             ++r1;

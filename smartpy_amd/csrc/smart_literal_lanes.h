@@ -46,7 +46,7 @@ namespace smart {
 // call (noinline), so that its registers are its own: inlined, the ~180 VGPRs of the literal step on top of the row
 // form's constants spilled into the hot loop (round 5: 117 ms per smartcpp.allsteps call instead of 61).  Every lane
 // of a row computes the same numbers.
-__device__ __attribute__((noinline)) static void literal_guarded_step(double *io)
+__device__ __attribute__((noinline, cold)) static void literal_guarded_step(double *io)
 {
     LiteralModel m;
     m.setup(io[10], io[11], io);
@@ -100,6 +100,7 @@ struct LiteralLanesModel {
     double LY, V, VRIV;
     // outputs of the last step
     double out0, outq, out6;
+    double aeva_last;  // actual evaporation [mm] of the last quick step: out[0] = (aeva / 1e3) area / dt, on demand
     double q_out, q_in, q_gw;
     bool quick;
 #ifdef SMART_LANES_COUNT
@@ -147,7 +148,7 @@ struct LiteralLanesModel {
         }
         nby = is_layer ? (double)(r + 1) : 1.0;
         by = 1.0 / nby;
-        out0 = outq = out6 = 0.0;
+        out0 = outq = out6 = aeva_last = 0.0;
         q_out = q_in = q_gw = 0.0;
         quick = false;
         // The conditions of LiteralModelT<true>'s reciprocal path: a divisor is fit for the correction step if it is a
@@ -211,7 +212,8 @@ struct LiteralLanesModel {
 
     __device__ void get_vars(double *v, const double * = nullptr) const
     {
-        v[0] = out0;
+        // (the last step was a quick one iff the last chunk was: `quick`; the guarded form leaves its out[0] in out0)
+        v[0] = quick ? Slow::dv<true>(Slow::dv<true>(aeva_last, 1e3, 1e-3) * s.area, s.dt, s.y_dt) : out0;
         v[1] = bcast<kOve>(outq);
         v[2] = bcast<kDra>(outq);
         v[3] = bcast<kInt>(outq);
@@ -425,7 +427,7 @@ struct LiteralLanesModel {
             aeva = rain; // 0.0 + rain: rain = rain_in * T is +0 or positive (T >= 0 is one of the run's conditions)
             evaporation(aeva, l, X, ex0);
         }
-        out0 = Slow::dv<true>(Slow::dv<true>(aeva, 1e3, 1e-3) * area, dt, s.y_dt); // :424
+        aeva_last = aeva; // (:424: the evaporation flow of the step is worked out when somebody asks for it, get_vars)
         // V / k as a TRUE division: a reservoir that is rarely fed (the drain: saturation excess only) decays geometrically
         // below the range the correction step is proven for, stays there for hundreds of steps, and in this form the five
         // quotients are one instruction sequence anyway (ten instructions instead of three)
