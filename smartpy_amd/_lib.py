@@ -86,6 +86,21 @@ def _apply_lint_verdict():
     import warnings
     from . import isa_lint
     ok, pairs, reason = isa_lint.verdict_for(LIB_PATH)
+    if ok and not pairs and isa_lint.read_sidecar(LIB_PATH) is None or (
+            ok and not pairs and 'another build' in reason):
+        # no record, or one for another file (a library that travelled without it, or was rebuilt by something else):
+        # look at the code now if the disassembler is at hand (~6 s, once: the record is written for the next load)
+        if os.path.exists(isa_lint.OBJDUMP):
+            report = isa_lint.check_library(LIB_PATH)
+            try:
+                isa_lint.write_sidecar(report, LIB_PATH)
+            except OSError:
+                pass
+            if report['checked']:
+                if report['handover'] is False or report['rows'] is False:
+                    ok, pairs, reason = False, False, '; '.join(report['problems'])
+                else:
+                    ok, pairs, reason = True, bool(report['pair_blocks']), '; '.join(report['problems'])
     if not ok:
         raise ImportError("smartpy_amd: %s failed the code lints of smartpy_amd.isa_lint (%s); rebuild it with "
                           "`python -m smartpy_amd.build --force`" % (LIB_PATH, reason))
