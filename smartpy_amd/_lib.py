@@ -86,8 +86,8 @@ def _apply_lint_verdict():
     import warnings
     from . import isa_lint
     ok, pairs, reason = isa_lint.verdict_for(LIB_PATH)
-    if ok and not pairs and isa_lint.read_sidecar(LIB_PATH) is None or (
-            ok and not pairs and 'another build' in reason):
+    unrecorded = isa_lint.read_sidecar(LIB_PATH) is None or 'another build' in reason
+    if ok and not pairs and unrecorded:
         # no record, or one for another file (a library that travelled without it, or was rebuilt by something else):
         # look at the code now if the disassembler is at hand (~6 s, once: the record is written for the next load)
         if os.path.exists(isa_lint.OBJDUMP):

@@ -101,13 +101,23 @@ def test_a_repeated_simulate_uploads_its_ten_parameters_and_nothing_else(example
                              sm.timeseries_report, 'summary', warm_up=sm.warm_up)
         assert bits_equal(d, want[0]) and g == want[1]
     assert bits_equal(sm.simulate(dict(zip(names, base)))[0], first[0])
-    # another report type is another kept run; the series are looked up by identity: replacing one starts afresh
+    # another report type is another kept run; the series are COMPARED with what is on the device on every call: the same
+    # numbers in another array cost nothing, a value written into the user's own array is noticed
     raw = sm.simulate(dict(zip(names, base)), report='raw')
     assert raw[0].shape == first[0].shape and len(sm._single) == 2
     sm.nd_rain = sm.nd_rain * 1.0
     before = engine.h2d_bytes
     again = sm.simulate(dict(zip(names, base)))
-    assert engine.h2d_bytes - before > 80 and bits_equal(again[0], first[0])
+    assert engine.h2d_bytes - before == 80 and bits_equal(again[0], first[0])
+    sm.nd_rain[100] += 5.0                                   # in place: same array object, other numbers
+    before = engine.h2d_bytes
+    wetter = sm.simulate(dict(zip(names, base)))
+    assert engine.h2d_bytes - before > 80 and not bits_equal(wetter[0], first[0]) and len(sm._single) == 1
+    want = structure.run(sm.area, sm.delta_simu, sm.nd_rain, sm.nd_peva, base, sm.extra, sm.timeseries,
+                         sm.timeseries_report, 'summary', warm_up=sm.warm_up)
+    assert bits_equal(wetter[0], want[0])
+    sm.nd_rain[100] -= 5.0
+    assert bits_equal(sm.simulate(dict(zip(names, base)))[0], first[0])
 
 
 def bits_equal(a, b):
