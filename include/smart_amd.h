@@ -255,6 +255,16 @@ int smart_db_append_rows(const char *path, const float *table, int64_t n_rows, i
 int64_t smart_db_parse_rows(const char *text, int64_t len, int64_t n_cols, const int32_t *cols, int32_t n_use,
                             float *out, int64_t max_rows, int32_t n_threads);
 
+/* The arithmetic class of ONE parameter row -- 0 regular, 1 stiff, 2 guard, 3 ill-conditioned / literal: the c of the
+ * SMART_PLAN_CLASS_* bit (1 << c) its kernel answers to -- worked out on the host with the rules the kernels apply on
+ * the device (smart_fast_model.h: wave_class).  params[10] as lhs.py:114 lays them out; initial12: the twelve initial
+ * states of the row, or NULL (the reference's half-full soil / educated guess, structure.py:97-140); area_m2 is read with
+ * initial12 only.  Pure host code, no device needed.  smart_allsteps_hip classifies its one row with it (ABI 6); a
+ * caller that launches one row at a time can fill SmartEnsemble.plan the same way:
+ *   plan = SMART_PLAN_VALID | (forcing bits of an earlier smart_plan_ensemble) | (1 << smart_row_class(...)).
+ * The device stays authoritative: a row this call misjudges meets no kernel and raises SMART_STATUS_STALE_PLAN. */
+int smart_row_class(const double *params, double delta_sec, const double *initial12, double area_m2);
+
 /* Device bookkeeping */
 int smart_device_count(void);           /* number of visible HIP devices (0 if none / no driver)      */
 int smart_abi_version(void);            /* SMART_AMD_ABI_VERSION the library was built with           */

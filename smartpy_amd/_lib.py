@@ -58,6 +58,7 @@ SYMBOLS = {
     'smart_db_parse_rows': (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.POINTER(ctypes.c_int32), ctypes.c_int32,
                                              ctypes.POINTER(ctypes.c_float), ctypes.c_int64, ctypes.c_int32]),
+    'smart_row_class': (ctypes.c_int, [_dp, ctypes.c_double, _dp, ctypes.c_double]),
     'smart_device_count': (ctypes.c_int, []),
     'smart_abi_version': (ctypes.c_int, []),
     'smart_build_info': (ctypes.c_char_p, []),

@@ -1290,6 +1290,13 @@ int smart_objfn_hip(int64_t n_samples, int64_t n_reports, const double *sim, int
     return SMART_OK;
 }
 
+int smart_row_class(const double *params, double delta_sec, const double *initial12, double area_m2)
+{
+    if (!params)
+        return fail(SMART_E_NULL, "smart_row_class: params is NULL");
+    return host_row_class(params, delta_sec, initial12, area_m2);
+}
+
 int smart_device_count(void)
 {
     int n = 0;

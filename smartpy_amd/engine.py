@@ -509,7 +509,7 @@ class SingleRun(object):
         p = self._prep
         if p._e.math_mode == MATH_FAST and p._ws is not None:
             # the row's class on the host (ten numbers, the rules of wave_class): the plan names its kernel and no other
-            cls = int(variant_classes(torch.from_numpy(row), self.delta_sec)[0])
+            cls = int(_lib.lib().smart_row_class(row.ctypes.data, self.delta_sec, None, 0.0))
             p._e.plan = _lib.PLAN_VALID | self._forcing_bits | _lib.PLAN_CLASS_BITS[cls]
             p.enqueue()
             out = p.verify()

@@ -398,6 +398,50 @@ def test_public_surface_has_every_name_of_the_reference():
     assert not problems, problems
 
 
+def test_the_three_statements_of_the_row_classes_agree():
+    """The rule that sends a parameter row to its arithmetic class is written down three times: on the device
+    (smart_fast_model.h: wave_class, authoritative), in torch for whole matrices (engine.variant_classes, which groups
+    the rows of a launch), and since round 5 in C on the host for ONE row (smart_row_class: smartcpp.allsteps and
+    SMART.simulate() name one kernel per call with it).  The two host statements are compared here on default-range
+    rows, daily and hourly, on rows with every kind of parameter that is none, and on given initial states; the GPU
+    suite compares the torch one with the device (smart_plan_ensemble's bits)."""
+    import ctypes
+    import torch
+    from smartpy_amd import engine, _lib
+    from oracle import lhs_oracle
+    L = _lib.lib()
+
+    def one(row, dt, init=None, area=0.0):
+        row = np.ascontiguousarray(row, dtype=np.float64)
+        st = None if init is None else np.ascontiguousarray(init, dtype=np.float64)
+        return L.smart_row_class(row.ctypes.data, dt, None if st is None else st.ctypes.data, area)
+
+    rng = np.random.default_rng(77)
+    p = lhs_oracle.lhs_params(4000, seed=21)
+    # a tenth of the rows get one parameter that is none, of every kind the rules name
+    odd = rng.choice(len(p), 400, replace=False)
+    kinds = [(0, -0.3), (0, 0.1), (1, -0.2), (2, 1.4), (2, -0.01), (3, 3.0), (3, -1.0), (4, 0.7), (4, -0.1), (5, 0.0),
+             (5, 0.4), (5, 5e3), (6, 0.0), (7, -2.0), (8, 0.0), (9, -1.0), (9, 0.3), (6, 0.5), (0, np.nan), (4, np.inf),
+             (9, np.nan), (5, -np.inf)]
+    for n, r in enumerate(odd):
+        col, val = kinds[n % len(kinds)]
+        p[r, col] = val
+    for dt in (86400.0, 3600.0, 900.0):
+        want = engine.variant_classes(torch.from_numpy(p), dt).numpy()
+        got = np.array([one(p[r], dt) for r in range(len(p))])
+        assert np.array_equal(got, want), (dt, np.nonzero(got != want)[0][:5])
+        assert set(np.unique(want)) >= {0, 2, 3}
+    # given initial states: NaN, infinity, a negative volume, -0.0 (a zero like any other), soil above capacity
+    q = lhs_oracle.lhs_params(256, seed=22)
+    init = np.full((256, 12), 1e5)
+    init[3, 0], init[9, 7], init[17, 11], init[25, 6], init[33, 4] = np.nan, np.inf, -1.0, 1e13, -0.0
+    init[40:80, 5:11] = rng.uniform(0.0, 6e6, (40, 6))          # some of these stand far above capacity
+    area = 175.46e6
+    want = engine.variant_classes(torch.from_numpy(q), 3600.0, torch.from_numpy(init), [area]).numpy()
+    got = np.array([one(q[r], 3600.0, init[r], area) for r in range(len(q))])
+    assert np.array_equal(got, want) and (want[[3, 9, 17, 25]] == 3).all() and want[33] == 0 and (want[40:80] == 3).any()
+
+
 # ---- sharding arithmetic -----------------------------------------------------------------------------------------
 def test_rows_are_classified_and_grouped_by_arithmetic_variant():
     """engine.variant_classes mirrors wave_class() of csrc/smart_fast_model.h: 1 stiff (some k*3600 < dt), 2 guarded
