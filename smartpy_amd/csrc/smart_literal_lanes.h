@@ -298,7 +298,7 @@ struct LiteralLanesModel {
         asm volatile("v_add_f64 %[sp], %[z], -%[l]\n\t"
                      "v_mul_f64 %[q], %[tot], %[yz]\n\t"
                      "v_fma_f64 %[r], -%[pZ], %[q], %[tot]\n\t"
-                     "v_fma_f64 %[q], %[r], %[yz], %[q]\n\t"
+                     "v_fmac_f64_e32 %[q], %[r], %[yz]\n\t"
                      "v_mul_f64 %[hp], %[pH], %[q]\n\t"
                      "v_mul_f64 %[r], %[hp], %[ex]\n\t"
                      "v_fma_f64 %[e], -%[r], %[wof], %[ex]\n\t"
@@ -364,7 +364,7 @@ struct LiteralLanesModel {
         double t, r;
         asm volatile("v_mul_f64 %[t], %[X], %[km]\n\t"
                      "v_fma_f64 %[r], -%[k], %[t], %[X]\n\t"
-                     "v_fma_f64 %[t], %[r], %[km], %[t]\n\t"
+                     "v_fmac_f64_e32 %[t], %[km], %[r]\n\t"
                      "v_mul_f64 %[t], %[t], %[area]\n\t"
                      "v_mul_f64 %[r], %[q], %[dt]\n\t"
                      "v_add_f64 %[t], %[t], -%[r]\n\t"
