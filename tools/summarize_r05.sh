@@ -19,7 +19,8 @@ for t in flat_forcing_1e6 raw_gap24_flat; do python $S gpurun_out/prof_r05_$t pr
   echo "round 3 ran these through smart_fast_plain, the general step loop, unsliced: 24.8 ms (raw, gap 24) and 43.7 ms (gap 1)."
   for t in raw_gap24 raw_gap24_flat gap1; do echo; echo "## $t"; echo; sed -n '/kernel stats/,$p' profiles/r05_$t.md; done; } > profiles/r05_plain.md
 cp gpurun_out/r05_recip_bits.txt profiles/
-[ -f gpurun_out/soak_round.log ] && cp gpurun_out/soak_round.log profiles/r05_time_slice_soak.txt
+for f in r05_time_slice_soak r05_microbench_lanes r05_hook_time r05_config2_classes; do [ -f gpurun_out/$f.txt ] && cp gpurun_out/$f.txt profiles/; done
+python tools/kernel_hashes.py > profiles/r05_kernel_hashes.txt 2>&1
 for c in "" _c2 _c4 _c5 _c4shard; do grep '^{' gpurun_out/bench_r05$c.log > profiles/r05_bench_${c#_}.jsonl; done
 mv profiles/r05_bench_.jsonl profiles/r05_bench_config3.jsonl   # (tools/gpu_final_check.sh's line is appended to it afterwards)
 for k in steps intervals steps_every intervals_raw; do python tools/isa_report.py smart_fast_$k profiles/r05_isa_$k --hot > /dev/null; done
