@@ -35,7 +35,7 @@ def rel(a, b, floor=0.0):
 #: what an excess() has to stay below.  1.0 is the tolerance itself; the call sites are held to a TENTH of it, which is
 #: where the measured margins allow it (round 5: the margins of a GPU run are printed at the end of the module and
 #: written to gpurun_out/parity_margins.txt -- the largest one the suite produces is 0.022).  A call site that needs more
-#: says so with a number of its own and the measurement behind it (two do: run_interval_cases, 0.5).
+#: says so with a number of its own and the measurement behind it (three do: run_interval_cases, 0.5).
 EXCESS_GATE = 0.1
 MARGINS = {}        # call site (line of this file) -> largest excess() seen there in this run
 
@@ -1473,14 +1473,14 @@ def run_interval_cases(eng, setenv, seed, n_cases, mode='summary'):
         good = ~(params[:, 9] * 3600.0 < 0.5 * dt)          # dt / RK <= 2: not the literal model's
         if good.any():
             got = fast.discharge.cpu().numpy()[good]
-            # (this family's two comparisons of a series get half the tolerance, not a tenth: of 2,400 fuzzed set-ups -- seeds
-            # 30000..30399, profiles/r05_fuzz.txt -- one reached 0.15 here and one 0.25 on the scores below, both under a
-            # report every step of a run of a few hundred steps; everything else stays below 0.03)
+            # (three comparisons of this family get half the tolerance, not a tenth: of 6,000 fuzzed set-ups -- seeds
+            # 30000..30399 and 31000..31599, profiles/r05_fuzz.txt -- one reached 0.15 here, one 0.20 on the groundwater ratio
+            # and one 0.25 on the scores below, each once, on runs of a few hundred steps; everything else stays below 0.03)
             assert excess(got, d1[good], REL_FAST) <= 5 * EXCESS_GATE, tag
             big = np.abs(d1[good]) > 1e-6 * np.abs(d1[good]).max(axis=1, keepdims=True)
             worst = max(worst, rel(got[big], d1[good][big]))
             ok = np.isfinite(g1[good])         # a ratio of sums: absolute floor of 1e-13 on a number in [0, 1]
-            assert excess(fast.gw.cpu().numpy()[good][ok], g1[good][ok], 1e-9, top=1.0) <= EXCESS_GATE, tag
+            assert excess(fast.gw.cpu().numpy()[good][ok], g1[good][ok], 1e-9, top=1.0) <= 5 * EXCESS_GATE, tag   # (0.20 once)
             want = objfn_oracle.objective_matrix(d1[good], obs, g1[good], 0.2)
             got = fast.objfn.cpu().numpy()[good]
             fin = np.isfinite(want[:, :7]).all(axis=1)
