@@ -305,6 +305,15 @@ def api_legs(forcing, obs, W_days, device):
             t2 = time.perf_counter()
             lhs.run()
             t3 = time.perf_counter()
+            # ... and SMART.simulate() on that very model (the shipped example's own series and parameter file)
+            lhs.model.parameters.set_parameters_with_file(os.path.join(tmp, 'in', 'Catchment', 'Catchment.parameters'))
+            lhs.model.simulate(lhs.model.parameters.values)
+            es = []
+            for row in rows[:5]:
+                t4 = time.perf_counter()
+                lhs.model.simulate(dict(zip(names, row)))
+                es.append((time.perf_counter() - t4) * 1e3)
+            legs['simulate_ms']['shipped_example_best'] = min(es)
             legs['e2e_lhs'] = {
                 'what': "montecarlo.LHS('Catchment', root, 'csv', 'csv', 100000) on the shipped example (2007-2016, hourly "
                         "steps, daily reports, 365 days of warm-up): constructor, then run() = one launch + device -> host "
