@@ -1575,6 +1575,47 @@ def test_asm_loops_are_bit_identical_to_the_compiled_ones(tmp_path):
         assert bits_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize('dt, gap, report, n_rows', [(3600.0, 24, 'summary', 203), (3600.0, 6, 'summary', 64), (10800.0, 7, 'raw', 130),
+                                                      (86400.0, 1, 'raw', 37), (900.0, 96, 'summary', 5)])
+def test_the_row_form_of_the_literal_step_under_every_kind_of_report(eng, example, dt, gap, report, n_rows):
+    """Round 5: the ill-conditioned rows of the fast mode run the literal step with one sample per DPP row
+    (smart_literal_lanes.h).  Besides BASELINE config 2's case (daily steps, a report every step: test_config2...) --
+    sub-daily steps with interval means over 6, 24 and 96 steps, raw reports over a ragged time axis, a report every
+    step; row counts that leave wavefronts with one, two and three of their four rows dead; with and without the educated
+    guess, warm-up and none; two catchments in one launch.  Every row has dt / RK > 2, so every row is the row form's;
+    discharge, groundwater ratio and final state are the oracle's bits (reference operation order, the product chain
+    for s' ** i, left-to-right interval sums: what the fast mode's own report does)."""
+    rng = np.random.default_rng(int(dt) + 31 * gap + n_rows)
+    params = lhs_oracle.lhs_params(n_rows, seed=int(gap + n_rows))
+    params[:, 9] = rng.uniform(0.05, 0.45, n_rows) * dt / 3600.0           # dt / RK between 2.2 and 20
+    params[::7, 6] = 0.3 * dt / 3600.0                                     # ... some of them stiff elsewhere as well
+    steps_per_day = int(86400 // dt) if dt <= 86400 else 1
+    days = 40 if dt < 86400 else 400
+    T = days * steps_per_day + (0 if report == 'summary' else 3)           # raw: a ragged last interval
+    T -= T % gap if report == 'summary' else 0
+    W = (T // 4) - (T // 4) % gap
+    rain = np.repeat(rng.gamma(0.6, 5.0, T // steps_per_day + 1) * (rng.random(T // steps_per_day + 1) < 0.6),
+                     steps_per_day)[:T] / steps_per_day
+    peva = np.maximum(0.0, rng.normal(1.5, 1.0, T)) / steps_per_day
+    rtype = so.REPORT_SUMMARY if report == 'summary' else so.REPORT_RAW
+    for extra, warm in ((example['extra'], W), (None, 0)):
+        fast = eng.run_ensemble(params, forcing_of(rain, peva), example['area'], dt, warm, gap, report=report, extra=extra,
+                                want_final=True)
+        assert 'smart_fast_illcond' in fast._prepared.describe()
+        d0, g0, f0 = so.run_batch(example['area'], dt, T, warm, rain, peva, params, extra, rtype, gap,
+                                  pow_mode=so.POW_MUL, sum_mode=so.SUM_SEQ, want_final=True)
+        assert bits_equal(fast.discharge.cpu().numpy(), d0), (dt, gap, report, extra is None)
+        assert bits_equal(fast.gw.cpu().numpy(), g0) and bits_equal(fast.final_vars.cpu().numpy(), f0)
+    # two catchments in one launch (grid.y), each with its own area and forcing: each equals its own launch
+    areas = np.array([example['area'], 0.37 * example['area']])
+    f2 = np.stack([forcing_of(rain, peva), forcing_of(rain[::-1].copy(), peva)])
+    both = eng.run_ensemble(params, f2, areas, dt, W, gap, report=report, extra=example['extra'])
+    for c in range(2):
+        one = eng.run_ensemble(params, f2[c], float(areas[c]), dt, W, gap, report=report, extra=example['extra'])
+        assert bits_equal(both.discharge[c].cpu().numpy(), one.discharge.cpu().numpy())
+        assert bits_equal(both.gw[c].cpu().numpy(), one.gw.cpu().numpy())
+
+
 def test_ill_conditioned_rows_with_wild_parameters_match_the_literal_kernel(eng, example):
     """The ill-conditioned rows of the fast mode run the reference's operation order with a few identities applied where
     wave-uniform checks allow them (divisions through reciprocals, clamps and the two cascades' hand-downs as
