@@ -63,6 +63,12 @@ def device_identity(device):
     return '%s/%s' % (os.uname().nodename, uuid or 'pci-%s' % getattr(props, 'pci_bus_id', device.index))
 
 
+def shares_a_device(identities):
+    """Do two of the ranks (one device_identity() each) sit on the same physical GPU?  RCCL refuses that; what the answer
+    does NOT depend on is how many devices any one rank can see."""
+    return len(set(identities)) < len(identities)
+
+
 def init(backend=None):
     """Initialise torch.distributed from the environment (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE).
     Returns (rank, world_size, device).
@@ -95,7 +101,7 @@ def init(backend=None):
             dist.init_process_group(backend='cpu:gloo,cuda:nccl', rank=rank, world_size=world)
             where = [None] * world
             dist.all_gather_object(where, device_identity(device))         # host objects: gloo
-            _STAGED = len(set(where)) < world
+            _STAGED = shares_a_device(where)
             if _STAGED and rank == 0:
                 import warnings
                 warnings.warn("smartpy_amd.distributed: %d ranks on %d physical device(s): device tensors are staged "

@@ -442,6 +442,21 @@ def test_the_three_statements_of_the_row_classes_agree():
     assert np.array_equal(got, want) and (want[[3, 9, 17, 25]] == 3).all() and want[33] == 0 and (want[40:80] == 3).any()
 
 
+def test_rccl_or_host_staging_is_decided_by_the_devices_the_ranks_sit_on():
+    """distributed.init(): device tensors go through RCCL unless two ranks share one physical GPU -- told from the
+    ranks' (host, UUID) identities, not from WORLD_SIZE against device_count() (round 4's rule, which sent a launch with
+    one visible device per rank, or one over several nodes, through the host: advisor)."""
+    from smartpy_amd import distributed as sdist
+    eight = ['node-a/GPU-%02x' % k for k in range(8)]
+    assert not sdist.shares_a_device(eight)                                     # one node, eight GPUs
+    assert not sdist.shares_a_device(eight + ['node-b/GPU-%02x' % k for k in range(8)])     # two nodes, same UUID-less numbering
+    assert not sdist.shares_a_device(['node-a/GPU-07'])
+    assert sdist.shares_a_device(['box/GPU-00'] * 8)                            # the one-GPU box running the 8-rank path
+    assert sdist.shares_a_device(eight[:7] + eight[:1])
+    import os
+    assert os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') is not None            # set at import, ahead of any GPU call
+
+
 # ---- sharding arithmetic -----------------------------------------------------------------------------------------
 def test_rows_are_classified_and_grouped_by_arithmetic_variant():
     """engine.variant_classes mirrors wave_class() of csrc/smart_fast_model.h: 1 stiff (some k*3600 < dt), 2 guarded
