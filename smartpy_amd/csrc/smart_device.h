@@ -701,35 +701,6 @@ struct Reporter {
         }
     }
 
-    // ... the same with the report's place in the discharge matrix kept as a per-lane pointer that moves on by ld per report
-    // (begin_rows() ahead of the first): a loop that reports every step spares itself a 64-bit multiply-add on the scalar
-    // unit -- and the scalar registers its operands live in -- per step
-    __device__ __forceinline__ void emit_ahead_row(const KArgs &a, const LaneCtx &x, long r, double val)
-    {
-        const double e = e_nx, w = w_nx;
-        prime(a, r + 1);
-        if (a.discharge) {
-            if (x.live)
-#if SMART_NT_STORE
-                __builtin_nontemporal_store(val, row);
-#else
-                *row = val;
-#endif
-            row += a.ld;
-        }
-        if (want_obj && r == 0)
-            shift = val;
-        if (want_obj && !is_nan_bits(e)) { // montecarlo.py:195-196
-            const double d = val - e;
-            const double u = val - shift;
-            A += d;
-            B += d * d;
-            C1 += u;
-            C2 += u * u;
-            C3 += w * u;
-        }
-    }
-
     // The streamed step loop (FastModel::stream_stretch) reports inside its asm (smart_fast_arms.h: SMART_P_REPORT) -- what
     // emit() does, operation for operation, with three differences of form: the report's place in the discharge matrix is
     // this per-lane pointer, moved on by ld per report (begin_rows / next_row keep it in step when emit() reports); a
@@ -840,18 +811,71 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
         // ill-conditioned rows of config 2 2.97 -> 2.18 ms, the stiff ones 1.62 -> see profiles/r05_config2.md).
         double num1 = 0.0, den1 = 0.0, total1 = 0.0;
         long r1 = 0;
-        if constexpr (kAhead)
-            rep.begin_rows(a, x, 0);
+        if constexpr (kAhead) {
+            // The row form's wavefront is alone on its SIMD: every instruction of the report is four to five cycles of
+            // the step.  The PMC counters of config 2 (profiles/r05_config2.md) had 54 scalar instructions per wave-step
+            // beside 152 vector ones; the report's share of them was the observation's index clamp and address (14), the
+            // spilled kernel arguments read back for the matrix's row stride (8 v_readlane), the NaN test of a vector-loaded
+            // observation (7), "is this report 0?" (5) and the EXEC mask of the store (4 + a branch).  Here: the
+            // observation and its deviation through the constant address space (scalar loads, requested BEFORE the step
+            // they belong to), two pointers that move on by 8 bytes, a missing observation told from the mark in its
+            // deviation (one scalar compare, smart_obs_prepare), report 0 peeled off, and every lane of a row storing the
+            // row's value (same address, same bits; the lanes beyond the batch carry the last sample's).
+            const bool obj = rep.want_obj, store = a.discharge != nullptr;
+            // (without observations the two loads still happen -- of the catchment's area, a double that is always there --
+            // and nobody looks at them: a load costs the wavefront less than the branch around it)
+            const_f64 pe = as_constant(obj ? rep.obs : a.area + x.c), pw = as_constant(obj ? rep.ws + kWsHead : a.area + x.c);
+            const long inc = obj ? 1 : 0;
+            const double zero = summary ? 0.0 : -0.0;
+            double *row = store ? a.discharge + x.c * a.R * a.ld + x.n : nullptr;
+            long stride; // the matrix's row stride in a VECTOR register pair: as a kernel argument it lives in a spilled scalar
+                         // tuple, which hipcc reads back with eight v_readlane per step to get at these two
+            asm volatile("v_mov_b64 %0, %1" : "=v"(stride) : "s"(a.ld));
+            auto step_and_report = [&](const double2 v, auto first) {
+                const double e = *pe, w = *pw;
+                pe += inc;
+                pw += inc;
+                double sink = 0.0;
+                m.step(v.x, v.y, 0.0, sink, num1, den1);
+                // summary: the mean over one step is (0.0 + q) / 1; raw: q itself.  One addition for both: x + (-0.0) is x
+                // for every x, the zeros and a NaN included
+                const double val = m.q_out + zero;
+                if (store) {
+#if SMART_NT_STORE
+                    __builtin_nontemporal_store(val, row);
+#else
+                    *row = val;
+#endif
+                    row += stride;
+                }
+                if (obj) {
+                    if constexpr (decltype(first)::value)
+                        rep.shift = val;
+                    if (!is_missing_mark(w)) { // montecarlo.py:195-196
+                        const double d = val - e;
+                        const double u = val - rep.shift;
+                        rep.A += d;
+                        rep.B += d * d;
+                        rep.C1 += u;
+                        rep.C2 += u * u;
+                        rep.C3 += w * u;
+                    }
+                }
+            };
+            if (a.T > 0) {
+                time_loop(m, f, 1, [&](const double2 v, const double) { step_and_report(v, std::true_type()); });
+                time_loop(m, f + 1, a.T - 1, [&](const double2 v, const double) { step_and_report(v, std::false_type()); });
+            }
+            write_results(a, x, m, rep, num1 / den1, nullptr);
+            return;
+        }
         if constexpr (Model::kBalanceSums)
             m.begin_run();
         time_loop(m, f, a.T, [&](const double2 v, const double ex) {
             double acc1 = 0.0;
             m.step(v.x, v.y, ex, acc1, num1, den1);
             const double val = summary ? acc1 : m.q_out;
-            if constexpr (kAhead)
-                rep.emit_ahead_row(a, x, r1, val);
-            else
-                rep.emit(a, x, r1, val);
+            rep.emit(a, x, r1, val);
             ++r1;
             if constexpr (Model::kBalanceSums)
                 total1 += acc1;
