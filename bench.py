@@ -365,7 +365,8 @@ def rank_evidence(device, launch_ms):
                     ranks=[mine])
     everyone = [None] * dist.get_world_size()
     dist.all_gather_object(everyone, mine)
-    return dict(lib, backend=sdist.data_backend(), group_backend=str(dist.get_backend()), world_size=dist.get_world_size(),
+    return dict(lib, backend=sdist.data_backend(), rccl_failure=sdist.rccl_failure, group_backend=str(dist.get_backend()),
+                world_size=dist.get_world_size(),
                 devices=[r['device'] for r in everyone], launch_ms_per_rank=[r['launch_ms'] for r in everyone],
                 ranks=everyone)
 

@@ -106,7 +106,51 @@ def init(backend=None):
                 import warnings
                 warnings.warn("smartpy_amd.distributed: %d ranks on %d physical device(s): device tensors are staged "
                               "through the host over gloo, not handed to RCCL" % (world, len(set(where))))
+            if not _STAGED:
+                _STAGED = not rccl_answers(device)
     return rank, world, device
+
+
+#: why rccl_answers() gave up on RCCL in this process (the text of the exception, or what came back wrong); None otherwise
+rccl_failure = None
+
+
+def _first_device_collective(device):
+    """One all-reduce of a double on the device: what makes RCCL build its communicator (and open its IPC handles)."""
+    t = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    torch.cuda.current_stream(device).synchronize()
+    return float(t.item())
+
+
+def rccl_answers(device, probe=None):
+    """Run the group's first device collective NOW, and let the ranks agree (over gloo) on whether it worked.
+
+    What travels between the ranks of this package is small (72 bytes per sample, once per ensemble; the compute never
+    waits for a peer), so a node whose RCCL cannot start -- a driver without the IPC mode it wants, a masked xGMI link
+    -- does not have to lose the run: if the collective RAISES on any rank, every rank stages its result blocks through
+    the host over gloo instead, rank 0 says so in a warning, `rccl_failure` keeps the reason and bench.py's line reports
+    backend 'gloo' with it.  A collective that hangs is not caught here (RCCL's own watchdog ends the job);
+    SMART_DIST_BACKEND=nccl asks for RCCL alone and never comes this way."""
+    global rccl_failure
+    world = dist.get_world_size()
+    try:
+        got = (probe or _first_device_collective)(device)
+        if got != float(world):
+            rccl_failure = 'the first all-reduce over %d ranks returned %r' % (world, got)
+    except Exception as e:      # noqa: BLE001 -- whatever the backend raises: the decision below is the handling
+        rccl_failure = '%s: %s' % (type(e).__name__, str(e).strip().splitlines()[0] if str(e).strip() else '')
+    bad = torch.tensor([0.0 if rccl_failure is None else 1.0])
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX)                    # a host tensor: gloo
+    if bad.item() > 0.0:
+        if rccl_failure is None:
+            rccl_failure = 'RCCL failed on another rank'
+        if dist.get_rank() == 0:
+            import warnings
+            warnings.warn("smartpy_amd.distributed: RCCL did not start (%s): result blocks are staged through the host "
+                          "over gloo" % rccl_failure)
+        return False
+    return True
 
 
 def is_distributed():

@@ -387,6 +387,37 @@ def test_gather_and_collect_rows_eight_ranks(tmp_path):
     assert [open(tmp_path / ('gather8_%d.txt' % r)).read() for r in range(8)] == ['ok'] * 8
 
 
+def _worker_probe(rank, world, port, out_dir, failing_rank):
+    _init(rank, world, port)
+    import warnings
+    from smartpy_amd import distributed as sdist
+
+    def probe(device):          # stands for the group's first device collective
+        if rank == failing_rank:
+            raise RuntimeError("NCCL error: unhandled cuda error\nhipIpcGetMemHandle: invalid argument")
+        return float(world)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        works = sdist.rccl_answers(torch.device('cpu'), probe=probe)
+    ok = works == (failing_rank is None)
+    if failing_rank is None:
+        ok = ok and sdist.rccl_failure is None and not w
+    else:
+        ok = ok and sdist.rccl_failure == ('RuntimeError: NCCL error: unhandled cuda error' if rank == failing_rank
+                                           else 'RCCL failed on another rank')
+        ok = ok and (len(w) == 1) == (rank == 0)
+    open(os.path.join(out_dir, 'probe_%d.txt' % rank), 'w').write('ok' if ok else 'FAILED %r %r' % (works, sdist.rccl_failure))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('failing_rank', [None, 0, 2])
+def test_ranks_agree_on_staging_when_rccl_does_not_start_on_one_of_them(tmp_path, failing_rank):
+    """distributed.init()'s first device collective, replaced by a stand-in that raises on one rank the way a refused
+    IPC handle does: every rank gives the same answer (stage through the host), rank 0 alone warns, each keeps a reason."""
+    mp.spawn(_worker_probe, args=(4, _free_port(), str(tmp_path), failing_rank), nprocs=4, join=True)
+    assert [open(tmp_path / ('probe_%d.txt' % r)).read() for r in range(4)] == ['ok'] * 4
+
+
 @pytest.mark.parametrize('n', [13, 5])
 def test_lhs_run_over_eight_ranks_with_saved_series(tmp_path, n):
     """MonteCarlo.run(save_sim=True) over eight ranks (n = 5: three of them without a row): the database rank 0 writes
