@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SMART_AMD_ABI_VERSION 6
+#define SMART_AMD_ABI_VERSION 7
 
 /* report_type, as structure.py:65-70 maps report='summary' / 'raw' */
 #define SMART_REPORT_SUMMARY 1
@@ -88,6 +88,20 @@ extern "C" {
                                            /* alike -- ordered by T, then by S*Z, as smartpy_amd/engine.py does when no   */
                                            /* discharge matrix is stored.  Wave-uniform early exits then pay off sooner.  */
 #define SMART_PLAN_VALID 0x100
+/* ABI 7: bits 12..30 of a plan from smart_plan_ensemble hold the NUMBER of blocks of 64 rows that take the literal      */
+/* arithmetic (SMART_PLAN_CLASS_ILLCOND), saturating; 0 in a plan put together by hand = not counted (the launch then    */
+/* reckons with every block of the call).  The launch picks the form of that kernel from it: see literal_form.           */
+#define SMART_PLAN_ILLCOND_BLOCKS_SHIFT 12
+#define SMART_PLAN_ILLCOND_BLOCKS_MAX 0x7ffff
+
+/* literal_form (ABI 7): how the rows of SMART_PLAN_CLASS_ILLCOND are laid over the wavefronts.  The same arithmetic,   */
+/* the same bits either way (structure.py:267-503 in the reference's operation order).                                  */
+#define SMART_LITERAL_FORM_AUTO 0  /* from the load: rows while the wavefronts of the call -- 16 per class-3 block, one    */
+                                   /* per other block -- fit into two rounds over the chip's SIMDs, lanes beyond         */
+#define SMART_LITERAL_FORM_ROWS 1  /* one sample per DPP row of 16 lanes, four per wavefront: a third of the             */
+                                   /* instructions per step -- the latency form (few rows: config 2, the smartcpp hook)  */
+#define SMART_LITERAL_FORM_LANES 2 /* one sample per lane, 64 per wavefront -- the throughput form (large daily          */
+                                   /* ensembles: a seventh of the SIMD cycles per sample-step)                           */
 
 /* status bits of a finished launch (smart_launch_status) */
 #define SMART_STATUS_SLICE_TIMEOUT 0x1 /* a time slice gave up waiting for its predecessor: the block's outputs are */
@@ -153,6 +167,9 @@ typedef struct SmartEnsemble {
                            /* of 64 samples than SIMDs); 1: never slice; n > 1: n slices                   */
     int32_t plan;          /* SMART_PLAN_* bits from smart_plan_ensemble for these params / forcing /      */
                            /* sizes, or 0: launch every kernel the call could need                         */
+    /* ---- ABI 7 ---------------------------------------------------------------------------------- */
+    int32_t literal_form;  /* SMART_LITERAL_FORM_*: 0 = chosen from the number of class-3 blocks in the plan */
+    int32_t reserved0;     /* must be 0                                                                    */
 } SmartEnsemble;
 
 /* Number of report steps R for a run (structure.py:190 / :193): T // g (summary), ceil(T / g) (raw). */
@@ -184,7 +201,9 @@ int smart_plan_ensemble(const SmartEnsemble *e, int32_t *plan);
 int smart_launch_status(const SmartEnsemble *e, int32_t *status);
 
 /* Which kernels smart_run_ensemble_hip would launch for *e on the current device, as text for logs and benchmark
- * lines: e.g. "smart_fast_intervals[16 slices x 1563 blocks, 2 resident per SIMD]".  Launches nothing. */
+ * lines: e.g. "smart_fast_intervals[16 slices x 1563 blocks, 2 resident per SIMD]"; the literal rows of a fast call
+ * with the form chosen for them: "smart_fast_illcond_lanes[1813 of 15625 blocks, one sample per lane]" (ABI 7).
+ * Launches nothing. */
 int smart_describe_launch(const SmartEnsemble *e, char *text, int64_t len);
 
 /*

@@ -13,11 +13,13 @@ LIB_PATH = os.environ.get('SMART_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libsm
 
 REPORT_SUMMARY, REPORT_RAW = 1, 2
 MATH_LITERAL, MATH_FAST = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 PLAN_VALID = 0x100
 PLAN_CLASS_BITS = {0: 0x01, 1: 0x02, 2: 0x04, 3: 0x08}     # regular, stiff, guard, ill-conditioned
 PLAN_FORCING_PIECEWISE, PLAN_FORCING_VARYING, PLAN_FORCING_RUNS = 0x10, 0x20, 0x80
 PLAN_ROWS_ORDERED = 0x40
+PLAN_ILLCOND_BLOCKS_SHIFT, PLAN_ILLCOND_BLOCKS_MAX = 12, 0x7ffff    # ABI 7: class-3 blocks counted by the plan
+LITERAL_FORM_AUTO, LITERAL_FORM_ROWS, LITERAL_FORM_LANES = 0, 1, 2
 STATUS_SLICE_TIMEOUT, STATUS_STALE_PLAN, STATUS_NONFINITE_FORCING = 0x1, 0x2, 0x4
 
 _dp = ctypes.c_void_p   # device or host address, passed as an integer
@@ -34,6 +36,7 @@ class SmartEnsemble(ctypes.Structure):
         ('discharge', _dp), ('discharge_ld', ctypes.c_int64), ('gw', _dp), ('objfn', _dp),
         ('final_vars', _dp), ('workspace', _dp), ('workspace_bytes', ctypes.c_int64), ('stream', _dp),
         ('time_slices', ctypes.c_int32), ('plan', ctypes.c_int32),
+        ('literal_form', ctypes.c_int32), ('reserved0', ctypes.c_int32),
     ]
 
 

@@ -259,13 +259,17 @@ __global__ void smart_workspace_reset(int *hdr, long n_hdr, int *flags, long n_f
 }
 
 // smart_plan_ensemble: the arithmetic classes present among the blocks of 64 rows, and the kinds of forcing
-constexpr int kHdrPlan = 8;
+constexpr int kHdrPlan = 8, kHdrPlanIllCond = 9;
 
 __global__ __launch_bounds__(kWave) void smart_classify_rows(KArgs a)
 {
     const int cls = wave_class(a, (long)blockIdx.x, (long)blockIdx.y);
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         __hip_atomic_fetch_or(a.hdr + kHdrPlan, 1 << cls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // round 6: HOW MANY blocks take the literal arithmetic -- the launch picks that kernel's form from it
+        if (cls == 3)
+            __hip_atomic_fetch_add(a.hdr + kHdrPlanIllCond, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __global__ void smart_classify_forcing(KArgs a, int *hdr)
@@ -330,7 +334,7 @@ static const char *const kFastKernelNames[kNumFastKernels] = {
     "smart_fast_intervals_exits", "smart_fast_intervals", "smart_fast_intervals_states", "smart_fast_steps",
     "smart_fast_steps_states", "smart_fast_plain", "smart_fast_stiff", "smart_fast_guard", "smart_fast_illcond",
     "smart_fast_runs_exits", "smart_fast_runs", "smart_fast_runs_states", "smart_fast_steps_raw",
-    "smart_fast_intervals_raw", "smart_fast_steps_every"};
+    "smart_fast_intervals_raw", "smart_fast_steps_every", "smart_fast_illcond_lanes"};
 
 // dynamic LDS that lets exactly `per_cu` workgroups of kernel k be resident on a CU (0: no such size); d->mu held
 static size_t lds_for_residency(DeviceCtx *d, FastKernel k, int per_cu)
@@ -461,6 +465,8 @@ static int check(const SmartEnsemble *e)
         return fail(SMART_E_SIZE, "time_slices must be >= 0");
     if (e->plan != 0 && !(e->plan & SMART_PLAN_VALID))
         return fail(SMART_E_SIZE, "plan must be 0 or a value returned by smart_plan_ensemble");
+    if (e->literal_form < SMART_LITERAL_FORM_AUTO || e->literal_form > SMART_LITERAL_FORM_LANES)
+        return fail(SMART_E_MODE, "literal_form must be SMART_LITERAL_FORM_AUTO, _ROWS or _LANES");
     g_err[0] = 0;
     return SMART_OK;
 }
@@ -672,7 +678,47 @@ struct Decision {
     int report = -1;        // merged_report(): which merged family takes the regular rows (-1: smart_fast_plain)
     bool intervals = false; // report == kReportMean
     double load = 0.0; // blocks of 64 samples per SIMD
+    long illcond_blocks = 0;  // class-3 blocks the launch expects (the plan's count; without one every block of the call)
+    bool illcond_rows = true; // their kernel: one sample per DPP row (smart_fast_illcond) or per lane (.._lanes)
 };
+
+// ---- the form of the literal step inside the fast mode (class 3), chosen per launch (round 6) -------------------------
+// smart_fast_illcond advances FOUR samples per wavefront in ~150 instructions a step, smart_fast_illcond_lanes SIXTY-FOUR
+// in ~440: per sample-step the row form costs seven times the SIMD cycles, and wins only while its sixteen wavefronts
+// per block of 64 samples find SIMDs of their own -- a wavefront alone on its SIMD is as fast as its instruction count
+// (DESIGN.md section 4.7).  Measured (profiles/r06_daily_form.txt; daily ensembles of the default LHS ranges, 11.6 % of
+// the rows in class 3, B blocks of them): class 3 alone, rows against lanes -- B = 55: 1.78 / 3.96 ms, 91: 3.54 / 4.00,
+// 127: 3.52 / 3.98 (two rounds of row-form wavefronts over 1,024 SIMDs still beat one round of the lane form), 181:
+// 5.26 / 4.12, 362: 10.4 / 4.14, 1,810: 49.3 / 6.4.  Beside the other classes' kernels of the same call the SIMDs are
+// shared: whole ensemble, rows against lanes -- 3e4 samples (880 row-form wavefronts + 416 others) 2.27 / 3.88 ms, 5e4
+// (1,456 + 692) 3.94 / 3.96, 7e4 (2,032 + 968) 5.29 / 4.66, 1e5 6.60 / 5.74, 1e6 57.6 / 11.4.  Hence: rows while ALL
+// the wavefronts of the call -- sixteen per class-3 block, one per other block -- fit into kIllCondRowRounds rounds over
+// the chip's SIMDs.  SMART_ILLCOND_FORM=rows|lanes and SmartEnsemble.literal_form override (tests, A/B).
+constexpr int kIllCondRowRounds = 2;
+
+static long count_illcond_blocks(const SmartEnsemble *e, int plan)
+{
+    const long counted = (plan >> SMART_PLAN_ILLCOND_BLOCKS_SHIFT) & SMART_PLAN_ILLCOND_BLOCKS_MAX;
+    const long all = (long)((e->n_samples + kWave - 1) / kWave * e->n_catchments);
+    // (no count: a plan made by hand -- smart_row_class -- or none at all; a saturated count: every block may be one)
+    return counted > 0 && counted < SMART_PLAN_ILLCOND_BLOCKS_MAX ? counted : all;
+}
+
+static bool illcond_form(const SmartEnsemble *e, int n_simd, long blocks)
+{
+    if (e->literal_form == SMART_LITERAL_FORM_ROWS)
+        return true;
+    if (e->literal_form == SMART_LITERAL_FORM_LANES)
+        return false;
+    if (const char *env = getenv("SMART_ILLCOND_FORM")) {
+        if (!strcmp(env, "rows"))
+            return true;
+        if (!strcmp(env, "lanes"))
+            return false;
+    }
+    const long all = (long)((e->n_samples + kWave - 1) / kWave * e->n_catchments);
+    return blocks * kIllCondWaves + (all - blocks) <= (long)kIllCondRowRounds * n_simd;
+}
 
 static int decide(const SmartEnsemble *e, const DeviceCtx *d, const Workspace &w, Decision *out)
 {
@@ -728,8 +774,11 @@ static int decide(const SmartEnsemble *e, const DeviceCtx *d, const Workspace &w
         x.push(kStiff, false);
     if (plan & SMART_PLAN_CLASS_GUARD)
         x.push(kGuard, false);
-    if (plan & SMART_PLAN_CLASS_ILLCOND)
-        x.push(kIllCond, false);
+    if (plan & SMART_PLAN_CLASS_ILLCOND) {
+        x.illcond_blocks = count_illcond_blocks(e, plan);
+        x.illcond_rows = illcond_form(e, d->n_simd, x.illcond_blocks);
+        x.push(x.illcond_rows ? kIllCond : kIllCondLanes, false);
+    }
     if (x.overflow)
         return fail(SMART_E_SIZE, "internal: a call wants more than %d kernels", kMaxTodo);
     if (x.n_todo == 0)
@@ -856,6 +905,11 @@ static int describe(const SmartEnsemble *e, char *text, int64_t len)
         if (x.todo[i].sliced && x.n_seg > 1)
             n = snprintf(text + used, (size_t)len - used, "%s%s[%d slices x %ld blocks, %d resident per SIMD]",
                          i ? " + " : "", kFastKernelNames[x.todo[i].k], x.n_seg, blocks, x.per_simd);
+        else if (x.todo[i].k == kIllCond || x.todo[i].k == kIllCondLanes)
+            // (the class-3 blocks the form was chosen for: the plan's count, or every block where there is none)
+            n = snprintf(text + used, (size_t)len - used, "%s%s[%ld of %ld blocks, one sample per %s]", i ? " + " : "",
+                         kFastKernelNames[x.todo[i].k], x.illcond_blocks, blocks,
+                         x.illcond_rows ? "DPP row x 16 wavefronts" : "lane");
         else
             n = snprintf(text + used, (size_t)len - used, "%s%s[%ld blocks]", i ? " + " : "",
                          kFastKernelNames[x.todo[i].k], blocks);
@@ -897,10 +951,13 @@ static int make_plan(const SmartEnsemble *e, int32_t *plan)
                            a, w.hdr);
     }
     HIP_TRY(hipGetLastError());
-    int bits = 0;
-    HIP_TRY(hipMemcpyAsync(&bits, w.hdr + kHdrPlan, sizeof(int), hipMemcpyDeviceToHost, s));
+    int bits[2] = {0, 0};
+    static_assert(kHdrPlanIllCond == kHdrPlan + 1, "read back together");
+    HIP_TRY(hipMemcpyAsync(bits, w.hdr + kHdrPlan, sizeof(bits), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *plan = SMART_PLAN_VALID | (bits & (0x3f | SMART_PLAN_FORCING_RUNS));
+    const long n_ill = bits[1] < 0 ? 0 : (bits[1] > SMART_PLAN_ILLCOND_BLOCKS_MAX ? SMART_PLAN_ILLCOND_BLOCKS_MAX : bits[1]);
+    *plan = SMART_PLAN_VALID | (bits[0] & (0x3f | SMART_PLAN_FORCING_RUNS)) |
+            (int32_t)(n_ill << SMART_PLAN_ILLCOND_BLOCKS_SHIFT);
     return SMART_OK;
 }
 

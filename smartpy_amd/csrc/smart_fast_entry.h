@@ -22,8 +22,10 @@
 //                                or every-step reports with the final state vector
 //   smart_fast_stiff             class 1: some k * 3600 < dt (clamps, 95 % rule reachable)        step loop, STIFF
 //   smart_fast_guard             class 2: S outside [0, 0.5], C < 0 or Z <= 0                     step loop, GUARD
-//   smart_fast_illcond           class 3: dt / (RK * 3600) > 2 (the river only)                   literal model, divisions
-//                                                                                                 through cached reciprocals
+//   smart_fast_illcond           class 3: dt / (RK * 3600) > 2 (the river only), few blocks      literal model, one sample per
+//                                                                                                 DPP row (latency form)
+//   smart_fast_illcond_lanes     class 3, many blocks (round 6: chosen per launch from the load)  literal model, one sample per
+//                                                                                                 lane, cached reciprocals
 #pragma once
 
 #include "smart_fast_model.h"
@@ -46,6 +48,7 @@ enum FastKernel : int {
     kStepsRaw,
     kIntervalsRaw,
     kStepsEvery,
+    kIllCondLanes,
     kNumFastKernels
 };
 

@@ -21,20 +21,25 @@ SMART_FAST_KERNEL(smart_fast_stiff) { guarded_kernel<1, FastModel<true, false>>(
 
 SMART_FAST_KERNEL(smart_fast_guard) { guarded_kernel<2, FastModel<true, true>>(a, forcing, obs, ws); }
 
-#ifndef SMART_ILLCOND_ROWS
-#define SMART_ILLCOND_ROWS 1 // one sample per DPP row (smart_literal_lanes.h; 0: one per lane, round 4's form -- A/B builds)
-#endif
 // the ill-conditioned rows (dt / RK > 2) and any row with a NaN or an infinite parameter (wave_class(): class 3) on
 // the literal model -- which is why this translation unit is compiled WITHOUT -fno-honor-nans (build.py): what a NaN
-// does in the reference's compares and branches is part of what this kernel reproduces, bit for bit with the literal
+// does in the reference's compares and branches is part of what these kernels reproduce, bit for bit with the literal
 // kernel (tests/test_gpu_parity.py: ..._wild_parameters_...).
-// Round 5: launched over SIXTEEN workgroups per block of 64 samples (grid.x = 16 ceil(N / 64), kIllCondWaves), each
-// taking four of the block's samples, one per DPP row: such rows are few (a tenth of a daily ensemble: 19 blocks of
-// config 2), their wavefronts are alone on their SIMDs, and a lone wavefront's time is its instruction count
-// (profiles/r05_microbench_lanes.txt: 4.67 -> 1.52 ms for config 2's 1,160 rows, every bit the same).
+//
+// TWO forms of the same arithmetic, the same bits (tests/test_gpu_parity.py: ..._two_forms_...), chosen per launch from
+// the number of class-3 blocks the plan counted (smart_capi.hip: illcond_form(); round 6):
+//
+//   smart_fast_illcond        the LATENCY form (round 5).  One sample per DPP row, SIXTEEN workgroups per block of 64
+//                             samples (grid.x = 16 ceil(N / 64), kIllCondWaves), four samples each.  A wavefront alone
+//                             on its SIMD is as fast as its instruction count, and this form's step is a third of the
+//                             other's -- but it advances 4 samples where the other advances 64: right while sixteen
+//                             wavefronts per block still find SIMDs of their own (config 2: 19 blocks, 4.67 -> 1.52 ms).
+//   smart_fast_illcond_lanes  the THROUGHPUT form (round 4's, LiteralModelT<true>).  One sample per lane, one workgroup
+//                             per block.  ~490 instructions per step for 64 samples against ~176 for 4: from a few
+//                             hundred class-3 blocks on (a daily ensemble of 1e5 samples and more) the row form queues
+//                             for SIMDs round after round and this one does not.
 SMART_FAST_KERNEL(smart_fast_illcond)
 {
-#if SMART_ILLCOND_ROWS
     Work w;
     w.block = (long)(blockIdx.x >> 4);
     w.c = (long)blockIdx.y;
@@ -44,10 +49,9 @@ SMART_FAST_KERNEL(smart_fast_illcond)
     if (w.block * kWave + w.seg * 4 >= a.N)
         return; // (the batch ends before this wavefront's four samples)
     run_ensemble<LiteralLanesModel, false>(a, forcing, obs, ws, nullptr, w.block, w.c, w.seg);
-#else
-    guarded_kernel<3, LiteralModelT<true>>(a, forcing, obs, ws);
-#endif
 }
+
+SMART_FAST_KERNEL(smart_fast_illcond_lanes) { guarded_kernel<3, LiteralModelT<true>>(a, forcing, obs, ws); }
 
 const void *fast_kernel_guarded(FastKernel k)
 {
@@ -58,6 +62,8 @@ const void *fast_kernel_guarded(FastKernel k)
         return reinterpret_cast<const void *>(&smart_fast_guard);
     case kIllCond:
         return reinterpret_cast<const void *>(&smart_fast_illcond);
+    case kIllCondLanes:
+        return reinterpret_cast<const void *>(&smart_fast_illcond_lanes);
     default:
         return nullptr;
     }

@@ -23,6 +23,7 @@ VARIABLES = ['Q_aeva', 'Q_ove', 'Q_dra', 'Q_int', 'Q_sgw', 'Q_dgw', 'Q_out',
 
 _REPORT = {'summary': REPORT_SUMMARY, 'raw': REPORT_RAW}
 _MATH = {'literal': MATH_LITERAL, 'fast': MATH_FAST}
+_LITERAL_FORMS = {'auto': _lib.LITERAL_FORM_AUTO, 'rows': _lib.LITERAL_FORM_ROWS, 'lanes': _lib.LITERAL_FORM_LANES}
 
 
 def report_code(report):
@@ -317,7 +318,8 @@ class PreparedEnsemble(object):
 
 def prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report='summary', extra=None,
                      initial=None, obs=None, gw_obs=None, math_mode='fast', want_discharge=True, want_objfn=None,
-                     want_final=False, device=None, discharge_out=None, group_variants=True, time_slices=0):
+                     want_final=False, device=None, discharge_out=None, group_variants=True, time_slices=0,
+                     literal_form='auto'):
     """Everything of run_ensemble() short of the launch: see PreparedEnsemble.  Arguments as run_ensemble()."""
     L = _lib.lib()
     device = torch.device(device) if device is not None else (
@@ -424,6 +426,10 @@ def prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, re
     e.discharge, e.discharge_ld, e.gw, e.objfn = ptr(dis), ld, ptr(p._gw), ptr(p._objfn)
     e.final_vars = ptr(p._fin)
     e.time_slices = int(time_slices)
+    try:
+        e.literal_form = _LITERAL_FORMS[literal_form]
+    except KeyError:
+        raise Exception("literal_form '{}' unknown ('auto', 'rows' or 'lanes').".format(literal_form))
     # the caller of the C ABI owns every buffer, the library's scratch included: header, observation statistics,
     # slice hand-over
     with torch.cuda.device(device):
@@ -447,7 +453,8 @@ def prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, re
 
 def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report='summary', extra=None,
                  initial=None, obs=None, gw_obs=None, math_mode='fast', want_discharge=True, want_objfn=None,
-                 want_final=False, device=None, discharge_out=None, group_variants=True, time_slices=0, verify=True):
+                 want_final=False, device=None, discharge_out=None, group_variants=True, time_slices=0, verify=True,
+                 literal_form='auto'):
     """One launch of the whole ensemble: the batched form of the spotpy loop over MonteCarlo.simulation /
     objectivefunction (montecarlo.py:153-154,179-209).
 
@@ -458,11 +465,17 @@ def run_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report
     verify: read the launch's status word afterwards (synchronises with the stream) and repeat the launch if a time
     slice timed out; skipped while the stream is being captured into a HIP graph.  Callers that pipeline launches
     use prepare_ensemble() / launch() and call verify() when they synchronise anyway.
+
+    literal_form: how the rows that need the reference's own operation order (class 3: dt / RK > 2 -- a tenth of a daily
+    ensemble -- or a parameter that is none) are laid over the wavefronts: 'rows' (one sample per DPP row, the latency
+    form), 'lanes' (one per lane, the throughput form) or 'auto' (from the number of such blocks the plan counted).
+    The same bits either way.
     """
     p = prepare_ensemble(params, forcing, area_m2, delta_sec, n_warm, report_gap, report=report, extra=extra,
                          initial=initial, obs=obs, gw_obs=gw_obs, math_mode=math_mode,
                          want_discharge=want_discharge, want_objfn=want_objfn, want_final=want_final, device=device,
-                         discharge_out=discharge_out, group_variants=group_variants, time_slices=time_slices)
+                         discharge_out=discharge_out, group_variants=group_variants, time_slices=time_slices,
+                         literal_form=literal_form)
     p.enqueue()
     if verify and p._ws is not None and p._e.math_mode == MATH_FAST and not torch.cuda.is_current_stream_capturing():
         out = p.verify()        # (builds the result once: after the status word has been read)

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
     assert sorted(_lib.SYMBOLS) == names            # the ctypes table mirrors the header exactly
     for n in names:
         assert getattr(L, n) is not None
-    assert L.smart_abi_version() == _lib.ABI_VERSION == 6
+    assert L.smart_abi_version() == _lib.ABI_VERSION == 7
     assert b"gfx950" in L.smart_build_info() and b"clang" in L.smart_build_info()
 
 

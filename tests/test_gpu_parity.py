@@ -1618,6 +1618,73 @@ def test_the_row_form_of_the_literal_step_under_every_kind_of_report(eng, exampl
         assert bits_equal(both.gw[c].cpu().numpy(), one.gw.cpu().numpy())
 
 
+def test_the_two_forms_of_the_literal_rows_give_the_same_bits(eng, example, monkeypatch):
+    """Round 6: the class-3 rows of a fast launch run on smart_fast_illcond (one sample per DPP row, sixteen wavefronts
+    per block of 64 samples: the latency form) or on smart_fast_illcond_lanes (one sample per lane: the throughput
+    form), chosen per launch from the number of class-3 blocks the plan counted.  The same arithmetic either way: on
+    one daily batch -- config 2's kind of rows, plus rows whose parameters are none, with and without the educated
+    guess -- discharge, groundwater ratio, objective functions and final state are the same bits, and the oracle's."""
+    import torch
+    rain, peva, _ = _synthetic_forcing(0, hourly=False)
+    f = forcing_of(rain, peva)
+    params = lhs_oracle.lhs_params(3000, seed=606)
+    params[5::40, 9] = 0.05                      # dt / RK = 20: the river's two forms alternate
+    params[7::50, 3] = 1.7                       # a share that is none
+    params[11::60, 4] = 0.9                      # guarded leaks inside the literal class
+    cls = eng.variant_classes(torch.from_numpy(params), 86400.0).numpy()
+    rows3 = np.nonzero(cls == 3)[0]
+    assert 300 < len(rows3) < 900
+    obs = np.abs(np.random.default_rng(6).normal(3, 1, 3653))
+    obs[::17] = np.nan
+    outs = {}
+    for form in ('rows', 'lanes'):
+        for extra, warm in ((example['extra'], 365), (None, 0)):
+            o = eng.run_ensemble(params, f, example['area'], 86400.0, warm, 1, extra=extra, want_final=True, obs=obs,
+                                 gw_obs=0.12667, literal_form=form)
+            text = o._prepared.describe()
+            n3 = -(-len(rows3) // 64)
+            want = ('smart_fast_illcond[%d of' % n3) if form == 'rows' else ('smart_fast_illcond_lanes[%d of' % n3)
+            assert want in text, text
+            outs[form, warm] = [t.cpu().numpy() for t in (o.discharge, o.gw, o.objfn, o.final_vars)]
+    for warm in (365, 0):
+        (d_r, g_r, o_r, f_r), (d_l, g_l, o_l, f_l) = outs['rows', warm], outs['lanes', warm]
+        # every row of the batch (the other classes' kernels are the same ones): the model's outputs are the same bits;
+        # the fused one-pass moments are the report's own arithmetic (the row form's every-step loop takes the observation
+        # with a vector load and contracts differently): rounding apart, held to 1e-9 where the oracle's gate is 1e-8
+        assert bits_equal(d_r, d_l) and bits_equal(g_r, g_l) and bits_equal(f_r, f_l)
+        worst = rel(o_r[:, :7], o_l[:, :7], floor=1e-12)
+        print('objective functions, rows against lanes (warm-up %d): %.2e relative' % (warm, worst))
+        assert worst <= 1e-9 and np.array_equal(o_r[:, 7], o_l[:, 7])
+    d0, g0, f0 = so.run_batch(example['area'], 86400.0, 3653, 365, rain, peva, params[rows3], example['extra'],
+                              so.REPORT_SUMMARY, 1, pow_mode=so.POW_MUL, sum_mode=so.SUM_SEQ, want_final=True)
+    for form in ('rows', 'lanes'):
+        dis, gw, _, fin = outs[form, 365]
+        assert bits_equal(dis[rows3], d0) and bits_equal(gw[rows3], g0) and bits_equal(fin[rows3], f0)
+    # the form follows the load: few class-3 blocks -> rows; the environment overrides (A/B runs), the argument wins
+    auto = eng.prepare_ensemble(params, f, example['area'], 86400.0, 365, 1, extra=example['extra'])
+    assert 'smart_fast_illcond[' in auto.describe() and 'one sample per DPP row' in auto.describe()
+    monkeypatch.setenv('SMART_ILLCOND_FORM', 'lanes')
+    assert 'smart_fast_illcond_lanes[' in auto.describe()
+    forced = eng.prepare_ensemble(params, f, example['area'], 86400.0, 365, 1, extra=example['extra'], literal_form='rows')
+    assert 'smart_fast_illcond[' in forced.describe()
+    monkeypatch.delenv('SMART_ILLCOND_FORM')
+    # ... many -> lanes: 30,000 daily rows of the default ranges hold ~3,500 of class 3 = 55 blocks -> still rows
+    # (16 x 55 + 416 wavefronts <= 2 rounds over 1,024 SIMDs); 120,000 hold ~218 blocks -> lanes
+    for n, kernel in ((30000, 'smart_fast_illcond['), (120000, 'smart_fast_illcond_lanes[')):
+        big = lhs_oracle.lhs_params(n, seed=n)
+        prep = eng.prepare_ensemble(big, f, example['area'], 86400.0, 365, 1, extra=example['extra'],
+                                    want_discharge=False, obs=obs)
+        assert kernel in prep.describe(), prep.describe()
+        res = prep.launch()
+        prep.verify()
+        pick = np.nonzero(big[:, 9] * 3600.0 < 43200.0)[0][:: max(1, n // 2000)][:48]
+        d1, g1, _ = so.run_batch(example['area'], 86400.0, 3653, 365, rain, peva, big[pick], example['extra'],
+                                 so.REPORT_SUMMARY, 1, pow_mode=so.POW_MUL, sum_mode=so.SUM_SEQ)
+        assert bits_equal(res.gw.cpu().numpy()[pick], g1)
+        want = objfn_oracle.objective_matrix(d1, obs)
+        assert rel(res.objfn.cpu().numpy()[pick, :7], want[:, :7]) < 1e-8
+
+
 def test_ill_conditioned_rows_with_wild_parameters_match_the_literal_kernel(eng, example):
     """The ill-conditioned rows of the fast mode run the reference's operation order with a few identities applied where
     wave-uniform checks allow them (divisions through reciprocals, clamps and the two cascades' hand-downs as
