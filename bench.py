@@ -205,12 +205,125 @@ def isa_model_summary(pmc_key, path=None, source_hash=None):
     return model, model.get('source', 'profiles/isa_model_latest.json')
 
 
-def cpu_baseline_and_parity(forcing, n_warm, gap, dt, device, budget_s=12.0):
+TRUTH_FIXTURE = os.path.join(ROOT, 'tests', 'golden', 'bench_truth.npz')
+TIMED_ROWS = 48                  # rows of its own timed launch every rank pushes through the oracle afterwards
+OBJFN_GATE = 1e-8                # objective functions (one-pass moments against numpy's two-pass): |diff| / max(|want|, 1)
+
+
+def load_oracle():
+    """The checker (oracle/smart_oracle.c through its ctypes binding), or (None, why not): a box without a C compiler and
+    without a built oracle library still gets its throughput line -- with `cpu_baseline` and `parity` null and the
+    reason beside them (round 5 died here)."""
+    if os.environ.get('SMART_BENCH_NO_ORACLE'):      # (tests: what a box without gcc sees)
+        return None, 'disabled by SMART_BENCH_NO_ORACLE'
+    try:
+        from oracle import smart_oracle as so
+        so.max_threads()
+        return so, None
+    except Exception as e:      # noqa: BLE001 -- no gcc, no write access, a library that does not load: all the same here
+        return None, '%s: %s' % (type(e).__name__, (str(e).strip().splitlines() or [''])[0][:200])
+
+
+def truth_discharge(so, forcing, dt, T, W, gap, hourly, from_fixture=False):
+    """Discharge of the "truth" parameter set, the base of the synthetic observations: from the oracle, or -- without one,
+    or when --obs-from-fixture says so -- from the committed fixture the oracle produced in the build container
+    (tests/golden/make_bench_truth.py; 58 KB).  Returns (series [R], where it came from)."""
+    if so is not None and not from_fixture:
+        return so.run_batch(AREA, dt, T, W, np.ascontiguousarray(forcing[:, 0]), np.ascontiguousarray(forcing[:, 1]),
+                            np.array([TRUTH]), EXTRA, so.REPORT_SUMMARY, gap, want_discharge=True)[0][0], 'oracle'
+    with np.load(TRUTH_FIXTURE) as z:
+        return z['hourly' if hourly else 'daily'].copy(), 'fixture tests/golden/bench_truth.npz'
+
+
+def synthetic_observations(truth, rng, R):
+    obs = truth * np.exp(rng.normal(0.0, 0.2, R))
+    obs[rng.random(R) < 0.12] = np.nan
+    return obs
+
+
+def rows_against_the_oracle(so, res, rows, params, forcing, area, obs, n_warm, gap, dt, catchment=None):
+    """`rows` of a finished launch (`res`: its EnsembleResult, rows in the caller's order) against the oracle on the same
+    inputs: the stored daily means where the launch stored them, the objective functions and the groundwater ratio
+    always.  -> dict of the largest differences."""
+    from oracle import objfn_oracle
+    T = forcing.shape[0]
+    want, want_gw, _ = so.run_batch(area, dt, T, n_warm, np.ascontiguousarray(forcing[:, 0]),
+                                    np.ascontiguousarray(forcing[:, 1]), np.ascontiguousarray(params[rows]), EXTRA,
+                                    so.REPORT_SUMMARY, gap, want_discharge=True, n_threads=so.max_threads())
+    pick = torch.as_tensor(rows, device=res.gw.device)
+    take = (lambda t: t[pick]) if catchment is None else (lambda t: t[catchment][pick])
+    out = {'max_rel_discharge': None, 'values': 0}
+    if res.discharge is not None:
+        got = take(res.discharge).cpu().numpy()
+        out['max_rel_discharge'] = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-300)))
+        out['values'] = int(got.size)
+    out['max_abs_gw_ratio'] = float(np.max(np.abs(take(res.gw).cpu().numpy() - want_gw)))
+    if res.objfn is not None and obs is not None:
+        fn = objfn_oracle.objective_matrix(want, obs, want_gw, GW_OBS)
+        got = take(res.objfn).cpu().numpy()
+        out['max_rel_objfn'] = float(np.max(np.abs(got[:, :7] - fn[:, :7]) / np.maximum(np.abs(fn[:, :7]), 1.0)))
+        out['gw_flag_equal'] = bool(np.array_equal(got[:, 7], fn[:, 7]))
+    return out
+
+
+def timed_launch_parity(so, why_not, job, kind, params_local, forcing_of, area_of, obs, n_warm, gap, dt):
+    """EVERY rank checks the launch it timed: TIMED_ROWS rows (fixed seed per rank) of its OWN job -- the stored [R, N]
+    rows where the matrix is stored, objective functions and groundwater ratio always -- against the oracle on its host;
+    the largest difference over the ranks goes into the line (round 5 checked a separate, unsliced 4,096-row batch on
+    rank 0 only: the launch the number came from was only looked at for NaNs).  kind: 'samples' (params_local = this
+    rank's rows) or 'catchments' (params_local = the shared rows; this rank's catchments are job's)."""
+    rank, world = sdist.rank_world()
+    have = sdist.sum_over_ranks(1.0 if so is not None else 0.0)
+    if have < world:
+        return {'timed_launch': None, 'why': 'no oracle on %d of %d rank(s): %s' % (world - int(have), world, why_not)}
+    worst = {'max_rel_discharge': -1.0, 'max_abs_gw_ratio': 0.0, 'max_rel_objfn': 0.0}
+    n_rows, flags_ok, values = 0, True, 0
+    if job.n_local > 0:
+        res = job.prepared.result()
+        rng = np.random.default_rng(6006 + rank)
+        if kind == 'samples':
+            rows = np.sort(rng.choice(job.n_local, size=min(TIMED_ROWS, job.n_local), replace=False))
+            got = [rows_against_the_oracle(so, res, rows, params_local, forcing_of(0), area_of(0), obs, n_warm, gap, dt)]
+            n_rows = len(rows)
+        else:
+            lo, _ = sdist.shard_bounds(job.n_total, world, rank)
+            per_c = max(1, TIMED_ROWS // min(job.n_local, 4))
+            got = []
+            for c in sorted(rng.choice(job.n_local, size=min(job.n_local, 4), replace=False).tolist()):
+                rows = np.sort(rng.choice(params_local.shape[0], size=per_c, replace=False))
+                got.append(rows_against_the_oracle(so, res, rows, params_local, forcing_of(lo + c), area_of(lo + c), obs,
+                                                   n_warm, gap, dt, catchment=c))
+                n_rows += len(rows)
+        for g in got:
+            for k in worst:
+                if g.get(k) is not None:
+                    worst[k] = max(worst[k], g[k])
+            flags_ok = flags_ok and g.get('gw_flag_equal', True)
+            values += g['values']
+    out = {k: sdist.max_over_ranks(v) for k, v in worst.items()}
+    if out['max_rel_discharge'] < 0.0:
+        out['max_rel_discharge'] = None         # (no matrix stored on any rank: objective functions and ratio only)
+    out['gw_flag_equal'] = sdist.sum_over_ranks(0.0 if flags_ok else 1.0) == 0.0
+    out['rows_per_rank'] = TIMED_ROWS
+    out['rows'] = int(sdist.sum_over_ranks(n_rows))
+    out['ranks'] = int(sdist.sum_over_ranks(1.0 if n_rows else 0.0))
+    out['values'] = int(sdist.sum_over_ranks(values))
+    out['kernel'] = job.prepared.describe()
+    out['gate'] = {'discharge': PARITY_GATE, 'gw_ratio': PARITY_GATE, 'objfn': OBJFN_GATE, 'contract': PARITY_CONTRACT}
+    out['ok'] = bool((out['max_rel_discharge'] is None or out['max_rel_discharge'] <= PARITY_GATE)
+                     and out['max_abs_gw_ratio'] <= PARITY_GATE and out['max_rel_objfn'] <= OBJFN_GATE
+                     and out['gw_flag_equal'] and out['ranks'] >= 1)
+    out['against'] = 'oracle/smart_oracle.c on every rank\'s host (reference operation order, libm pow, numpy summation ' \
+                     'order) + oracle/objfn_oracle.py, on rows of the timed job itself'
+    return {'timed_launch': out}
+
+
+
+def cpu_baseline_and_parity(so, forcing, n_warm, gap, dt, device, budget_s=12.0):
     """(1) The oracle's OpenMP batch runner (a C port of the reference loop) on the host cores, on a bounded sample of
     the same workload: reported next to the GPU number, never part of the timed GPU region.  (2) The same rows through
     the engine: the largest relative difference of the discharge and of the groundwater ratio -- parity measured in
     the run that reports the throughput."""
-    from oracle import smart_oracle as so
     cores = so.max_threads()
     rain, pe = np.ascontiguousarray(forcing[:, 0]), np.ascontiguousarray(forcing[:, 1])
     T = len(rain)
@@ -327,6 +440,38 @@ def api_legs(forcing, obs, W_days, device):
     return legs
 
 
+def daily_leg(so, n, device, steps, from_fixture=False):
+    """A DAILY ensemble of n LHS samples beside the headline (round 5's verdict: daily data is the reference's normal use
+    -- examples/in/ExampleDaily -- and no number existed above 1e4 samples): ten years of daily steps, a report every
+    step, objective functions fused, no matrix stored.  With daily steps the default ranges put 11.6 % of the rows into
+    the literal arithmetic (dt / RK > 2) and 20 % into the stiff variant; the launch picks the literal kernel's form from
+    the load (smart_describe_launch says which).  48 rows of the timed launch, every class among them, against the
+    oracle."""
+    forcing, rng = synthetic_forcing(0, hourly=False)
+    T, W, dt, gap = forcing.shape[0], WARM_DAYS, 86400.0, 1
+    truth, _ = truth_discharge(so, forcing, dt, T, W, gap, False, from_fixture)
+    obs = synthetic_observations(truth, rng, T)
+    params = latin_hypercube(n, Parameters().ranges, seed=2718)
+    prep = engine.prepare_ensemble(torch.from_numpy(params).to(device), forcing, AREA, dt, W, gap, obs=obs, gw_obs=GW_OBS,
+                                   extra=EXTRA, want_discharge=False, device=device)
+    _, ms, _ = timed_steps(prep.launch, steps, 1, device)
+    res = prep.verify()
+    cls = engine.variant_classes(torch.from_numpy(params), dt).numpy()
+    leg = {'what': '%d-sample LHS ensemble x daily 10-yr synthetic forcing (T=%d + warm-up %d steps), a report every step, '
+                   'objective functions fused, discharge not stored' % (n, T, W),
+           'kernel': prep.describe(), 'launch_ms': ms, 'value': n * (T + W) / (ms * 1e-3), 'unit': 'sample-timesteps/s',
+           'steps': steps, 'rows_per_class': {'regular': int((cls == 0).sum()), 'stiff': int((cls == 1).sum()),
+                                              'guard': int((cls == 2).sum()), 'literal': int((cls == 3).sum())}}
+    if so is not None:
+        pick = np.random.default_rng(61)
+        rows = np.sort(np.concatenate([pick.choice(np.nonzero(cls == c)[0], size=min(16, int((cls == c).sum())),
+                                                   replace=False) for c in range(4) if (cls == c).any()]))
+        leg['parity'] = dict(rows_against_the_oracle(so, res, rows, params, forcing, AREA, obs, W, gap, dt), rows=len(rows))
+        leg['parity']['ok'] = bool(leg['parity']['max_abs_gw_ratio'] <= PARITY_GATE
+                                   and leg['parity']['max_rel_objfn'] <= OBJFN_GATE and leg['parity']['gw_flag_equal'])
+    return leg
+
+
 def timed_steps(step, n_steps, n_warmup, device):
     """W untimed steps, then K steps between barrier + synchronize on both sides.  Returns (wall seconds, max over
     ranks; mean HIP-event milliseconds of a step on the stream the kernels are launched on)."""
@@ -381,20 +526,53 @@ def spawn_ranks(n_gpus, argv):
     parallel='mpi' (montecarlo.py:153-154, docs/_doc_src/tutorial/montecarlo_experiment.rst:129-141)."""
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this driver
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
-    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=os.getcwd())
-    for raw in child.stdout:
-        text = raw.decode('utf8', 'replace')
-        out = sys.stdout if text.startswith('{') else sys.stderr
-        out.write(text)
-        out.flush()
-    return child.wait()
+
+    def start(extra_env):
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL across processes needs it on this driver
+        env.update(extra_env)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=os.getcwd())
+        printed = False
+        for raw in child.stdout:
+            text = raw.decode('utf8', 'replace')
+            printed = printed or text.startswith('{')
+            out = sys.stdout if text.startswith('{') else sys.stderr
+            out.write(text)
+            out.flush()
+        return child.wait(), printed
+
+    rc, printed = start({})
+    if rc != 0 and not printed and os.environ.get('SMART_DIST_BACKEND') is None:
+        # The ranks ended without a line: whatever it was (an RCCL that aborted its process, a watchdog), this launcher
+        # has made no GPU call and can start a FRESH job whose result blocks travel through the host (72 bytes per
+        # sample once per step: the path does not need RCCL to be measured) -- and the line says why it did.
+        why = 'the ranks started over RCCL exited with code %d before printing a line; restarted with ' \
+              'SMART_DIST_BACKEND=gloo' % rc
+        sys.stderr.write('bench.py: %s\n' % why)
+        rc, printed = start({'SMART_DIST_BACKEND': 'gloo', 'SMART_DIST_RCCL_FAILURE': why})
+    return rc
+
+
+def arm_deadline():
+    """Whatever hangs -- a collective, a driver call -- the run ends with a reason and a non-zero code after
+    SMART_BENCH_DEADLINE seconds (1,500) instead of sitting silent until somebody's watchdog fires."""
+    import threading
+    limit = float(os.environ.get('SMART_BENCH_DEADLINE', '1500'))
+
+    def fire():
+        sys.stderr.write('bench.py: no result after %.0f s (SMART_BENCH_DEADLINE): rank %s gives up\n'
+                         % (limit, os.environ.get('RANK', '0')))
+        sys.stderr.flush()
+        os._exit(3)
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def main():
@@ -409,10 +587,15 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip cpu_baseline and the in-run parity check')
     ap.add_argument('--no-flat', action='store_true', help='skip the flat_forcing / runs_of_6 / objectives_only legs')
     ap.add_argument('--no-strong', action='store_true', help='skip the strong_1e6 leg (config 4 beside config 3)')
+    ap.add_argument('--no-daily', action='store_true', help='skip the daily_1e6 leg (a daily ensemble beside config 3)')
+    ap.add_argument('--obs-from-fixture', action='store_true',
+                    help='observations from tests/golden/bench_truth.npz instead of a run of the oracle (automatic when '
+                         'the oracle cannot be built: a box without gcc)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:    # started bare: this process becomes the launcher
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    arm_deadline()
     rank, world, device = sdist.init()
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE is %d' % (args.gpus, world))
@@ -434,14 +617,14 @@ def main():
     # took them from a run of the engine itself: circular) -- on RANK 0 ONLY, and broadcast (29 KB): the checker is a
     # gcc-built library next to its source, and N ranks of a freshly pushed tree building and loading it side by side
     # is a race the benchmark has no business running (round 4's advisor; oracle.smart_oracle.build() is atomic as well)
-    obs = None
+    obs, so, no_oracle, obs_source = None, None, None, None
     if rank == 0:
-        from oracle import smart_oracle as so
-        truth = so.run_batch(AREA, dt, T, W, np.ascontiguousarray(forcing[:, 0]), np.ascontiguousarray(forcing[:, 1]),
-                             np.array([TRUTH]), EXTRA, so.REPORT_SUMMARY, gap, want_discharge=True)[0]
-        obs = truth[0] * np.exp(rng.normal(0.0, 0.2, R))
-        obs[rng.random(R) < 0.12] = np.nan
+        so, no_oracle = load_oracle()
+        truth, obs_source = truth_discharge(so, forcing, dt, T, W, gap, hourly, args.obs_from_fixture)
+        obs = synthetic_observations(truth, rng, R)
     obs = sdist.broadcast_matrix(obs if rank == 0 else np.empty(0), src=0)
+    if rank != 0:       # (behind the broadcast: rank 0 has built the library, the others only load it)
+        so, no_oracle = load_oracle()
 
     store = not args.no_discharge and cfg in (2, 3)     # configs 4 and 5 gather objective functions only
     kw = dict(extra=EXTRA, math_mode=args.math, want_discharge=store, device=device)
@@ -486,6 +669,13 @@ def main():
     res = res if again is None else again
     assert bool(torch.isfinite(res[..., :7]).all())
     ranks = rank_evidence(device, launch_ms)
+    # every rank, on rows of the job it has just timed (cfg 5: four of its catchments)
+    if cfg == 5:
+        timed = timed_launch_parity(so, no_oracle, job, 'catchments', params, lambda c: synthetic_forcing(c, True)[0],
+                                    lambda c: float(areas[c]), obs, W, gap, dt)
+    else:
+        timed = timed_launch_parity(so, no_oracle, job, 'samples', params[lo:hi] if cfg == 4 else params,
+                                    lambda c: forcing, lambda c: AREA, obs, W, gap, dt)
 
     # config 4's strong-scaled figure in the same line (SURVEY.md 7.3-3 asks for both series from the driver's runs):
     # 1e6 samples IN TOTAL, cut by rows over the ranks, objective functions only, one all-gather
@@ -508,6 +698,7 @@ def main():
                   'launch_ms_per_rank': rank_evidence(device, s_ms)['launch_ms_per_rank']}
         del sjob, p_all
 
+    failed = 0
     if rank == 0:
         steps_per_run = W + T
         units_per_step = n_runs_total * steps_per_run            # executed sample-timesteps, all ranks, per step
@@ -677,15 +868,34 @@ def main():
             del every
         if world == 1 and cfg == 3 and not args.no_flat and args.math == 'fast':
             line.update(api_legs(forcing, obs, WARM_DAYS, device))
-        if not args.no_cpu_baseline:
+        if world == 1 and cfg == 3 and not args.no_daily and not args.no_flat and args.math == 'fast':
+            line['daily_1e6'] = daily_leg(so, 1000000, device, max(2, args.steps // 4), args.obs_from_fixture)
+        line['observations'] = obs_source
+        if args.no_cpu_baseline:
+            line['parity'] = dict(timed)
+        elif so is None:
+            # no checker on this box (no gcc and no built oracle): the throughput line stands, the baseline does not
+            line['cpu_baseline'], line['parity'] = None, dict(timed, why='oracle unavailable: %s' % no_oracle)
+        else:
             # rank 0's host cores and rank 0's GPU, whatever the world size (the other ranks wait at the barrier below)
-            line['cpu_baseline'], line['parity'] = cpu_baseline_and_parity(forcing, W, gap, dt, device)
+            line['cpu_baseline'], line['parity'] = cpu_baseline_and_parity(so, forcing, W, gap, dt, device)
+            line['parity'].update(timed)
         print(json.dumps(line), flush=True)
-        if line.get('parity') and not line['parity']['ok']:
-            raise SystemExit('bench.py: in-run parity check failed: %r' % (line['parity'],))
+        bad = [k for k in ('ok',) if line['parity'].get(k) is False]
+        if line['parity'].get('timed_launch') and not line['parity']['timed_launch']['ok']:
+            bad.append('timed_launch')
+        if line.get('daily_1e6', {}).get('parity', {}).get('ok') is False:
+            bad.append('daily_1e6')
+        if bad:
+            sys.stdout.flush()
+            sys.stderr.write('bench.py: in-run parity check failed (%s): %r\n' % (', '.join(bad), line['parity']))
+            failed = 1
+    # the ranks leave together, with one code: a parity failure anywhere is a non-zero exit everywhere
+    failed = int(sdist.max_over_ranks(float(failed)))
     sdist.barrier()
-    if sdist.is_distributed():
-        torch.distributed.destroy_process_group()
+    sdist.finish(failed)
+    if failed:
+        raise SystemExit(failed)
 
 
 if __name__ == '__main__':

@@ -16,19 +16,23 @@ all-gather returns [C, N, 9].  ShardedEnsemble below does either.
 The helpers work on CPU tensors with the gloo backend too, which is how tests/test_dist_gloo.py covers them.
 """
 import os
+import threading
+import time
+from datetime import timedelta
 
-# RCCL between the processes of a node hands device memory from rank to rank through IPC handles, and the host driver
-# of the MI355X pool this was built on supports dmabuf IPC only: with the legacy mode left on, hipIpcGetMemHandle
-# fails ("invalid argument") and with it the first collective of any N > 1 run.  The pool's own environment exports
-# HSA_ENABLE_IPC_MODE_LEGACY=0 for that reason (the build notes say so; that, not a measurement of ours, decides it:
-# no run with more than one GPU was available to the builder).  The HSA runtime reads the variable when it starts,
-# i.e. at this process's first GPU call -- so it is set here, at import, ahead of anything that could make one, for
-# every way the ranks may have been started (torchrun, mpirun, srun, bench.py's own launcher).  A value the user set
-# stands.
-os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+import torch
+import torch.distributed as dist
 
-import torch                            # noqa: E402
-import torch.distributed as dist        # noqa: E402
+# HSA_ENABLE_IPC_MODE_LEGACY.  RCCL between the processes of a node hands device memory from rank to rank through IPC
+# handles; on a host driver that supports dmabuf IPC only, the legacy mode makes hipIpcGetMemHandle fail ("invalid
+# argument") and with it the first collective of any N > 1 run.  The MI355X pool this was built on exports
+# HSA_ENABLE_IPC_MODE_LEGACY=0 for that reason -- and a driver that knows the legacy mode only needs the opposite.  So
+# this module does NOT touch the variable on import (round 5 did; advisor: it changed every user process that imported
+# smartpy_amd.montecarlo): what the launcher exported stands; SMART_DIST_IPC_DMABUF=1 asks init() to set it to 0 (before
+# this process's first GPU call, when the HSA runtime reads it); bench.py's own launcher sets it for the ranks it starts.
+# INTEGRATION.md section 5 has the note.  RCCL with more than one rank has not run on hardware available to the builder:
+# the N > 1 RCCL path below is UNVERIFIED until a multi-GPU run exists; everything around it (sharding, agreement,
+# host staging) runs in tests/test_dist_gloo.py.
 
 
 def shard_bounds(n_rows, world_size, rank):
@@ -49,10 +53,28 @@ def env_world():
             int(os.environ.get('LOCAL_RANK', '0')))
 
 
-#: how device tensors travel in this process group: None = as the group's backend takes them (RCCL for device tensors);
-#: True = staged through the host over gloo, because two ranks of the group sit on ONE device, which RCCL refuses.
-#: Decided by init(); a group initialised elsewhere (the tests' own gloo groups) is read off its backend.
+#: how device tensors travel in this process group: None = as the group's backend takes them (a group somebody else
+#: initialised: read off its backend); False = through the RCCL subgroup init() made (_DATA_GROUP); True = staged
+#: through the host over gloo -- two ranks of the group sit on ONE device (which RCCL refuses), or RCCL did not answer.
 _STAGED = None
+#: the RCCL subgroup device tensors travel through (init() makes it beside the gloo default group); None: the default group
+_DATA_GROUP = None
+#: a communicator that raised or never answered was left behind in this process: finish() must not wait for it
+_ABANDONED = False
+#: why init() gave up on RCCL in this process (the text of the exception, or what came back wrong); None otherwise
+rccl_failure = None
+
+
+def timeouts():
+    """(seconds a host-side collective may wait for a peer, seconds the first device collective may take, seconds RCCL's
+    own watchdog allows a device collective) -- SMART_DIST_TIMEOUT (120), SMART_DIST_PROBE_TIMEOUT (half of it),
+    SMART_DIST_RCCL_TIMEOUT (1800).  A rank that never arrives makes its peers RAISE after the first; a first device
+    collective that hangs makes every rank fall back to host staging after the second; the third is what torch's watchdog
+    ends the process with when a LATER device collective hangs (long on purpose: a communicator that was given up on must
+    not take the process down while it works through the host)."""
+    host = float(os.environ.get('SMART_DIST_TIMEOUT', '120'))
+    probe = float(os.environ.get('SMART_DIST_PROBE_TIMEOUT', str(host / 2)))
+    return host, probe, float(os.environ.get('SMART_DIST_RCCL_TIMEOUT', '1800'))
 
 
 def device_identity(device):
@@ -69,88 +91,128 @@ def shares_a_device(identities):
     return len(set(identities)) < len(identities)
 
 
-def init(backend=None):
+def init(backend=None, probe=None):
     """Initialise torch.distributed from the environment (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE).
     Returns (rank, world_size, device).
 
-    With GPUs the group is created with BOTH backends (gloo for host tensors, RCCL for device tensors; RCCL's
-    communicator is only built by the first device collective), the ranks then tell each other which physical device
-    each of them sits on (host name + UUID, over gloo), and only if two of them share one -- a one-GPU box running the
-    N-rank code path -- are device tensors staged through the host instead of handed to RCCL, which refuses two ranks
-    on a device.  The decision does not look at WORLD_SIZE against device_count(): a launch with one visible device
-    per rank (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES per task, `srun --gpus-per-task=1`) or over several nodes has
-    more ranks than visible devices with every rank on a GPU of its own, and keeps RCCL.  `backend` /
-    SMART_DIST_BACKEND ('nccl' | 'gloo') overrides."""
-    global _STAGED
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # (see the top of the module; before the first GPU call)
+    The DEFAULT group is gloo, with a timeout (timeouts()): host objects, agreements on outcomes, and the data path of
+    last resort travel through it, and a rank that never arrives makes its peers raise instead of wait.  With GPUs the
+    ranks then tell each other which physical device each of them sits on (host name + UUID); if no two share one, an
+    RCCL SUBGROUP over all ranks is made for the device tensors (communicator built by its first collective), and that
+    first collective is run here, at once, with a bound (rccl_answers): if it raises or does not answer on ANY rank,
+    every rank drops the subgroup and stages its result blocks through the host over gloo -- 72 bytes per sample, once
+    per ensemble -- `rccl_failure` keeps the reason and bench.py's line reports it.  Two ranks on one device (a one-GPU
+    box running the N-rank code path) stage through the host from the start.  The decision does not look at WORLD_SIZE
+    against device_count(): a launch with one visible device per rank (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES per
+    task, `srun --gpus-per-task=1`) has more ranks than visible devices with every rank on a GPU of its own.
+    `backend` / SMART_DIST_BACKEND: 'gloo' = host staging, no RCCL; 'nccl' = RCCL for everything or nothing (one group,
+    no fallback).  `probe`: tests put a stand-in for the first device collective here."""
+    global _STAGED, _DATA_GROUP, _ABANDONED, rccl_failure
+    # (a group initialised earlier in this process, by this function or by somebody else, leaves nothing behind here)
+    _STAGED, _DATA_GROUP, _ABANDONED = None, None, False
+    rccl_failure = os.environ.get('SMART_DIST_RCCL_FAILURE') or None   # (bench.py's launcher: why it restarted on gloo)
+    if os.environ.get('SMART_DIST_IPC_DMABUF') == '1':
+        os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'         # (see the top of the module; before the first GPU call)
     rank, world, local = env_world()
     backend = backend or os.environ.get('SMART_DIST_BACKEND') or None      # e.g. gloo: two ranks sharing one GPU
     use_gpu = torch.cuda.is_available()
     if use_gpu:
         torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     device = torch.device('cuda', torch.cuda.current_device()) if use_gpu else torch.device('cpu')
-    if world > 1 and not dist.is_initialized():
+    # (SMART_DIST_SINGLE=1: a group of ONE rank -- what a one-GPU box can run of the RCCL subgroup's code, tests only)
+    if (world > 1 or os.environ.get('SMART_DIST_SINGLE') == '1') and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        if backend is not None or not use_gpu:
-            backend = backend or 'gloo'
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
-            _STAGED = backend == 'gloo'
-        else:
-            # lazy communicator creation (no device_id): the first device collective binds RCCL to the current device
-            dist.init_process_group(backend='cpu:gloo,cuda:nccl', rank=rank, world_size=world)
+        t_host, _, t_rccl = timeouts()
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world, timeout=timedelta(seconds=t_rccl))
+            _STAGED = False
+            return rank, world, device
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=timedelta(seconds=t_host))
+        _STAGED = True
+        if backend is None and use_gpu:
             where = [None] * world
-            dist.all_gather_object(where, device_identity(device))         # host objects: gloo
-            _STAGED = shares_a_device(where)
-            if _STAGED and rank == 0:
-                import warnings
-                warnings.warn("smartpy_amd.distributed: %d ranks on %d physical device(s): device tensors are staged "
-                              "through the host over gloo, not handed to RCCL" % (world, len(set(where))))
-            if not _STAGED:
-                _STAGED = not rccl_answers(device)
+            dist.all_gather_object(where, device_identity(device))
+            if shares_a_device(where):
+                if rank == 0:
+                    import warnings
+                    warnings.warn("smartpy_amd.distributed: %d ranks on %d physical device(s): device tensors are staged "
+                                  "through the host over gloo, not handed to RCCL" % (world, len(set(where))))
+            else:
+                group = dist.new_group(backend='nccl', timeout=timedelta(seconds=t_rccl))
+                if rccl_answers(device, group=group, probe=probe):
+                    _DATA_GROUP, _STAGED = group, False
     return rank, world, device
 
 
-#: why rccl_answers() gave up on RCCL in this process (the text of the exception, or what came back wrong); None otherwise
-rccl_failure = None
-
-
-def _first_device_collective(device):
-    """One all-reduce of a double on the device: what makes RCCL build its communicator (and open its IPC handles)."""
+def _first_device_collective(device, group=None):
+    """One all-reduce of a double on the device: what makes RCCL build its communicator (and open its IPC handles).
+    Asynchronous, and polled: nothing here makes the device's default stream wait for a collective that may never end."""
+    torch.cuda.set_device(device)           # (the current device is a per-thread setting)
     t = torch.ones(1, dtype=torch.float64, device=device)
-    dist.all_reduce(t)
-    torch.cuda.current_stream(device).synchronize()
+    work = dist.all_reduce(t, group=group, async_op=True)
+    while not work.is_completed():
+        time.sleep(0.002)
+    work.wait()
     return float(t.item())
 
 
-def rccl_answers(device, probe=None):
-    """Run the group's first device collective NOW, and let the ranks agree (over gloo) on whether it worked.
+def rccl_answers(device, group=None, probe=None):
+    """Run the group's first device collective NOW, in a thread of its own and with a bound (timeouts()[1]), and let the
+    ranks agree (over the gloo default group) on whether it worked.
 
     What travels between the ranks of this package is small (72 bytes per sample, once per ensemble; the compute never
     waits for a peer), so a node whose RCCL cannot start -- a driver without the IPC mode it wants, a masked xGMI link
-    -- does not have to lose the run: if the collective RAISES on any rank, every rank stages its result blocks through
-    the host over gloo instead, rank 0 says so in a warning, `rccl_failure` keeps the reason and bench.py's line reports
-    backend 'gloo' with it.  A collective that hangs is not caught here (RCCL's own watchdog ends the job);
-    SMART_DIST_BACKEND=nccl asks for RCCL alone and never comes this way."""
-    global rccl_failure
+    -- does not have to lose the run: if the collective RAISES, returns something wrong or DOES NOT ANSWER within the
+    bound on any rank, every rank stages its result blocks through the host instead, rank 0 says so in a warning and
+    `rccl_failure` keeps the reason.  The communicator that failed is left alone (its peers may sit inside its set-up
+    for good; destroying it could wait for them): finish() ends such a process without waiting for it."""
+    global rccl_failure, _ABANDONED
     world = dist.get_world_size()
-    try:
-        got = (probe or _first_device_collective)(device)
-        if got != float(world):
-            rccl_failure = 'the first all-reduce over %d ranks returned %r' % (world, got)
-    except Exception as e:      # noqa: BLE001 -- whatever the backend raises: the decision below is the handling
-        rccl_failure = '%s: %s' % (type(e).__name__, str(e).strip().splitlines()[0] if str(e).strip() else '')
-    bad = torch.tensor([0.0 if rccl_failure is None else 1.0])
-    dist.all_reduce(bad, op=dist.ReduceOp.MAX)                    # a host tensor: gloo
+    bound = timeouts()[1]
+    box = {}
+
+    def run():
+        try:
+            box['got'] = (probe or _first_device_collective)(device, group)
+        except Exception as e:      # noqa: BLE001 -- whatever the backend raises: the decision below is the handling
+            box['error'] = '%s: %s' % (type(e).__name__, str(e).strip().splitlines()[0] if str(e).strip() else '')
+
+    th = threading.Thread(target=run, name='smartpy_amd-first-collective', daemon=True)
+    t0 = time.monotonic()
+    th.start()
+    th.join(bound)
+    mine = None
+    if th.is_alive():
+        mine = 'the first device collective over %d ranks did not answer within %.0f s' % (world, bound)
+    elif 'error' in box:
+        mine = box['error']
+    elif box.get('got') != float(world):
+        mine = 'the first all-reduce over %d ranks returned %r' % (world, box.get('got'))
+    bad = torch.tensor([0.0 if mine is None else 1.0])
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX)                    # a host tensor over the gloo default group
     if bad.item() > 0.0:
-        if rccl_failure is None:
-            rccl_failure = 'RCCL failed on another rank'
+        rccl_failure = mine if mine is not None else 'RCCL failed on another rank'
+        _ABANDONED = True
         if dist.get_rank() == 0:
             import warnings
-            warnings.warn("smartpy_amd.distributed: RCCL did not start (%s): result blocks are staged through the host "
-                          "over gloo" % rccl_failure)
+            warnings.warn("smartpy_amd.distributed: RCCL did not start (%s; %.1f s): result blocks are staged through the "
+                          "host over gloo" % (rccl_failure, time.monotonic() - t0))
         return False
     return True
+
+
+def finish(code=0):
+    """The end of a program that called init(): destroy the process group -- unless a communicator that failed or hung
+    was left behind (rccl_answers), in which case tearing it down could wait for peers that never come: then the
+    standard streams are flushed and the process ends at once with `code`."""
+    import sys
+    if dist.is_available() and dist.is_initialized():
+        if _ABANDONED:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(code)
+        dist.destroy_process_group()
 
 
 def is_distributed():
@@ -158,11 +220,17 @@ def is_distributed():
 
 
 def _host_staged():
-    """Are device tensors staged through the CPU for the collectives (gloo moves host memory; test set-ups and ranks that
-    share a device only: RCCL takes device tensors as they are)?"""
+    """Are device tensors staged through the CPU for the collectives (gloo moves host memory: test set-ups, ranks that
+    share a device, an RCCL that did not answer; RCCL takes device tensors as they are)?"""
     if _STAGED is not None:
         return _STAGED
     return dist.get_backend() == 'gloo'        # a group somebody else initialised
+
+
+def _host_scalars():
+    """Do one-number agreements (outcomes, timings) travel as host tensors?  Whenever the default group can carry them
+    (init()'s gloo default group; any group with a gloo part): an agreement must not depend on the device data path."""
+    return _host_staged() or 'gloo' in str(dist.get_backend()) or not torch.cuda.is_available()
 
 
 def data_backend():
@@ -185,7 +253,7 @@ def barrier():
     if is_distributed():
         t = torch.zeros(1, dtype=torch.float64,
                         device='cpu' if _host_staged() else torch.device('cuda', torch.cuda.current_device()))
-        dist.all_reduce(t)
+        dist.all_reduce(t, group=_DATA_GROUP if t.is_cuda else None)
         if t.is_cuda:
             torch.cuda.current_stream(t.device).synchronize()
 
@@ -210,7 +278,7 @@ def gather_rows(local, n_rows_total, out=None):
         out = None
     if out is None:
         out = torch.empty((world * per,) + tail, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous())
+    dist.all_gather_into_tensor(out, local.contiguous(), group=_DATA_GROUP if local.is_cuda else None)
     return out[:n_rows_total].to(device)
 
 
@@ -237,16 +305,25 @@ def collect_rows(local, n_rows_total, dst=0):
     mine = local.contiguous()
     if staged:
         mine = mine.cpu()
+    group = None if staged else _DATA_GROUP
     tail = tuple(mine.shape[1:])
+    # the receiving rank makes room FIRST (the whole [N, R] matrix on its host: 15 GB of float32 at N = 1e6), and the
+    # ranks agree that it could before anybody sends: a sender must not sit in dist.send() towards a rank that has
+    # raised MemoryError (round 5's advisor)
+    failure, out, buf = None, None, None
+    if rank == dst:
+        try:
+            out = np.empty((n_rows_total,) + tail, dtype=torch.empty(0, dtype=mine.dtype).numpy().dtype)
+            buf = torch.empty((-(-n_rows_total // world),) + tail, dtype=mine.dtype, device=mine.device)
+        except Exception as e:      # noqa: BLE001 -- MemoryError, a torch allocation error: the peers hear of either
+            failure = e
+    agree_or_raise(failure)
     if rank != dst:
         lo, hi = shard_bounds(n_rows_total, world, rank)
         if hi > lo:
-            dist.send(mine[:hi - lo].contiguous(), dst=dst)
+            dist.send(mine[:hi - lo].contiguous(), dst=dst, group=group)
             last_collect_bytes = (hi - lo) * int(np.prod(tail, dtype=np.int64)) * mine.element_size()
         return None
-    out = np.empty((n_rows_total,) + tail, dtype=torch.empty(0, dtype=mine.dtype).numpy().dtype)
-    per = -(-n_rows_total // world)
-    buf = torch.empty((per,) + tail, dtype=mine.dtype, device=mine.device)
     for r in range(world):
         lo, hi = shard_bounds(n_rows_total, world, r)
         if hi <= lo:
@@ -254,16 +331,17 @@ def collect_rows(local, n_rows_total, dst=0):
         if r == rank:
             out[lo:hi] = mine[:hi - lo].cpu().numpy()
         else:
-            dist.recv(buf[:hi - lo], src=r)
+            dist.recv(buf[:hi - lo], src=r, group=group)
             out[lo:hi] = buf[:hi - lo].cpu().numpy()
             last_collect_bytes += (hi - lo) * int(np.prod(tail, dtype=np.int64)) * mine.element_size()
     return out
 
 
 def agree_or_raise(failure, device=None):
-    """All ranks get here; `failure` is this rank's exception (or None).  If ANY rank failed, EVERY rank raises, in this
-    call: the failed one its own exception, the others a SmartEngineError that says so -- no rank is left waiting in a
-    collective its failed peer never joins."""
+    """All ranks get here; `failure` is this rank's exception (or None; ANY exception: a status word that did not clear,
+    a HIP out-of-memory, a ValueError).  If ANY rank failed, EVERY rank raises, in this call: the failed one its own
+    exception, the others a SmartEngineError that says so -- no rank is left waiting in a collective its failed peer
+    never joins."""
     from .engine import SmartEngineError
     worst = max_over_ranks(1.0 if failure is not None else 0.0, device)
     if failure is not None:
@@ -287,7 +365,7 @@ def broadcast_matrix(matrix, src=0):
         t = torch.from_numpy(np.ascontiguousarray(matrix)).to(device)
     else:
         t = torch.empty(tuple(head[0]), dtype=getattr(torch, head[1]), device=device)
-    dist.broadcast(t, src=src)
+    dist.broadcast(t, src=src, group=_DATA_GROUP if t.is_cuda else None)
     return t.cpu().numpy()
 
 
@@ -402,8 +480,9 @@ class ShardedEnsemble(object):
 
 
 def _scalar_device(device=None):
-    """Where a one-number reduction lives: the host when the group stages through it, else the given (or current) GPU."""
-    if _host_staged() or not torch.cuda.is_available():
+    """Where a one-number reduction lives: the host whenever the default group carries host tensors (init()'s does), else
+    the given (or current) GPU."""
+    if _host_scalars():
         return torch.device('cpu')
     return device if device is not None else torch.device('cuda', torch.cuda.current_device())
 

@@ -136,14 +136,19 @@ class MonteCarlo(object):
             return
         lo, hi = sdist.shard_bounds(n, world, rank)
         rows = self._device_sample if self._device_sample is not None else self._sample
-        # one rank's launch failing (a status word its repeated launch could not clear) must not leave its peers waiting
-        # in the gather below: the outcome is agreed over the ranks first, and every rank raises if any did
-        failure, out = None, None
+        # one rank's launch failing -- a status word its repeated launch could not clear, a HIP out-of-memory at
+        # save_sim=True, any other exception (round 5 caught SmartEngineError only: advisor) -- must not leave its peers
+        # waiting in the gather below: the outcome is agreed over the ranks first, and every rank raises if any did (a
+        # failing MPI worker ends the reference's run as well, montecarlo.py:153-154 -- here promptly, and on every rank)
+        failure, out, block, mine = None, None, None, None
         try:
             out = self.model.simulate_ensemble(rows[lo:hi] if hi > lo else rows[:1],
                                                objective_functions=True, gw_constraint=self.constraints['gw'],
                                                save_discharge=self.save_sim, math_mode=self.math_mode)
-        except SmartEngineError as e:
+            block = torch.cat([out.objfn[:hi - lo, :n_obj], out.gw[:hi - lo].unsqueeze(1)], dim=1)
+            if self.save_sim:       # (the float32 the database keeps, montecarlo.py:225: a device copy that can fail too)
+                mine = out.discharge[:hi - lo].to(torch.float32)
+        except Exception as e:      # noqa: BLE001 -- re-raised below, on this rank as it is
             failure = e
         if world > 1:
             sdist.agree_or_raise(failure)
@@ -151,7 +156,6 @@ class MonteCarlo(object):
             raise failure
         # the [N, 9] block of objective functions and groundwater ratios goes to every rank (72 bytes per sample: second
         # stages select from it on any rank) ...
-        block = torch.cat([out.objfn[:hi - lo, :n_obj], out.gw[:hi - lo].unsqueeze(1)], dim=1)
         gathered = sdist.gather_rows(block, n)
         self.device_obj_fns, self.device_gw = gathered[:, :n_obj], gathered[:, n_obj]
         host = gathered.cpu().numpy()
@@ -161,12 +165,19 @@ class MonteCarlo(object):
         # :211-231).  Never all-gathered: [N, R] is 29 GB of fp64 at N = 1e6.
         series = None
         if self.save_sim:
-            series = sdist.collect_rows(out.discharge[:hi - lo].to(torch.float32), n, dst=0)
+            series = sdist.collect_rows(mine, n, dst=0)
+        failure = None
         if rank == 0:
-            db = self._open_database()
-            db.write_table(self.obj_fns, self._sample, series)
-            self._finish_database(db, compression)
-        sdist.barrier()
+            try:
+                db = self._open_database()
+                db.write_table(self.obj_fns, self._sample, series)
+                self._finish_database(db, compression)
+            except Exception as e:      # noqa: BLE001 -- a full disk on rank 0 ends the call on every rank
+                failure = e
+        if world > 1:
+            sdist.agree_or_raise(failure)       # (every rank has got here: the barrier of the call, with an outcome)
+        elif failure is not None:
+            raise failure
 
     # ---- the per-sample protocol of the reference (spotpy setup class) ------------------------------------
     def parameters(self):

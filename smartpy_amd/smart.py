@@ -91,8 +91,11 @@ class SMART(object):
         device = engine.default_device()
         extra = tuple(engine.extra_vector(self.extra)) if self.extra else None
         forcing = self._device_forcing(device)          # (compares the series with what is on the device: see there)
-        # what a kept run was made for; `forcing` is a new tensor whenever the series changed, so its identity counts
-        key = (report, str(device), extra, float(self.area), self.warm_up, id(forcing))
+        # what a kept run was made for; `forcing` is a new tensor whenever the series changed, so its identity counts --
+        # and so do the lengths a user script may change between calls by replacing timeseries / timeseries_report /
+        # delta_simu (round 5's key left them out: the old gap, warm-up and output length were reused silently; the
+        # reference's structure.run recomputes them on every call)
+        key = (report, str(device), extra, float(self.area), self.warm_up, id(forcing), T, gap, n_warm, delta_sec)
         run = self._single.get(key)
         if run is None:
             if len(self._single) >= 4:

@@ -115,6 +115,19 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert p['ok'] is True and p['max_rel_discharge'] <= 1e-9 and p['gate'] == 1e-9 and p['contract'] == 1e-6 and p['rows'] >= 64
     print('bench parity: discharge %.2e relative, gw ratio %.2e absolute (gate %.0e, contract %.0e)' % (
         p['max_rel_discharge'], p['max_abs_gw_ratio'], p['gate'], p['contract']))
+    # round 6: the launch that was TIMED is checked as well -- 48 rows of the stored matrix, their objective functions and
+    # groundwater ratios against the oracle -- and says which kernel it was
+    t = p['timed_launch']
+    assert t['ok'] is True and t['kernel'] == r['kernel'] and t['ranks'] == 1 and t['rows'] == 48
+    assert t['max_rel_discharge'] <= 1e-9 and t['max_abs_gw_ratio'] <= 1e-9 and t['max_rel_objfn'] <= 1e-8
+    assert t['values'] == 48 * 3653 and d['observations'] == 'oracle'
+    print('timed launch: discharge %.2e, objective functions %.2e, gw ratio %.2e' % (
+        t['max_rel_discharge'], t['max_rel_objfn'], t['max_abs_gw_ratio']))
+    # ... and a daily ensemble of 1e6 samples beside the headline: the literal rows in the throughput form
+    dy = d['daily_1e6']
+    assert 'smart_fast_illcond_lanes[' in dy['kernel'] and 'smart_fast_stiff' in dy['kernel']
+    assert dy['parity']['ok'] and dy['parity']['rows'] == 48 and dy['rows_per_class']['literal'] > 100000
+    assert dy['value'] > 1.5e11
     assert 'smart_fast_intervals' in d['objectives_only']['kernel'] and d['objectives_only']['value'] > 0.9 * d['value']
     f = d['flat_forcing']
     assert 'smart_fast_steps' in f['kernel'] and 0 < f['value'] < d['value'] * 1.05
@@ -167,6 +180,10 @@ def test_bench_with_two_ranks_launched_the_way_the_driver_does(config, samples):
     assert r['backend'] == 'gloo' and r['world_size'] == 2 and len(r['devices']) == 2
     assert len(r['launch_ms_per_rank']) == 2 and all(ms > 0 for ms in r['launch_ms_per_rank'])
     assert sorted(x['rank'] for x in r['ranks']) == [0, 1] and len({x['pid'] for x in r['ranks']}) == 2
+    # every rank has checked rows of its own timed launch against the oracle on its host
+    t = d['parity']['timed_launch']
+    assert t['ok'] and t['ranks'] == 2 and t['kernel'] == d['roofline']['kernel'] and t['max_rel_objfn'] <= 1e-8
+    assert (t['max_rel_discharge'] is not None) == (config == 3)          # (configs 4 and 5 store no matrix)
     if config == 3:
         # N > 1 keeps rank 0's CPU baseline and the in-run parity check, and carries config 4's strong-scaled figure
         assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 1e6
@@ -211,6 +228,39 @@ def test_bench_with_eight_ranks_launched_the_way_the_driver_does(config, samples
     else:
         assert d['scaling'] == 'strong' and c['runs_total'] == 64 * samples and c['runs_per_gpu'] == 8 * samples
     assert abs(d['value'] - c['runs_total'] * 96432 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+    # round 6: per-rank correctness of an N-rank run -- each of the eight ranks has pushed rows of ITS OWN timed job
+    # through the oracle, the line carries the largest difference and how many ranks took part
+    t = d['parity']['timed_launch']
+    assert t['ok'] and t['ranks'] == 8 and t['kernel'] == d['roofline']['kernel']
+    assert t['rows'] == 8 * min(48, c['runs_per_gpu']) if config != 5 else t['rows'] >= 8 * 12
+    assert t['max_abs_gw_ratio'] <= 1e-9 and t['max_rel_objfn'] <= 1e-8
+
+
+@pytest.mark.gpu
+def test_bench_without_a_checker_still_prints_its_line():
+    """A box without gcc and without a built oracle (round 5: no line at all): the observations come from the committed
+    fixture, the throughput line stands, `cpu_baseline` and `parity.timed_launch` are null with the reason."""
+    env = dict(os.environ, SMART_BENCH_NO_ORACLE='1')
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1',
+                                   '--samples', '20000', '--no-flat', '--no-strong'], cwd=ROOT, env=env,
+                                  stderr=subprocess.DEVNULL).decode()
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith('{')][0])
+    assert d['value'] > 1e11 and d['cpu_baseline'] is None and d['observations'].startswith('fixture')
+    assert d['parity']['timed_launch'] is None and 'SMART_BENCH_NO_ORACLE' in d['parity']['why']
+
+
+def test_the_committed_truth_fixture_is_what_the_oracle_computes():
+    """tests/golden/bench_truth.npz (bench.py --obs-from-fixture) against a run of the oracle, bit for bit."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import smart_oracle as so
+    for hourly in (True, False):
+        forcing, _ = bench.synthetic_forcing(0, hourly=hourly)
+        dt, gap = (3600.0, 24) if hourly else (86400.0, 1)
+        W = bench.WARM_DAYS * (24 if hourly else 1)
+        live, src = bench.truth_discharge(so, forcing, dt, forcing.shape[0], W, gap, hourly)
+        kept, src2 = bench.truth_discharge(None, forcing, dt, forcing.shape[0], W, gap, hourly)
+        assert src == 'oracle' and src2.startswith('fixture') and np.array_equal(live, kept)
 
 
 def test_the_legs_of_the_line_are_priced_against_the_issue_roof_with_their_own_counts():

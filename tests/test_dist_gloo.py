@@ -99,6 +99,13 @@ def _failing_simulate_ensemble(self, parameters, **kw):
     return _oracle_simulate_ensemble(self, parameters, **kw)
 
 
+def _oom_simulate_ensemble(self, parameters, **kw):
+    """... and one that runs out of device memory on rank 3 (what torch raises is a RuntimeError, not the engine's own)."""
+    if dist.is_initialized() and dist.get_rank() == 3:
+        raise RuntimeError('HIP out of memory. Tried to allocate 27.22 GiB')
+    return _oracle_simulate_ensemble(self, parameters, **kw)
+
+
 def _worker_lhs(rank, world, port, root, save_sim, seeded=True, n=13, failing=False):
     if world > 1:
         _init(rank, world, port)
@@ -108,7 +115,8 @@ def _worker_lhs(rank, world, port, root, save_sim, seeded=True, n=13, failing=Fa
     from smartpy_amd.montecarlo import LHS
     from smartpy_amd import distributed as sdist
     from smartpy_amd.engine import SmartEngineError
-    SMART.simulate_ensemble = _failing_simulate_ensemble if failing else _oracle_simulate_ensemble
+    SMART.simulate_ensemble = {False: _oracle_simulate_ensemble, True: _failing_simulate_ensemble,
+                               'oom': _oom_simulate_ensemble}[failing]
     # seeded: every rank draws the same sample.  Unseeded (what the reference's own scripts do): every process draws
     # another one from NumPy's global stream, and rank 0's has to win
     np.random.seed(2718 if seeded else 1000 + rank)
@@ -122,6 +130,8 @@ def _worker_lhs(rank, world, port, root, save_sim, seeded=True, n=13, failing=Fa
             outcome = 'returned'
         except SmartEngineError as e:
             outcome = 'peer' if 'another rank' in str(e) else 'own'
+        except RuntimeError as e:
+            outcome = 'own: ' + str(e)[:18]
         dist.barrier()
         open(os.path.join(root, 'outcome_r%d.txt' % rank), 'w').write(outcome)
         dist.destroy_process_group()
@@ -387,35 +397,93 @@ def test_gather_and_collect_rows_eight_ranks(tmp_path):
     assert [open(tmp_path / ('gather8_%d.txt' % r)).read() for r in range(8)] == ['ok'] * 8
 
 
-def _worker_probe(rank, world, port, out_dir, failing_rank):
+def _worker_probe(rank, world, port, out_dir, failing_rank, hangs=False):
     _init(rank, world, port)
     import warnings
     from smartpy_amd import distributed as sdist
 
-    def probe(device):          # stands for the group's first device collective
+    import time
+
+    def probe(device, group):   # stands for the group's first device collective
+        if rank == failing_rank and hangs:
+            time.sleep(600)     # a communicator set-up that never returns (the commoner RCCL failure)
         if rank == failing_rank:
             raise RuntimeError("NCCL error: unhandled cuda error\nhipIpcGetMemHandle: invalid argument")
         return float(world)
+    t0 = time.monotonic()
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
         works = sdist.rccl_answers(torch.device('cpu'), probe=probe)
+    took = time.monotonic() - t0
     ok = works == (failing_rank is None)
     if failing_rank is None:
-        ok = ok and sdist.rccl_failure is None and not w
+        ok = ok and sdist.rccl_failure is None and not w and not sdist._ABANDONED
     else:
-        ok = ok and sdist.rccl_failure == ('RuntimeError: NCCL error: unhandled cuda error' if rank == failing_rank
-                                           else 'RCCL failed on another rank')
-        ok = ok and (len(w) == 1) == (rank == 0)
-    open(os.path.join(out_dir, 'probe_%d.txt' % rank), 'w').write('ok' if ok else 'FAILED %r %r' % (works, sdist.rccl_failure))
-    dist.destroy_process_group()
+        mine = ('the first device collective over 4 ranks did not answer within 3 s' if hangs
+                else 'RuntimeError: NCCL error: unhandled cuda error')
+        ok = ok and sdist.rccl_failure == (mine if rank == failing_rank else 'RCCL failed on another rank')
+        ok = ok and (len(w) == 1) == (rank == 0) and sdist._ABANDONED
+        ok = ok and took < 20.0          # bounded: the probe's 3 s + the agreement, not the ten minutes of a watchdog
+    open(os.path.join(out_dir, 'probe_%d.txt' % rank), 'w').write('ok' if ok else 'FAILED %r %r %.1f' % (works, sdist.rccl_failure, took))
+    # (a rank whose stand-in still sleeps ends the way finish() ends a process that left a communicator behind)
+    sdist.finish(0)
 
 
-@pytest.mark.parametrize('failing_rank', [None, 0, 2])
-def test_ranks_agree_on_staging_when_rccl_does_not_start_on_one_of_them(tmp_path, failing_rank):
+@pytest.mark.parametrize('failing_rank, hangs', [(None, False), (0, False), (2, False), (1, True)])
+def test_ranks_agree_on_staging_when_rccl_does_not_start_on_one_of_them(tmp_path, monkeypatch, failing_rank, hangs):
     """distributed.init()'s first device collective, replaced by a stand-in that raises on one rank the way a refused
-    IPC handle does: every rank gives the same answer (stage through the host), rank 0 alone warns, each keeps a reason."""
-    mp.spawn(_worker_probe, args=(4, _free_port(), str(tmp_path), failing_rank), nprocs=4, join=True)
+    IPC handle does -- or that never RETURNS (round 5 caught the raise only; a hang waited for RCCL's watchdog, ten
+    minutes of silence and no line): every rank gives the same answer (stage through the host) within the probe's
+    bound, rank 0 alone warns, each keeps a reason, and the process ends without waiting for the thread that hangs."""
+    monkeypatch.setenv('SMART_DIST_PROBE_TIMEOUT', '3')
+    mp.spawn(_worker_probe, args=(4, _free_port(), str(tmp_path), failing_rank, hangs), nprocs=4, join=True)
     assert [open(tmp_path / ('probe_%d.txt' % r)).read() for r in range(4)] == ['ok'] * 4
+
+
+def _worker_absent(rank, world, port, out_dir):
+    """distributed.init() itself (no GPU here: the gloo default group with its timeout), then one rank never joins."""
+    import time
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from smartpy_amd import distributed as sdist
+    sdist.init()
+    assert sdist.data_backend() == 'gloo' and sdist.max_over_ranks(rank) == world - 1
+    t0 = time.monotonic()
+    outcome = 'returned'
+    if rank == 2:
+        time.sleep(12.0)        # (asleep through the collective: a rank that died, or one stuck in a driver call)
+        outcome = 'slept'
+    else:
+        try:
+            sdist.agree_or_raise(None)
+        except Exception as e:      # noqa: BLE001 -- gloo's timeout surfaces as a RuntimeError / DistBackendError
+            outcome = 'raised after %.0f s' % (time.monotonic() - t0) if time.monotonic() - t0 < 11.0 else 'raised late'
+    open(os.path.join(out_dir, 'absent_%d.txt' % rank), 'w').write(outcome)
+    os._exit(0)     # (the group is broken by now: no orderly shutdown to be had)
+
+
+def test_a_rank_that_never_arrives_makes_its_peers_raise_within_the_bound(tmp_path, monkeypatch):
+    """init() gives the default group a timeout (SMART_DIST_TIMEOUT, 120 s by default; round 5 passed none, so a peer
+    that never arrived meant ten minutes of silence): the ranks that wait raise within it."""
+    monkeypatch.setenv('SMART_DIST_TIMEOUT', '5')
+    mp.spawn(_worker_absent, args=(4, _free_port(), str(tmp_path)), nprocs=4, join=True)
+    got = [open(tmp_path / ('absent_%d.txt' % r)).read() for r in range(4)]
+    assert got[2] == 'slept' and all(g.startswith('raised after') for i, g in enumerate(got) if i != 2), got
+
+
+def test_importing_the_package_leaves_the_hsa_ipc_mode_alone(tmp_path):
+    """Round 5 set HSA_ENABLE_IPC_MODE_LEGACY=0 on import of smartpy_amd.distributed (advisor: every user process got
+    its environment changed).  Now: untouched on import; init() sets it only when SMART_DIST_IPC_DMABUF=1 asks."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('HSA_ENABLE_IPC_MODE_LEGACY', 'SMART_DIST_IPC_DMABUF')}
+    code = ("import os, sys; sys.path.insert(0, %r); import smartpy_amd.montecarlo, smartpy_amd.distributed as d; "
+            "a = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'); d.init(); b = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'); "
+            "os.environ['SMART_DIST_IPC_DMABUF'] = '1'; d.init(); print(a, b, os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))" % ROOT)
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ['None', 'None', '0']
 
 
 @pytest.mark.parametrize('n', [13, 5])
@@ -450,3 +518,12 @@ def test_a_failing_rank_makes_all_eight_raise(tmp_path):
     mp.spawn(_worker_lhs, args=(8, _free_port(), root, True, True, 13, True), nprocs=8, join=True)
     got = [open(os.path.join(root, 'outcome_r%d.txt' % r)).read() for r in range(8)]
     assert got == ['peer'] * 3 + ['own'] + ['peer'] * 4
+
+
+def test_a_rank_out_of_memory_makes_all_eight_raise(tmp_path):
+    """... and so does an exception that is not the engine's own (round 5 caught SmartEngineError only: a HIP
+    out-of-memory on one rank left the seven others in the gather): the rank re-raises its own RuntimeError."""
+    root = _make_root(str(tmp_path / 'eight'))
+    mp.spawn(_worker_lhs, args=(8, _free_port(), root, True, True, 13, 'oom'), nprocs=8, join=True)
+    got = [open(os.path.join(root, 'outcome_r%d.txt' % r)).read() for r in range(8)]
+    assert got == ['peer'] * 3 + ['own: HIP out of memory.'] + ['peer'] * 4

@@ -426,6 +426,54 @@ def test_the_c_abi_from_a_c_program(tmp_path, example):
     assert np.array_equal(dis, ref.discharge_report_major.cpu().numpy())
 
 
+def test_init_makes_an_rccl_subgroup_beside_the_gloo_default_group_and_probes_it():
+    """Round 6's distributed.init(): a gloo default group (host objects, agreements) + an RCCL subgroup for the device
+    tensors whose first collective runs at once, in a thread, with a bound.  A one-GPU box cannot hold two RCCL ranks,
+    but a group of ONE runs every call of that path: new_group(backend='nccl'), the polled first all-reduce, and the
+    package's collectives through the subgroup (gather, broadcast, point-to-point collection, barrier) -- then
+    finish()."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29641', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                  SMART_DIST_SINGLE='1')
+os.environ.pop('SMART_DIST_BACKEND', None)
+import numpy as np, torch, torch.distributed as dist
+from smartpy_amd import distributed as sd
+rank, world, device = sd.init()
+assert (rank, world) == (0, 1) and device.type == 'cuda' and dist.is_initialized()
+assert str(dist.get_backend()) == 'gloo' and sd._DATA_GROUP is not None and sd._STAGED is False
+assert sd.rccl_failure is None and not sd._ABANDONED and str(dist.get_backend(sd._DATA_GROUP)) == 'nccl'
+sd.is_distributed = lambda: True                      # a world of one is "not distributed" for the product
+assert sd.data_backend() == 'nccl'
+x = torch.arange(27, dtype=torch.float64, device='cuda').reshape(3, 9)
+out = sd.gather_rows(x, 3)
+assert out.is_cuda and torch.equal(out, x)
+assert sd.max_over_ranks(2.5) == 2.5 and sd.sum_over_ranks(1.5) == 1.5      # (host scalars: the gloo default group)
+sd.barrier()
+m = np.arange(30, dtype=np.float64).reshape(3, 10) / 7
+assert np.array_equal(sd.broadcast_matrix(m), m)
+got = sd.collect_rows(x.to(torch.float32), 3, dst=0)
+assert got.dtype == np.float32 and np.array_equal(got, x.cpu().numpy().astype(np.float32))
+sd.agree_or_raise(None)
+# a first collective that raises: every rank (here: the one) falls back to host staging and says why
+os.environ['SMART_DIST_PROBE_TIMEOUT'] = '2'
+def boom(device, group):
+    raise RuntimeError('NCCL error: unhandled cuda error')
+import warnings
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    assert sd.rccl_answers(device, group=sd._DATA_GROUP, probe=boom) is False
+assert 'unhandled cuda error' in sd.rccl_failure and sd._ABANDONED and len(w) == 1
+print('subgroup ok')
+sd.finish(0)
+''' % ROOT
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'subgroup ok' in r.stdout, r.stdout + r.stderr
+
+
 def test_rccl_code_path_with_a_single_rank_group():
     """A box with one GPU cannot hold a two-rank RCCL group, but a one-rank group runs the very calls the multi-GPU
     path makes on device tensors (all_gather_into_tensor, all_reduce, broadcast, barrier with device_ids): the
