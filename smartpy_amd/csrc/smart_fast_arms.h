@@ -661,19 +661,64 @@
 // hipcc's own loop over the same arithmetic carries 5 to 8 more per step (a 64-bit counter, a constant rebuilt in
 // every turn, s_waitcnt's for loads that were long in) -- and a lone wavefront issues ONE instruction of any kind
 // per turn of its SIMD.  s', s'^2, s'^3 in registers of their own here: `ex` and `eh` live across the steps.
-#define SMART_A_WET_HEAD SMART_A_ROUTE "v_fma_f64 %[xf], -%[eh], %[tot], %[ex]\n\t" SMART_A_FILL1("l0", "xf")
+// SMART_WET_E32 (round 6).  A wavefront that has its SIMD (nearly) to itself is fed by the instruction fetch: an 8-byte
+// encoding costs it 5.6 cycles, a 4-byte one 4.7 (profiles/r05_microbench_lanes.txt, `probe`) -- and every fp64
+// instruction is a VOP3 of 8 bytes except ONE: v_fmac_f64_e32  dst = src0 * src1 + dst, no modifiers.  22 of the wet
+// step's 73 instructions are of that shape once the powers carry the sign (n_i = -s'^i: l = l * n_i + l is the leak
+// fma(-l, s'^i, l), the same bits -- a product's magnitude does not depend on its factors' signs) and -D sits in a
+// register of its own: the two products of the routing sum, the saturation excess' two shares, and the eighteen leaks.
+// They come in runs of even length, so every 8-byte instruction starts where it did (SMART_A_WET_INTERVAL has the parities).
+// The second leak pass forms its five factors first (four scratch registers more) and then leaks six times in a row.
+#ifndef SMART_WET_E32
+#define SMART_WET_E32 0
+#endif
+#if SMART_WET_E32
+#define SMART_A_ROUTE_W                                                                                                \
+    "v_mul_f64 %[t0], %[cg], %[yg]\n\t"                                                                                \
+    "v_fmac_f64_e32 %[t0], %[cf], %[yf]\n\t"                                                                           \
+    "v_fmac_f64_e32 %[t0], %[cs], %[ys]\n\t"                                                                           \
+    "v_add_f64 %[acc], %[acc], %[riv]\n\t"                                                                             \
+    "v_fma_f64 %[riv], %[riv], %[oma], %[t0]\n\t"
+#define SMART_A_SAT_SHARES                                                                                             \
+    "v_fmac_f64_e32 %[xf], %[npd], %[t1]\n\t"                                                                          \
+    "v_fmac_f64_e32 %[xs], %[pd], %[t1]\n\t"
+#define SMART_A_LEAK_N(l, p) "v_fmac_f64_e32 %[" l "], %[" l "], %[" p "]\n\t"
+// s1 .. p6 hold -s', -s'^2, ... -s'^6 here
+#define SMART_A_LEAKS_W                                                                                                \
+    "v_mul_f64 %[s1], -%[sz], %[tot]\n\t"                                                                              \
+    "v_mul_f64 %[p2], %[s1], -%[s1]\n\t"                                                                               \
+    "v_mul_f64 %[p3], %[p2], -%[s1]\n\t"                                                                               \
+    "v_mul_f64 %[p4], %[p2], -%[p2]\n\t"                                                                               \
+    "v_mul_f64 %[p5], %[p4], -%[s1]\n\t"                                                                               \
+    "v_mul_f64 %[p6], %[p3], -%[p3]\n\t" SMART_A_LEAK_N("l0", "s1") SMART_A_LEAK_N("l1", "p2")                         \
+        SMART_A_LEAK_N("l2", "p3") SMART_A_LEAK_N("l3", "p4") SMART_A_LEAK_N("l4", "p5") SMART_A_LEAK_N("l5", "p6")    \
+            SMART_A_LSUM("ai") "v_mul_f64 %[t1], %[s1], 0.5\n\t"                                                       \
+                               "v_mul_f64 %[t0], %[s1], %[k3]\n\t"                                                     \
+                               "v_ldexp_f64 %[xg], %[s1], -2\n\t"                                                      \
+                               "v_mul_f64 %[q1], %[s1], %[k5]\n\t"                                                     \
+                               "v_mul_f64 %[q2], %[s1], %[k6]\n\t" SMART_A_LEAK_N("l0", "s1") SMART_A_LEAK_N("l1", "t1") \
+                SMART_A_LEAK_N("l2", "t0") SMART_A_LEAK_N("l3", "xg") SMART_A_LEAK_N("l4", "q1")                       \
+                    SMART_A_LEAK_N("l5", "q2") SMART_A_LEAK_N("l0", "p6") SMART_A_LEAK_N("l1", "p5")                   \
+                        SMART_A_LEAK_N("l2", "p4") SMART_A_LEAK_N("l3", "p3") SMART_A_LEAK_N("l4", "p2")               \
+                            SMART_A_LEAK_N("l5", "s1")
+#else
+#define SMART_A_ROUTE_W SMART_A_ROUTE
+#define SMART_A_SAT_SHARES                                                                                             \
+    "v_fma_f64 %[xf], -%[pd], %[t1], %[xf]\n\t"                                                                        \
+    "v_fma_f64 %[xs], %[pd], %[t1], %[xs]\n\t"
+#define SMART_A_LEAKS_W SMART_A_LEAKS_("s1", "p2", "p3", "")
+#endif
+#define SMART_A_WET_HEAD SMART_A_ROUTE_W "v_fma_f64 %[xf], -%[eh], %[tot], %[ex]\n\t" SMART_A_FILL1("l0", "xf")
 #define SMART_A_WET_FILL_TAIL                                                                                          \
     SMART_A_FILL1("l1", "t1") SMART_A_FILL1("l2", "t1") SMART_A_FILL1("l3", "t1") SMART_A_FILL1("l4", "t1")            \
-        SMART_A_FILL1("l5", "t1") "v_mul_f64 %[xs], %[eh], %[tot]\n\t"                                                 \
-                                  "v_fma_f64 %[xf], -%[pd], %[t1], %[xf]\n\t"                                          \
-                                  "v_fma_f64 %[xs], %[pd], %[t1], %[xs]\n\t"
+        SMART_A_FILL1("l5", "t1") "v_mul_f64 %[xs], %[eh], %[tot]\n\t" SMART_A_SAT_SHARES
 #define SMART_A_WET_REST                                                                                               \
-    SMART_A_LEAKS_("s1", "p2", "p3", "") "v_add_f64 %[t1], %[tot], -%[ai]\n\t"                                         \
-                                         "v_add_f64 %[xf], %[xf], %[t1]\n\t" SMART_A_TOT_XG                            \
-                                         "v_fma_f64 %[ys], %[ys], %[ds], %[xs]\n\t"                                    \
-                                         "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                    \
-                                         "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                    \
-                                         "v_add_f64 %[xgs], %[xgs], %[xg]\n\t"
+    SMART_A_LEAKS_W "v_add_f64 %[t1], %[tot], -%[ai]\n\t"                                                              \
+                    "v_add_f64 %[xf], %[xf], %[t1]\n\t" SMART_A_TOT_XG                                                 \
+                    "v_fma_f64 %[ys], %[ys], %[ds], %[xs]\n\t"                                                         \
+                    "v_fma_f64 %[yf], %[yf], %[df], %[xf]\n\t"                                                         \
+                    "v_fma_f64 %[yg], %[yg], %[dg], %[xg]\n\t"                                                         \
+                    "v_add_f64 %[xgs], %[xgs], %[xg]\n\t"
 #define SMART_A_WET_STEP SMART_A_WET_HEAD SMART_A_WET_FILL_TAIL SMART_A_WET_REST
 // SMART_WET_MODES 0: every step fills all six layers (round 3's first form, kept for the A/B).
 // 1 / 2: two loops.  While the rain excess of every lane fits into the TOP layer -- 39 % of the wet wave-steps of the

@@ -509,6 +509,23 @@ struct FastModel {
             double tot = layer_sum();
             double t0, t1, xs, xf, xg, w_s1, w_p2, w_p3, w_p4, w_p5, w_p6, w_ai;
             int cnt;
+#if SMART_WET_E32
+            // (the powers carry the sign here -- n_i = -s'^i -- so the second pass's factors are +1/2 ... +1/6 of -s', and
+            // -D sits in a register: smart_fast_arms.h, SMART_WET_E32)
+            double w_q1, w_q2;
+            asm volatile(SMART_A_WET_INTERVAL
+                         : [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), [l4] "+v"(l4), [l5] "+v"(l5),
+                           [ys] "+v"(u_ove), [yf] "+v"(u_int), [yg] "+v"(u_sgw), [riv] "+v"(u_riv), [acc] "+v"(acc),
+                           [tot] "+v"(tot), [xgs] "+v"(xg_sum), [t0] "=&v"(t0), [t1] "=&v"(t1), [xs] "=&v"(xs),
+                           [xf] "=&v"(xf), [xg] "=&v"(xg), [s1] "=&v"(w_s1), [p2] "=&v"(w_p2), [p3] "=&v"(w_p3),
+                           [p4] "=&v"(w_p4), [p5] "=&v"(w_p5), [p6] "=&v"(w_p6), [ai] "=&v"(w_ai), [q1] "=&v"(w_q1),
+                           [q2] "=&v"(w_q2), [cnt] "=&s"(cnt)
+                         : [cs] "v"(car_s), [cf] "v"(car_f), [cg] "v"(car_g), [oma] "v"(om_ar), [ds] "v"(dec_s),
+                           [df] "v"(dec_f), [dg] "v"(dec_g), [sz] "v"(sz), [z] "v"(z), [pd] "v"(pD), [npd] "v"(-pD),
+                           [ex] "v"(ex), [eh] "v"(e_h), [k3] "s"(1.0 / 3.0), [k5] "s"(0.2), [k6] "s"(1.0 / 6.0),
+                           [n] "s"((int)n), [ok] "s"(__builtin_amdgcn_readfirstlane((int)fits))
+                         : "scc", "vcc");
+#else
             asm volatile(SMART_A_WET_INTERVAL
                          : [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), [l4] "+v"(l4), [l5] "+v"(l5),
                            [ys] "+v"(u_ove), [yf] "+v"(u_int), [yg] "+v"(u_sgw), [riv] "+v"(u_riv), [acc] "+v"(acc),
@@ -520,6 +537,7 @@ struct FastModel {
                            [eh] "v"(e_h), [k3] "s"(-(1.0 / 3.0)), [k5] "s"(-0.2), [k6] "s"(-(1.0 / 6.0)),
                            [n] "s"((int)n), [ok] "s"(__builtin_amdgcn_readfirstlane((int)fits))
                          : "scc", "vcc");
+#endif
         } else if (kLeakBalance) {
             const double e_h = ex * hz;
             double tot = layer_sum();

@@ -5,7 +5,14 @@
 
 namespace smart {
 
-SMART_FAST_KERNEL(smart_fast_steps) { merged_kernel<FastModel<false, false, true>, kForcingVarying>(a, forcing, obs, ws); }
+// SMART_STEPS_WAVES (A/B builds, round 6): ask hipcc for an allocation that lets that many wavefronts of smart_fast_steps
+// share a SIMD (3: <= 168 VGPRs where it takes 170 by itself; profiles/r06_ab_steps_third_wave.txt has what that buys)
+#ifdef SMART_STEPS_WAVES
+#define SMART_STEPS_OCC __attribute__((amdgpu_waves_per_eu(SMART_STEPS_WAVES, SMART_STEPS_WAVES)))
+#else
+#define SMART_STEPS_OCC
+#endif
+SMART_STEPS_OCC SMART_FAST_KERNEL(smart_fast_steps) { merged_kernel<FastModel<false, false, true>, kForcingVarying>(a, forcing, obs, ws); }
 
 SMART_FAST_KERNEL(smart_fast_steps_states) { merged_kernel<FastModel<false, false, true, true, true>, kForcingVarying>(a, forcing, obs, ws); }
 

@@ -469,7 +469,7 @@ with warnings.catch_warnings(record=True) as w:
 assert 'unhandled cuda error' in sd.rccl_failure and sd._ABANDONED and len(w) == 1
 print('subgroup ok')
 sd.finish(0)
-''' % ROOT
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'subgroup ok' in r.stdout, r.stdout + r.stderr
 

@@ -1685,6 +1685,21 @@ def test_the_two_forms_of_the_literal_rows_give_the_same_bits(eng, example, monk
         assert rel(res.objfn.cpu().numpy()[pick, :7], want[:, :7]) < 1e-8
 
 
+def test_the_randomized_families_with_the_literal_rows_in_the_lane_form(eng, example, monkeypatch):
+    """The randomized and adversarial families above launch a few hundred rows at a time, which the launch's own choice
+    puts on the row form (smart_fast_illcond); the lane form (smart_fast_illcond_lanes) is what LARGE daily ensembles
+    get.  Here the same families -- parameters far outside the sampling ranges, NaNs and infinities, soil above capacity,
+    shares that are none, every report mode -- run with the lane form forced: the same assertions (class-3 rows the
+    literal kernel's bits, the others within tolerance of the reference-exact oracle)."""
+    monkeypatch.setenv('SMART_ILLCOND_FORM', 'lanes')
+    for seed, upto in ((9001, 4), (9040, 6), (606, 5)):
+        run_wide_cases(eng, seed, upto)
+    run_batch_cases(eng, 607, 4, stress_initial=True)
+    test_adversarial_parameter_rows_against_the_oracle(eng, 26)
+    test_rows_with_shares_that_are_none_take_the_literal_arithmetic(eng)
+    test_ill_conditioned_rows_with_wild_parameters_match_the_literal_kernel(eng, example)
+
+
 def test_ill_conditioned_rows_with_wild_parameters_match_the_literal_kernel(eng, example):
     """The ill-conditioned rows of the fast mode run the reference's operation order with a few identities applied where
     wave-uniform checks allow them (divisions through reciprocals, clamps and the two cascades' hand-downs as
