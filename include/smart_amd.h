@@ -287,8 +287,11 @@ int smart_row_class(const double *params, double delta_sec, const double *initia
 /* Device bookkeeping */
 int smart_device_count(void);           /* number of visible HIP devices (0 if none / no driver)      */
 int smart_abi_version(void);            /* SMART_AMD_ABI_VERSION the library was built with           */
-const char *smart_build_info(void);     /* the compiler that built the library ("hipcc <HIP version> | clang <version> |
-                                         * gfx950"): the layout lints of smartpy_amd/isa_lint.py hold for that build */
+const char *smart_build_info(void);     /* the compiler that built the library, the ABI, and the stamp of the build's code lint:
+                                         * "hipcc <HIP version> | clang <version> | gfx950 | ABI 7 | SMART_LINT_STAMP=pairs-ok"
+                                         * (smartpy_amd.build writes the stamp into the file it has linted; "unchecked": a
+                                         * build by another route -- the step loops then run without computed jumps unless
+                                         * the environment says SMART_PAIR_BLOCKS=1) */
 const char *smart_last_error(void);     /* text of the calling thread's last error ("" if none)       */
 
 #ifdef __cplusplus

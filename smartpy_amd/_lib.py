@@ -91,28 +91,49 @@ def _apply_lint_verdict():
     from . import isa_lint
     ok, pairs, reason = isa_lint.verdict_for(LIB_PATH)
     unrecorded = isa_lint.read_sidecar(LIB_PATH) is None or 'another build' in reason
-    if ok and not pairs and unrecorded:
-        # no record, or one for another file (a library that travelled without it, or was rebuilt by something else):
-        # look at the code now if the disassembler is at hand (~6 s, once: the record is written for the next load)
-        if os.path.exists(isa_lint.OBJDUMP):
-            report = isa_lint.check_library(LIB_PATH)
-            try:
-                isa_lint.write_sidecar(report, LIB_PATH)
-            except OSError:
-                pass
-            if report['checked']:
-                if report['handover'] is False or report['rows'] is False:
-                    ok, pairs, reason = False, False, '; '.join(report['problems'])
-                else:
-                    ok, pairs, reason = True, bool(report['pair_blocks']), '; '.join(report['problems'])
+    if ok and not pairs and unrecorded and os.path.exists(isa_lint.OBJDUMP):
+        # no record, or one for another file (a library that travelled without it, or was rebuilt by something else): look
+        # at the code now (~6 s) and leave the record for the next load.  ONE process of a job does it -- the others wait
+        # at the lock and read what it wrote (round 5: the N ranks of a launch each disassembled the library: advisor)
+        lock = None
+        try:
+            import fcntl
+            lock = open(LIB_PATH + '.lint.lock', 'w')
+            fcntl.flock(lock, fcntl.LOCK_EX)
+        except (ImportError, OSError):
+            lock = None         # (a read-only tree: every process looks for itself, as before)
+        try:
+            ok, pairs, reason = isa_lint.verdict_for(LIB_PATH)
+            if ok and not pairs and (isa_lint.read_sidecar(LIB_PATH) is None or 'another build' in reason):
+                report = isa_lint.check_library(LIB_PATH)
+                report['stamp'] = isa_lint.library_stamp(LIB_PATH)
+                try:
+                    isa_lint.write_sidecar(report, LIB_PATH)
+                except OSError:
+                    pass
+                if report['checked']:
+                    if report['handover'] is False or report['rows'] is False:
+                        ok, pairs, reason = False, False, '; '.join(report['problems'])
+                    else:
+                        ok, pairs, reason = True, bool(report['pair_blocks']), '; '.join(report['problems'])
+        finally:
+            if lock is not None:
+                lock.close()
     if not ok:
         raise ImportError("smartpy_amd: %s failed the code lints of smartpy_amd.isa_lint (%s); rebuild it with "
                           "`python -m smartpy_amd.build --force`" % (LIB_PATH, reason))
-    if not pairs and 'SMART_PAIR_BLOCKS' not in os.environ:
+    if 'SMART_PAIR_BLOCKS' in os.environ:
+        return                  # (the caller's word stands: A/B builds, tools/variants)
+    if not pairs:
         os.environ['SMART_PAIR_BLOCKS'] = '0'
         warnings.warn("smartpy_amd: %s; the step loops run their threaded chunks instead of the pair blocks "
                       "(SMART_PAIR_BLOCKS=0).  `python -m smartpy_amd.build --force` builds and checks the library."
                       % reason)
+    elif isa_lint.library_stamp(LIB_PATH) != 'pairs-ok':
+        # the code has been looked at (just now, or by the record's writer) but the file carries no stamp of it -- a
+        # library that smartpy_amd.build did not link: the library by itself would run the threaded chunks (smart_capi.hip:
+        # pair_blocks_wanted); this process has the lint's word for the pair blocks
+        os.environ['SMART_PAIR_BLOCKS'] = '1'
 
 
 def lib():

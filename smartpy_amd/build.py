@@ -74,16 +74,34 @@ def build(force=False, verbose=False, extra_flags=(), lib_path=LIB):
             print(' '.join(cmd))
         try:
             subprocess.check_call(cmd)
-            report = lint(tmp, verbose)
-            os.replace(tmp, lib_path)
             from . import isa_lint
+            report = lint(tmp, verbose)
+            # the verdict on the pair blocks goes INTO the file (a caller of the C ABI reads no record next to it), then
+            # the record is written for the file as it now is
+            isa_lint.stamp_library(tmp, bool(report['pair_blocks']))
+            report['sha256'] = isa_lint.sha256_of(tmp)
+            report['stamp'] = isa_lint.library_stamp(tmp)
+            os.replace(tmp, lib_path)
             isa_lint.write_sidecar(report, lib_path)
         finally:
             if os.path.exists(tmp):
                 os.remove(tmp)
     elif lint_missing(lib_path):
+        # a library without a record of its own (copied here, or its record lost): looked at now, stamped in a copy that
+        # then takes its place (a process that has the old file loaded keeps it)
         from . import isa_lint
-        isa_lint.write_sidecar(lint(lib_path, verbose), lib_path)
+        report = lint(lib_path, verbose)
+        tmp = '%s.%d.tmp' % (lib_path, os.getpid())
+        try:
+            shutil.copy(lib_path, tmp)
+            isa_lint.stamp_library(tmp, bool(report['pair_blocks']))
+            report['sha256'] = isa_lint.sha256_of(tmp)
+            report['stamp'] = isa_lint.library_stamp(tmp)
+            os.replace(tmp, lib_path)
+            isa_lint.write_sidecar(report, lib_path)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return lib_path
 
 

@@ -385,11 +385,24 @@ static size_t slice_bytes(int64_t n_samples, int64_t n_catchments)
 static int merged_report(const SmartEnsemble *e);
 static int plan_time_slices(const SmartEnsemble *e, int n_simd, int *per_simd, double *load);
 
-// SMART_PAIR_BLOCKS=0 in the environment: the threaded chunks instead of the pair blocks (A/B runs of the tools)
+// The streaming step loops jump through byte offsets that another kernel wrote (smart_fast_arms.h: pair blocks): right for
+// a library whose code smartpy_amd.isa_lint has looked at.  smartpy_amd.build lints every library it links and, when the
+// pair blocks lie where the code words point, writes "pairs-ok" over the "unchecked" of this stamp IN THE FILE (round 6:
+// round 5 kept the verdict in a record next to the library, which a caller of the C ABI never reads -- advisor).  A
+// library that carries no such stamp -- built by another route, by another hipcc -- runs the THREADED CHUNKS (the same
+// arithmetic, bit for bit, no computed jumps) unless the environment says SMART_PAIR_BLOCKS=1; SMART_PAIR_BLOCKS=0 asks
+// for the threaded chunks whatever the stamp (A/B runs of the tools).
+extern "C" __attribute__((used, visibility("default"))) volatile char smart_lint_stamp[40] = "SMART_LINT_STAMP=unchecked";
+
 static bool pair_blocks_wanted()
 {
-    const char *env = getenv("SMART_PAIR_BLOCKS");
-    return !(env && atoi(env) == 0);
+    if (const char *env = getenv("SMART_PAIR_BLOCKS"))
+        return atoi(env) != 0;
+    static const char ok[] = "SMART_LINT_STAMP=pairs-ok";
+    for (size_t i = 0; i + 1 < sizeof(ok); ++i)
+        if (smart_lint_stamp[i] != ok[i])
+            return false;
+    return true;
 }
 
 // what a sliced launch of this call needs for its hand-over (0: the call is not sliced, or no device to ask)
@@ -1368,8 +1381,17 @@ int smart_abi_version(void) { return SMART_AMD_ABI_VERSION; }
 #define SMART_STR(x) SMART_STR_(x)
 const char *smart_build_info(void)
 {
-    return "hipcc " SMART_STR(HIP_VERSION_MAJOR) "." SMART_STR(HIP_VERSION_MINOR) "." SMART_STR(HIP_VERSION_PATCH)
-           " | clang " __clang_version__ " | gfx950 | ABI " SMART_STR(SMART_AMD_ABI_VERSION);
+    static char text[256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        char stamp[40];
+        for (size_t i = 0; i < sizeof(stamp); ++i)
+            stamp[i] = smart_lint_stamp[i];
+        stamp[sizeof(stamp) - 1] = 0;
+        snprintf(text, sizeof(text), "hipcc %d.%d.%d | clang %s | gfx950 | ABI %d | %s", HIP_VERSION_MAJOR,
+                 HIP_VERSION_MINOR, HIP_VERSION_PATCH, __clang_version__, SMART_AMD_ABI_VERSION, stamp);
+    });
+    return text;
 }
 
 const char *smart_last_error(void) { return g_err; }

@@ -28,7 +28,48 @@ import shutil
 import subprocess
 import tempfile
 
-OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+
+
+def _find_objdump():
+    """llvm-objdump of the ROCm toolchain: $ROCM_PATH, the usual place, or whatever the PATH holds (round 5 knew one
+    hard-coded path: advisor)."""
+    roots = [os.environ.get('ROCM_PATH'), os.environ.get('ROCM_HOME'), '/opt/rocm']
+    for root in roots:
+        if root:
+            exe = os.path.join(root, 'lib', 'llvm', 'bin', 'llvm-objdump')
+            if os.path.exists(exe):
+                return exe
+    return shutil.which('llvm-objdump') or '/opt/rocm/lib/llvm/bin/llvm-objdump'
+
+
+OBJDUMP = _find_objdump()
+
+STAMP_UNCHECKED = b'SMART_LINT_STAMP=unchecked'
+STAMP_PAIRS_OK = b'SMART_LINT_STAMP=pairs-ok\0'          # (same length: written over the other in the file)
+
+
+def stamp_library(path, pairs_ok):
+    """The lint's verdict on the pair blocks INTO the library file (smart_capi.hip: smart_lint_stamp), so that a caller of
+    the C ABI who never sees the record next to the file gets the computed jumps only from a library whose code was looked
+    at.  -> True if the stamp was found (once) and written."""
+    with open(path, 'rb') as fh:
+        blob = fh.read()
+    assert len(STAMP_PAIRS_OK) == len(STAMP_UNCHECKED)
+    if blob.count(STAMP_UNCHECKED) != 1:
+        return False
+    if pairs_ok:
+        with open(path, 'wb') as fh:
+            fh.write(blob.replace(STAMP_UNCHECKED, STAMP_PAIRS_OK))
+    return True
+
+
+def library_stamp(path):
+    """'pairs-ok' | 'unchecked' | None (no stamp in the file)"""
+    with open(path, 'rb') as fh:
+        blob = fh.read()
+    if STAMP_PAIRS_OK.rstrip(b'\0') in blob:
+        return 'pairs-ok'
+    return 'unchecked' if STAMP_UNCHECKED in blob else None
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, 'csrc', 'libsmart_amd.so')
 FP64 = ('v_fma_f64', 'v_fmac_f64', 'v_add_f64', 'v_mul_f64', 'v_min_f64', 'v_max_f64', 'v_ldexp_f64')

@@ -114,3 +114,41 @@ def test_a_library_whose_hand_over_fails_the_lint_is_refused(tmp_path, monkeypat
     monkeypatch.setattr(_lib, 'LIB_PATH', lib)
     with pytest.raises(ImportError, match='failed the code lints'):
         _lib._apply_lint_verdict()
+
+
+def test_the_lint_verdict_travels_inside_the_library(tmp_path, monkeypatch):
+    """Round 6: a caller of the C ABI never reads the record next to the library, so the verdict on the pair blocks is
+    written INTO the file (smart_capi.hip: smart_lint_stamp; smartpy_amd.build stamps what it has linted and found in
+    order).  The library of this tree says so in smart_build_info(); a copy whose stamp is back to 'unchecked' -- what a
+    build by another route carries -- runs its threaded chunks by itself, and the loader, once the lint has looked at
+    that copy's code, gives this process its word for the pair blocks (SMART_PAIR_BLOCKS=1)."""
+    import ctypes
+    from smartpy_amd import _lib
+    assert isa_lint.library_stamp(isa_lint.LIB) == 'pairs-ok'
+    info = ctypes.CDLL(isa_lint.LIB).smart_build_info
+    info.restype = ctypes.c_char_p
+    assert info().decode().endswith('SMART_LINT_STAMP=pairs-ok') and 'ABI 7' in info().decode()
+    # a library that was never stamped (another build route)
+    plain = str(tmp_path / 'libsmart_amd.so')
+    with open(isa_lint.LIB, 'rb') as fh:
+        blob = fh.read()
+    assert blob.count(isa_lint.STAMP_PAIRS_OK) == 1
+    with open(plain, 'wb') as fh:
+        fh.write(blob.replace(isa_lint.STAMP_PAIRS_OK, isa_lint.STAMP_UNCHECKED))
+    assert isa_lint.library_stamp(plain) == 'unchecked'
+    # (in a process of its own: a second copy of the library in this one would register its code objects twice)
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, '-c', 'import ctypes, sys; f = ctypes.CDLL(sys.argv[1]).smart_build_info; '
+                          'f.restype = ctypes.c_char_p; print(f().decode())', plain], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith('SMART_LINT_STAMP=unchecked'), out.stdout + out.stderr
+    # stamping: only a passed lint writes 'pairs-ok'; the stamp is found exactly once
+    assert isa_lint.stamp_library(plain, False) and isa_lint.library_stamp(plain) == 'unchecked'
+    monkeypatch.setattr(_lib, 'LIB_PATH', plain)
+    monkeypatch.delenv('SMART_PAIR_BLOCKS', raising=False)
+    _lib._apply_lint_verdict()              # no record: looks at the code (under the lock), finds the blocks in order
+    assert os.environ['SMART_PAIR_BLOCKS'] == '1' and isa_lint.read_sidecar(plain)['pair_blocks'] is True
+    monkeypatch.delenv('SMART_PAIR_BLOCKS', raising=False)
+    assert isa_lint.stamp_library(plain, True) and isa_lint.library_stamp(plain) == 'pairs-ok'
+    assert not isa_lint.stamp_library(plain, True)          # (nothing left to stamp)
