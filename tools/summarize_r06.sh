@@ -15,11 +15,11 @@ for t in flat_forcing runs_of_6 raw_gap24 gap1; do python $S gpurun_out/prof_r06
 # daily ensembles: the form the library picks (counters), the other form's kernel trace beside it
 python $S gpurun_out/prof_r06_daily_1e4 profiles/r06_daily_1e4 > /dev/null
 python $S gpurun_out/prof_r06_daily_1e5 profiles/r06_daily_1e5 > /dev/null
-python $S gpurun_out/prof_r06_daily_1e6 profiles/r06_daily_1e6 "leg:daily_1e6" > /dev/null
+python $S gpurun_out/prof_r06_daily_1e6 profiles/r06_daily_1e6 > /dev/null
 for t in daily_1e4_lanes daily_1e5_rows daily_1e6_rows; do
   python $S gpurun_out/prof_r06_$t /tmp/r06_$t > /dev/null
   base=${t%_*}; { echo; echo "## the same ensemble with the literal rows in the OTHER form (\`${t##*_}\`): kernel trace only"; echo
-    sed -n '/kernel stats/,/^$/p' /tmp/r06_$t.md | tail -n +2; } >> profiles/r06_$base.md
+    sed -n '/kernel stats/,$p' /tmp/r06_$t.md | sed -n '3,8p'; } >> profiles/r06_$base.md
 done
 for f in r06_daily_form r06_hook_time r06_time_slice_soak; do [ -f gpurun_out/$f.txt ] && cp gpurun_out/$f.txt profiles/; done
 python tools/kernel_hashes.py > profiles/r06_kernel_hashes.txt 2>&1
