@@ -67,13 +67,13 @@ rccl_failure = None
 
 def timeouts():
     """(seconds a host-side collective may wait for a peer, seconds the first device collective may take, seconds RCCL's
-    own watchdog allows a device collective) -- SMART_DIST_TIMEOUT (120), SMART_DIST_PROBE_TIMEOUT (half of it),
+    own watchdog allows a device collective) -- SMART_DIST_TIMEOUT (120), SMART_DIST_PROBE_TIMEOUT (three quarters of it),
     SMART_DIST_RCCL_TIMEOUT (1800).  A rank that never arrives makes its peers RAISE after the first; a first device
     collective that hangs makes every rank fall back to host staging after the second; the third is what torch's watchdog
     ends the process with when a LATER device collective hangs (long on purpose: a communicator that was given up on must
     not take the process down while it works through the host)."""
     host = float(os.environ.get('SMART_DIST_TIMEOUT', '120'))
-    probe = float(os.environ.get('SMART_DIST_PROBE_TIMEOUT', str(host / 2)))
+    probe = float(os.environ.get('SMART_DIST_PROBE_TIMEOUT', str(0.75 * host)))
     return host, probe, float(os.environ.get('SMART_DIST_RCCL_TIMEOUT', '1800'))
 
 
