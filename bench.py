@@ -290,7 +290,7 @@ def timed_launch_parity(so, why_not, job, kind, params_local, forcing_of, area_o
             per_c = max(1, TIMED_ROWS // min(job.n_local, 4))
             got = []
             for c in sorted(rng.choice(job.n_local, size=min(job.n_local, 4), replace=False).tolist()):
-                rows = np.sort(rng.choice(params_local.shape[0], size=per_c, replace=False))
+                rows = np.sort(rng.choice(params_local.shape[0], size=min(per_c, params_local.shape[0]), replace=False))
                 got.append(rows_against_the_oracle(so, res, rows, params_local, forcing_of(lo + c), area_of(lo + c), obs,
                                                    n_warm, gap, dt, catchment=c))
                 n_rows += len(rows)

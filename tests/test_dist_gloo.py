@@ -245,6 +245,9 @@ class _OraclePrepared(object):
     def verify(self):
         return self._last
 
+    def describe(self):
+        return 'oracle stand-in[%d rows]' % len(self.a[0])
+
 
 class _FlakyPrepared(_OraclePrepared):
     """... whose first launch on rank 1 comes back poisoned (a time slice that timed out writes NaN), and whose
@@ -527,3 +530,51 @@ def test_a_rank_out_of_memory_makes_all_eight_raise(tmp_path):
     mp.spawn(_worker_lhs, args=(8, _free_port(), root, True, True, 13, 'oom'), nprocs=8, join=True)
     got = [open(os.path.join(root, 'outcome_r%d.txt' % r)).read() for r in range(8)]
     assert got == ['peer'] * 3 + ['own: HIP out of memory.'] + ['peer'] * 4
+
+
+# ---- bench.py: every rank checks rows of the job it timed (parity.timed_launch) -----------------------------------------
+def _worker_timed_parity(rank, world, port, out_dir):
+    _init(rank, world, port)
+    import bench
+    from oracle import smart_oracle as so
+    from smartpy_amd import distributed as sdist, engine
+    engine.prepare_ensemble = _OraclePrepared
+    C, _, forcing, _, areas, obs, _, _ = _sharded_setup()
+    from oracle import lhs_oracle
+    params = lhs_oracle.lhs_params(150, seed=8)
+    W, gap, dt = 240, 24, 3600.0
+    ok = True
+    # sample axis: 75 rows per rank, 48 of them checked on each
+    job = sdist.ShardedEnsemble(params, forcing[1], float(areas[1]), dt, W, gap, axis='samples', obs=obs[1],
+                                gw_obs=bench.GW_OBS, extra=bench.EXTRA, device='cpu')
+    job.step()
+    lo, hi = sdist.shard_bounds(150, world, rank)
+    args = (job, 'samples', params[lo:hi], lambda c: forcing[1], lambda c: float(areas[1]), obs[1], W, gap, dt)
+    t = bench.timed_launch_parity(so, None, *args)['timed_launch']
+    ok = ok and t['ok'] and t['ranks'] == world and t['rows'] == 48 * world and t['max_rel_discharge'] is None
+    ok = ok and t['max_rel_objfn'] <= 1e-12 and t['max_abs_gw_ratio'] == 0.0 and t['kernel'].startswith('oracle stand-in')
+    # one rank's launch is off by 1e-6 in one groundwater ratio: every rank's line says so, and says not ok
+    if rank == 1:
+        job.prepared.result().gw[:] += 1e-6
+    t = bench.timed_launch_parity(so, None, *args)['timed_launch']
+    ok = ok and not t['ok'] and abs(t['max_abs_gw_ratio'] - 1e-6) < 1e-9 and t['ranks'] == world
+    # a rank without a checker: nobody claims a check that was not made
+    t = bench.timed_launch_parity(so if rank == 0 else None, 'no gcc on this rank', *args)
+    ok = ok and t['timed_launch'] is None and 'no oracle on 1 of %d' % world in t['why']
+    # catchment axis: five catchments over the ranks, up to four of each rank's checked
+    cat = sdist.ShardedEnsemble(params[:20], lambda c: forcing[c], areas, dt, W, gap, axis='catchments', n_catchments=C,
+                                obs=np.tile(obs[1], (C, 1)), gw_obs=bench.GW_OBS, extra=bench.EXTRA, device='cpu')
+    cat.step()
+    t = bench.timed_launch_parity(so, None, cat, 'catchments', params[:20], lambda c: forcing[c],
+                                  lambda c: float(areas[c]), obs[1], W, gap, dt)['timed_launch']
+    ok = ok and t['ok'] and t['ranks'] == world and t['rows'] >= 12 * world and t['max_rel_objfn'] <= 1e-12
+    open(os.path.join(out_dir, 'timed_%d.txt' % rank), 'w').write('ok' if ok else 'FAILED %r' % (t,))
+    dist.destroy_process_group()
+
+
+def test_every_rank_checks_rows_of_its_own_timed_launch(tmp_path):
+    """bench.timed_launch_parity over two ranks, with the launch replaced by the oracle: how many ranks and rows took
+    part, the largest difference over the ranks (a deviation planted on one rank shows on the line of all), a rank
+    without a checker, the catchment axis."""
+    mp.spawn(_worker_timed_parity, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / ('timed_%d.txt' % r)).read() for r in range(2)] == ['ok', 'ok']
