@@ -698,7 +698,12 @@ def main():
                   'launch_ms_per_rank': rank_evidence(device, s_ms)['launch_ms_per_rank']}
         del sjob, p_all
 
-    failed = 0
+    # Every collective of the run lies behind this line: what follows on rank 0 (the legs, the CPU baseline: tens of
+    # seconds of host work) is its own business, and its peers do not wait for it -- a wait would be bounded by the
+    # group's timeout (SMART_DIST_TIMEOUT), and a slow host must not turn into "a peer never arrived".  The verdict of
+    # the timed launch's check is the same number on every rank (a reduction): a failure there is every rank's exit code.
+    sdist.barrier()
+    failed = int(bool(timed.get('timed_launch')) and not timed['timed_launch']['ok'])
     if rank == 0:
         steps_per_run = W + T
         units_per_step = n_runs_total * steps_per_run            # executed sample-timesteps, all ranks, per step
@@ -877,7 +882,7 @@ def main():
             # no checker on this box (no gcc and no built oracle): the throughput line stands, the baseline does not
             line['cpu_baseline'], line['parity'] = None, dict(timed, why='oracle unavailable: %s' % no_oracle)
         else:
-            # rank 0's host cores and rank 0's GPU, whatever the world size (the other ranks wait at the barrier below)
+            # rank 0's host cores and rank 0's GPU, whatever the world size
             line['cpu_baseline'], line['parity'] = cpu_baseline_and_parity(so, forcing, W, gap, dt, device)
             line['parity'].update(timed)
         print(json.dumps(line), flush=True)
@@ -890,9 +895,6 @@ def main():
             sys.stdout.flush()
             sys.stderr.write('bench.py: in-run parity check failed (%s): %r\n' % (', '.join(bad), line['parity']))
             failed = 1
-    # the ranks leave together, with one code: a parity failure anywhere is a non-zero exit everywhere
-    failed = int(sdist.max_over_ranks(float(failed)))
-    sdist.barrier()
     sdist.finish(failed)
     if failed:
         raise SystemExit(failed)
