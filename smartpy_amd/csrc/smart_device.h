@@ -811,7 +811,17 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
         // ill-conditioned rows of config 2 2.97 -> 2.18 ms, the stiff ones 1.62 -> see profiles/r05_config2.md).
         double num1 = 0.0, den1 = 0.0, total1 = 0.0;
         long r1 = 0;
-        if constexpr (kAhead) {
+        // Round 6: the lean report below -- built in round 5 for the row form alone -- for the one-sample-per-lane models
+        // of this loop as well (stiff, guard, the literal rows' lane form): their lanes beyond the batch carry the last
+        // sample (lane_ctx) and store its value to its address, the same bits.  Same-box A/B, every output bit equal
+        // (profiles/r06_ab_lean_every.txt): smart_fast_stiff 1.30 -> 1.12 ms on config 2's stiff rows (21 scalar
+        // instructions and 6 branches a step beside 85 vector ones before), smart_fast_illcond_lanes 4.12 -> 3.95 ms,
+        // the daily ensemble of 1e6 samples 11.28 -> 10.97 ms.  SMART_LEAN_EVERY=0 builds the old form (A/B).
+#ifndef SMART_LEAN_EVERY
+#define SMART_LEAN_EVERY 1
+#endif
+        constexpr bool kLean = kAhead || (SMART_LEAN_EVERY && !Model::kBalanceSums);
+        if constexpr (kLean) {
             // The row form's wavefront is alone on its SIMD: every instruction of the report is four to five cycles of
             // the step.  The PMC counters of config 2 (profiles/r05_config2.md) had 54 scalar instructions per wave-step
             // beside 152 vector ones; the report's share of them was the observation's index clamp and address (14), the
@@ -831,12 +841,12 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
             long stride; // the matrix's row stride in a VECTOR register pair: as a kernel argument it lives in a spilled scalar
                          // tuple, which hipcc reads back with eight v_readlane per step to get at these two
             asm volatile("v_mov_b64 %0, %1" : "=v"(stride) : "s"(a.ld));
-            auto step_and_report = [&](const double2 v, auto first) {
+            auto step_and_report = [&](const double2 v, const double ex, auto first) {
                 const double e = *pe, w = *pw;
                 pe += inc;
                 pw += inc;
                 double sink = 0.0;
-                m.step(v.x, v.y, 0.0, sink, num1, den1);
+                m.step(v.x, v.y, ex, sink, num1, den1); // (ex: the fast models' excess, worked out ahead by time_loop)
                 // summary: the mean over one step is (0.0 + q) / 1; raw: q itself.  One addition for both: x + (-0.0) is x
                 // for every x, the zeros and a NaN included
                 const double val = m.q_out + zero;
@@ -863,8 +873,9 @@ __device__ __forceinline__ void run_ensemble(const KArgs &a, const double2 *__re
                 }
             };
             if (a.T > 0) {
-                time_loop(m, f, 1, [&](const double2 v, const double) { step_and_report(v, std::true_type()); });
-                time_loop(m, f + 1, a.T - 1, [&](const double2 v, const double) { step_and_report(v, std::false_type()); });
+                time_loop(m, f, 1, [&](const double2 v, const double ex) { step_and_report(v, ex, std::true_type()); });
+                time_loop(m, f + 1, a.T - 1,
+                          [&](const double2 v, const double ex) { step_and_report(v, ex, std::false_type()); });
             }
             write_results(a, x, m, rep, num1 / den1, nullptr);
             return;
