@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from smartpy_amd import engine
 import test_gpu_parity as t
-t.EXCESS_GATE = 1.0
+t.EXCESS_GATE = t.FUZZ_GATE = 1.0        # (the randomized families read FUZZ_GATE: round 5)
 setenv = lambda k, v: os.environ.__setitem__(k, str(v)) if v else os.environ.pop(k, None)     # noqa: E731
 for seed in (int(a) for a in sys.argv[1:]):
     t.MARGINS.clear()
