@@ -79,6 +79,7 @@ def main():
     if rank == 0:
         print('GLUE: %d behavioural sets -> %s' % (len(glue.behavioural_params), glue.db_file))
         print('Best: 10 best KGE among the sets meeting the groundwater constraint -> %s' % top.db_file)
+    distributed.finish()        # (several ranks: leave the process group -- without waiting for a communicator that never answered)
 
 
 if __name__ == '__main__':
