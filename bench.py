@@ -461,7 +461,10 @@ def daily_leg(so, n, device, steps, from_fixture=False):
                    'objective functions fused, discharge not stored' % (n, T, W),
            'kernel': prep.describe(), 'launch_ms': ms, 'value': n * (T + W) / (ms * 1e-3), 'unit': 'sample-timesteps/s',
            'steps': steps, 'rows_per_class': {'regular': int((cls == 0).sum()), 'stiff': int((cls == 1).sum()),
-                                              'guard': int((cls == 2).sum()), 'literal': int((cls == 3).sum())}}
+                                              'guard': int((cls == 2).sum()), 'literal': int((cls == 3).sum())},
+           # the launch is three kernels side by side: their vector instructions summed (tools/daily_roofline.py, from the
+           # committed PMC passes of this workload) x 4 issue cycles over the SIMD cycles of this run's launch
+           'roofline': leg_roofline('daily_%s' % ('1e6' if n == 1000000 else n), ms)}
     if so is not None:
         pick = np.random.default_rng(61)
         rows = np.sort(np.concatenate([pick.choice(np.nonzero(cls == c)[0], size=min(16, int((cls == c).sum())),

@@ -54,7 +54,10 @@ def test_pmc_figures_are_only_quoted_for_the_code_they_were_measured_on(tmp_path
     committed = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_latest.json')))
     assert key in committed['workloads'] and len(bench.kernel_source_hash()) == 16
     for entry in committed['workloads'].values():
-        assert 0 < entry['issue_frac_at_held_clock'] <= 1.0 and entry['valu_insts_per_launch'] > 0
+        # (a launch of several kernels side by side -- the daily leg -- carries the summed count and no fraction "at the
+        # clock held": the counter passes serialise its kernels, tools/daily_roofline.py)
+        held = entry['issue_frac_at_held_clock']
+        assert (held is None or 0 < held <= 1.0) and entry['valu_insts_per_launch'] > 0
 
 
 def test_bench_started_bare_with_gpus_2_starts_its_own_ranks():
@@ -127,7 +130,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     dy = d['daily_1e6']
     assert 'smart_fast_illcond_lanes[' in dy['kernel'] and 'smart_fast_stiff' in dy['kernel']
     assert dy['parity']['ok'] and dy['parity']['rows'] == 48 and dy['rows_per_class']['literal'] > 100000
-    assert dy['value'] > 1.5e11
+    assert dy['value'] > 1.5e11 and 'roofline' in dy          # (its issue fraction only for the profiled kernel build)
     assert 'smart_fast_intervals' in d['objectives_only']['kernel'] and d['objectives_only']['value'] > 0.9 * d['value']
     f = d['flat_forcing']
     assert 'smart_fast_steps' in f['kernel'] and 0 < f['value'] < d['value'] * 1.05

@@ -21,6 +21,10 @@ for t in daily_1e4_lanes daily_1e5_rows daily_1e6_rows; do
   base=${t%_*}; { echo; echo "## the same ensemble with the literal rows in the OTHER form (\`${t##*_}\`): kernel trace only"; echo
     sed -n '/kernel stats/,$p' /tmp/r06_$t.md | sed -n '3,8p'; } >> profiles/r06_$base.md
 done
+# a daily launch is three kernels side by side: their instructions summed against the issue roof (and the bench leg's key)
+python tools/daily_roofline.py gpurun_out/prof_r06_daily_1e4 profiles/r06_daily_1e4 > /dev/null
+python tools/daily_roofline.py gpurun_out/prof_r06_daily_1e5 profiles/r06_daily_1e5 > /dev/null
+python tools/daily_roofline.py gpurun_out/prof_r06_daily_1e6 profiles/r06_daily_1e6 "leg:daily_1e6" > /dev/null
 for f in r06_daily_form r06_hook_time r06_time_slice_soak; do [ -f gpurun_out/$f.txt ] && cp gpurun_out/$f.txt profiles/; done
 python tools/kernel_hashes.py > profiles/r06_kernel_hashes.txt 2>&1
 for c in "" _c2 _c4 _c5 _c4shard; do grep '^{' gpurun_out/bench_r06$c.log > profiles/r06_bench_${c#_}.jsonl; done
