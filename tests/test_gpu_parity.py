@@ -660,6 +660,53 @@ def test_config4_size_one_million_samples(eng):
     assert rel(gw[rows], gwo) < 1e-10
 
 
+def test_daily_ensemble_of_one_million_samples(eng):
+    """Round 6: the size the literal rows' lane form exists for -- 1e6 LHS samples x ten years of DAILY steps on one GPU
+    (bench.py's `daily_1e6` leg), three kernels side by side: 685,000 regular rows, 199,000 stiff ones, 116,000 of the
+    literal class on smart_fast_illcond_lanes.  (i) a row's results do not depend on its neighbours: a 125,000-row block of
+    the matrix run on its own (one rank's shard on 8 GPUs: other wavefront compositions, still the lane form) and a
+    30,000-row block (few enough class-3 blocks for the ROW form of their kernel) give the same bits;
+    (ii) 64 rows, sixteen of every class, against the oracle: the literal rows' groundwater ratios bit for bit, every
+    row's objective functions; (iii) physical ranges."""
+    import torch
+    import bench
+    N = 1000000
+    params = lhs_oracle.lhs_params(N, seed=4242)
+    f, rng = bench.synthetic_forcing(0, hourly=False)
+    T, W = f.shape[0], 365
+    obs = np.abs(rng.normal(2.0, 1.0, T))
+    obs[rng.random(T) < 0.12] = np.nan
+    dev_p = torch.from_numpy(params).cuda()
+    kw = dict(extra=bench.EXTRA, obs=obs, gw_obs=0.12667, want_discharge=False)
+    out = eng.run_ensemble(dev_p, f, bench.AREA, 86400.0, W, 1, **kw)
+    text = out._prepared.describe()
+    assert 'smart_fast_illcond_lanes[' in text and 'smart_fast_stiff' in text and 'smart_fast_steps_every[8 slices' in text
+    gw, obj = out.gw.cpu().numpy(), out.objfn.cpu().numpy()
+    assert np.all(np.isfinite(obj[:, :7])) and np.all((gw >= 0) & (gw <= 1)) and np.all(obj[:, 0] <= 1)
+    for lo, hi, kernel in ((375000, 500000, 'smart_fast_illcond_lanes['), (40000, 70000, 'smart_fast_illcond[')):
+        part = eng.run_ensemble(dev_p[lo:hi].contiguous(), f, bench.AREA, 86400.0, W, 1, **kw)
+        assert kernel in part._prepared.describe(), part._prepared.describe()
+        assert torch.equal(part.gw, out.gw[lo:hi])
+        # (the fused moments of a class-3 row are the report's arithmetic, which the two forms of its kernel round
+        # differently -- test_the_two_forms...: compared to 1e-9; every other row, and every ratio: the same bits)
+        cls3 = params[lo:hi, 9] * 3600.0 < 43200.0
+        a, b = part.objfn.cpu().numpy(), obj[lo:hi]
+        assert bits_equal(a[~cls3], b[~cls3]) and rel(a[cls3, :7], b[cls3, :7], floor=1e-12) <= 1e-9
+    cls = eng.variant_classes(torch.from_numpy(params), 86400.0).numpy()
+    pick = np.random.default_rng(12)
+    rows = np.sort(np.concatenate([pick.choice(np.nonzero(cls == c)[0], 16, replace=False) for c in (0, 1, 3)]
+                                  + [pick.choice(N, 16, replace=False)]))
+    dis, gwo, _ = so.run_batch(bench.AREA, 86400.0, T, W, f[:, 0].copy(), f[:, 1].copy(), params[rows], bench.EXTRA,
+                               so.REPORT_SUMMARY, 1)
+    want = objfn_oracle.objective_matrix(dis, obs, gwo, 0.12667)
+    assert rel(obj[rows, :7], want[:, :7]) < 1e-8 and np.array_equal(obj[rows, 7], want[:, 7])
+    assert rel(gw[rows], gwo) < 1e-9
+    lit = cls[rows] == 3
+    d3, g3, _ = so.run_batch(bench.AREA, 86400.0, T, W, f[:, 0].copy(), f[:, 1].copy(), params[rows][lit], bench.EXTRA,
+                             so.REPORT_SUMMARY, 1, pow_mode=so.POW_MUL, sum_mode=so.SUM_SEQ)
+    assert bits_equal(gw[rows][lit], g3)
+
+
 def _synthetic_forcing(catchment, hourly):
     """seeded synthetic daily rain / PE, hourly = daily / 24 repeated."""
     rng = np.random.default_rng(12345 + catchment)
